@@ -1,0 +1,665 @@
+/*
+ * twx_oracle.c -- CPU restatement of the TopoWx interpolation hot path.
+ * TEST INFRASTRUCTURE ONLY (see twx_oracle.h for the parity status of each
+ * part; the universal-kriging solve is PARITY UNPINNED).
+ *
+ * Written from the behaviour of the reference (file:line cited per function,
+ * relative to /root/reference) and, for the kriging solve, from the published
+ * gstat / sp algorithm.  Plain C99, fp64 throughout.
+ */
+#define _GNU_SOURCE
+#include "twx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RADIAN_CONVERSION_FACTOR 0.017453292519943295 /* util_geo.py:21 */
+#define AVG_EARTH_RADIUS_KM 6371.009                  /* util_geo.py:22 */
+#define ORC_MAXK 512
+
+/* ---------------------------------------------------------------- a1 ---- */
+/* util_geo.py:24-40: haversine on the IUGG mean sphere, same operation order. */
+double orc_grt_circle_dist(double lon1, double lat1, double lon2, double lat2)
+{
+    double lat1rad = lat1 * RADIAN_CONVERSION_FACTOR;
+    double lat2rad = lat2 * RADIAN_CONVERSION_FACTOR;
+    double lon1rad = lon1 * RADIAN_CONVERSION_FACTOR;
+    double lon2rad = lon2 * RADIAN_CONVERSION_FACTOR;
+    double dlat = lat1rad - lat2rad;
+    double dlon = lon1rad - lon2rad;
+    double s1 = sin(dlat / 2), s2 = sin(dlon / 2);
+    double ca = 2 * asin(sqrt(s1 * s1 + cos(lat1rad) * cos(lat2rad) * (s2 * s2)));
+    return AVG_EARTH_RADIUS_KM * ca;
+}
+
+/* Appendix B.1: sp / gstat great-circle distance on the WGS84 ellipsoid
+ * (Andoyer-Lambert form, km).  Reached because the data carry a longlat CRS
+ * (interp.R:218-221).  [upstream-recall: parity unpinned] */
+double orc_ellip_dist(double lon1, double lat1, double lon2, double lat2)
+{
+    const double a = 6378.137, f = 1.0 / 298.257223563;
+    const double eps = 2.220446049250313e-16;
+    if (fabs(lat1 - lat2) < eps) {
+        if (fabs(lon1 - lon2) < eps)
+            return 0.0;
+        if (fabs((fabs(lon1) + fabs(lon2)) - 360.0) < eps)
+            return 0.0;
+    }
+    double de2ra = M_PI / 180.0;
+    double lat1r = lat1 * de2ra, lat2r = lat2 * de2ra;
+    double lon1r = lon1 * de2ra, lon2r = lon2 * de2ra;
+    double F = (lat1r + lat2r) / 2.0, G = (lat1r - lat2r) / 2.0, L = (lon1r - lon2r) / 2.0;
+    double sinG2 = sin(G) * sin(G), cosG2 = cos(G) * cos(G);
+    double sinF2 = sin(F) * sin(F), cosF2 = cos(F) * cos(F);
+    double sinL2 = sin(L) * sin(L), cosL2 = cos(L) * cos(L);
+    double S = sinG2 * cosL2 + cosF2 * sinL2;
+    double C = cosG2 * cosL2 + sinF2 * sinL2;
+    double w = atan(sqrt(S / C));
+    double R = sqrt(S * C) / w;
+    double D = 2 * w * a;
+    double H1 = (3 * R - 1) / (2 * C);
+    double H2 = (3 * R + 1) / (2 * S);
+    return D * (1 + f * H1 * sinF2 * cosG2 - f * H2 * cosF2 * sinG2);
+}
+
+/* ---------------------------------------------------------------- a2 ---- */
+typedef struct { double d; int32_t i; } di_t;
+
+static int di_less(const di_t *a, const di_t *b)
+{
+    return a->d < b->d || (a->d == b->d && a->i < b->i);
+}
+
+static void heap_sift_down(di_t *h, int64_t n, int64_t i)
+{
+    for (;;) {
+        int64_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && di_less(&h[m], &h[l])) m = l;
+        if (r < n && di_less(&h[m], &h[r])) m = r;
+        if (m == i) return;
+        di_t t = h[i]; h[i] = h[m]; h[m] = t;
+        i = m;
+    }
+}
+
+static int di_cmp(const void *a, const void *b)
+{
+    const di_t *x = a, *y = b;
+    return di_less(x, y) ? -1 : (di_less(y, x) ? 1 : 0);
+}
+
+/* station_select.py:72-119: distances to ALL stations, ordered ascending,
+ * excluded ids (and, if rm_zero_dist, zero-distance stations) dropped after the
+ * sort.  Only the first ksel entries are ever read (station_select.py:164-166),
+ * so a bounded max-heap replaces the full argsort; ties (undefined under the
+ * reference's unstable argsort, :111) break on the smaller station index. */
+int64_t orc_nearest(const orc_db *db, double lat, double lon, int32_t excl,
+                    int rm_zero_dist, int64_t ksel, int32_t *idx, double *dist)
+{
+    if (ksel > db->n) ksel = db->n;
+    if (ksel <= 0) return 0;
+    di_t *h = malloc(sizeof(di_t) * (size_t)ksel);
+    int64_t nh = 0;
+    for (int64_t j = 0; j < db->n; ++j) {
+        if (j == excl) continue;
+        double d = orc_grt_circle_dist(lon, lat, db->lon[j], db->lat[j]);
+        if (rm_zero_dist && d == 0.0) continue;
+        di_t e = { d, (int32_t)j };
+        if (nh < ksel) {
+            h[nh++] = e;
+            if (nh == ksel)
+                for (int64_t i = nh / 2 - 1; i >= 0; --i) heap_sift_down(h, nh, i);
+        } else if (di_less(&e, &h[0])) {
+            h[0] = e;
+            heap_sift_down(h, nh, 0);
+        }
+    }
+    qsort(h, (size_t)nh, sizeof(di_t), di_cmp);
+    for (int64_t i = 0; i < nh; ++i) { idx[i] = h[i].i; dist[i] = h[i].d; }
+    free(h);
+    return nh;
+}
+
+static int i32_cmp_perm(const void *a, const void *b)
+{
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* station_select.py:121-192: k nearest, bandwidth = distance of the (k+1)-th
+ * (:164), bisquare weights (:169), re-ordered by ascending station id (:179-182;
+ * the table is id-sorted so index order == id order). */
+int orc_select(const int32_t *near_idx, const double *near_dist, int64_t nnear,
+               int k, int32_t *idx, double *dist, double *wgt)
+{
+    if (k < 0 || k >= nnear) return ORC_ERR_FEW_STATIONS; /* IndexError at :164 */
+    double dbw = near_dist[k];
+    if (!(dbw > 0.0)) return ORC_ERR_NUMERIC;             /* 0/0 or x/0 -> FloatingPointError */
+    /* sort positions by station index */
+    int32_t key[ORC_MAXK][2];
+    if (k > ORC_MAXK) return ORC_ERR_RANGE;
+    for (int i = 0; i < k; ++i) { key[i][0] = near_idx[i]; key[i][1] = i; }
+    qsort(key, (size_t)k, sizeof(key[0]), i32_cmp_perm);
+    for (int i = 0; i < k; ++i) {
+        int p = key[i][1];
+        double r = near_dist[p] / dbw;
+        double t = 1.0 - r * r;
+        idx[i] = near_idx[p];
+        dist[i] = near_dist[p];
+        wgt[i] = t * t;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------- a3, a4 ---- */
+/* interp_tair.py:821-835 (and :245-259): weighted mean of the neighbours'
+ * optimal bandwidth over finite entries, np.round (half-even) -> int. */
+int orc_smooth_nnghs(const double *optim_m, const int32_t *idx, const double *wgt,
+                     int k, int *nnghs)
+{
+    double num = 0.0, den = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < k; ++i) {
+        double v = optim_m[idx[i]];
+        if (isfinite(v)) { num += v * wgt[i]; den += wgt[i]; ++cnt; }
+    }
+    if (cnt == 0) return ORC_ERR_NNGHS;
+    if (!(den != 0.0)) return ORC_ERR_NUMERIC; /* np.average: weights sum to zero */
+    *nnghs = (int)nearbyint(num / den);
+    return ORC_OK;
+}
+
+/* interp_tair.py:837-851: weighted means over neighbours with finite nugget. */
+int orc_smooth_vario(const double *nug_m, const double *psill_m, const double *rng_m,
+                     const int32_t *idx, const double *wgt, int k, double vario[3])
+{
+    double sn = 0, sp = 0, sr = 0, den = 0;
+    int cnt = 0;
+    for (int i = 0; i < k; ++i) {
+        int32_t j = idx[i];
+        if (isfinite(nug_m[j])) {
+            sn += nug_m[j] * wgt[i]; sp += psill_m[j] * wgt[i]; sr += rng_m[j] * wgt[i];
+            den += wgt[i]; ++cnt;
+        }
+    }
+    if (cnt == 0) return ORC_ERR_VARIO;
+    if (!(den != 0.0)) return ORC_ERR_NUMERIC;
+    vario[0] = sn / den; vario[1] = sp / den; vario[2] = sr / den;
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- a5 ---- */
+/* in-place lower Cholesky of a dense n x n (row-major, ld = n) */
+static int chol_lower(double *A, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int p = 0; p < j; ++p) s -= A[j * n + p] * A[j * n + p];
+        if (!(s > 0.0) || !isfinite(s)) return 1;
+        double ljj = sqrt(s);
+        A[j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            for (int p = 0; p < j; ++p) t -= A[i * n + p] * A[j * n + p];
+            A[i * n + j] = t / ljj;
+        }
+    }
+    return 0;
+}
+
+static void fwd_solve(const double *L, int n, double *b)
+{
+    for (int i = 0; i < n; ++i) {
+        double t = b[i];
+        for (int p = 0; p < i; ++p) t -= L[i * n + p] * b[p];
+        b[i] = t / L[i * n + i];
+    }
+}
+
+static void bwd_solve_t(const double *L, int n, double *b)
+{
+    for (int i = n - 1; i >= 0; --i) {
+        double t = b[i];
+        for (int p = i + 1; p < n; ++p) t -= L[p * n + i] * b[p];
+        b[i] = t / L[i * n + i];
+    }
+}
+
+/* Covariance of the variogram model of interp.R:223-231 (Appendix B.2):
+ * Exp(nug, psill, range): c(h>0) = psill exp(-h/range), c(0) = nug + psill;
+ * range == 0 -> pure nugget of variance psill + nug. */
+static double cov_model(double h, double nug, double psill, double rng)
+{
+    if (h == 0.0) return nug + psill;
+    if (rng == 0.0) return 0.0;
+    return psill * exp(-h / rng);
+}
+
+/* interp.R:198-270 -> gstat::krige(tair ~ lon+lat+elev+lst, model) with a
+ * global neighbourhood of exactly the k stations passed (Appendix B.2):
+ *   beta = (X'C^-1 X)^-1 X'C^-1 y
+ *   mean = x0'beta + c0'C^-1 (y - X beta)
+ *   var  = c(0) - c0'C^-1 c0 + (x0 - X'C^-1 c0)' (X'C^-1 X)^-1 (x0 - X'C^-1 c0)
+ * The four trend columns are centred and scaled per neighbourhood; universal
+ * kriging is invariant to that re-parameterisation (the basis keeps the
+ * intercept) and it keeps the 5x5 normal matrix well conditioned.
+ * [parity unpinned: gstat is not runnable here] */
+int orc_uk(int k, const double *lon, const double *lat, const double *elev,
+           const double *lst, const double *y, double plon, double plat,
+           double pelev, double plst, double nug, double psill, double rng,
+           double *mean, double *var)
+{
+    enum { P = 5 };
+    if (k < 1) return ORC_ERR_RANGE;
+    if (!isfinite(nug) || !isfinite(psill) || !isfinite(rng)) return ORC_ERR_NUMERIC;
+    double *C = malloc(sizeof(double) * (size_t)k * k);
+    double *A = malloc(sizeof(double) * (size_t)k * (P + 2)); /* cols: X(5), y, c0 */
+    const double *cols[4] = { lon, lat, elev, lst };
+    double p0[4] = { plon, plat, pelev, plst };
+    double x0[P];
+    int rc = ORC_OK;
+
+    for (int i = 0; i < k; ++i) {
+        C[i * k + i] = nug + psill;
+        for (int j = 0; j < i; ++j) {
+            double h = orc_ellip_dist(lon[i], lat[i], lon[j], lat[j]);
+            C[i * k + j] = C[j * k + i] = cov_model(h, nug, psill, rng);
+        }
+    }
+    x0[0] = 1.0;
+    for (int i = 0; i < k; ++i) A[i * (P + 2)] = 1.0;
+    for (int c = 0; c < 4; ++c) {
+        double mu = 0, sc = 0;
+        for (int i = 0; i < k; ++i) mu += cols[c][i];
+        mu /= k;
+        for (int i = 0; i < k; ++i) { double t = fabs(cols[c][i] - mu); if (t > sc) sc = t; }
+        if (!(sc > 0.0)) sc = 1.0; /* constant column: left collinear -> singular below */
+        for (int i = 0; i < k; ++i) A[i * (P + 2) + 1 + c] = (cols[c][i] - mu) / sc;
+        x0[1 + c] = (p0[c] - mu) / sc;
+    }
+    for (int i = 0; i < k; ++i) {
+        A[i * (P + 2) + P] = y[i];
+        double h = orc_ellip_dist(plon, plat, lon[i], lat[i]);
+        A[i * (P + 2) + P + 1] = cov_model(h, nug, psill, rng);
+    }
+    if (chol_lower(C, k)) { rc = ORC_ERR_NUMERIC; goto done; }
+    /* A <- L^-1 A (all 7 columns) */
+    for (int i = 0; i < k; ++i) {
+        for (int c = 0; c < P + 2; ++c) {
+            double t = A[i * (P + 2) + c];
+            for (int p = 0; p < i; ++p) t -= C[i * k + p] * A[p * (P + 2) + c];
+            A[i * (P + 2) + c] = t / C[i * k + i];
+        }
+    }
+    {
+        double N[P * P], r[P], q[P], gg = 0, gb = 0;
+        memset(N, 0, sizeof N); memset(r, 0, sizeof r); memset(q, 0, sizeof q);
+        for (int i = 0; i < k; ++i) {
+            const double *a = &A[i * (P + 2)];
+            for (int c = 0; c < P; ++c) {
+                for (int d = 0; d <= c; ++d) N[c * P + d] += a[c] * a[d];
+                r[c] += a[c] * a[P];
+                q[c] += a[c] * a[P + 1];
+            }
+            gg += a[P + 1] * a[P + 1];
+            gb += a[P + 1] * a[P];
+        }
+        for (int c = 0; c < P; ++c) for (int d = c + 1; d < P; ++d) N[c * P + d] = N[d * P + c];
+        if (chol_lower(N, P)) { rc = ORC_ERR_NUMERIC; goto done; }
+        double beta[P], u[P];
+        memcpy(beta, r, sizeof r);
+        fwd_solve(N, P, beta); bwd_solve_t(N, P, beta);
+        for (int c = 0; c < P; ++c) u[c] = x0[c] - q[c];
+        double m = gb, v;
+        for (int c = 0; c < P; ++c) m += u[c] * beta[c]; /* x0'b + g'(b - A beta) */
+        fwd_solve(N, P, u);
+        v = (nug + psill) - gg;
+        for (int c = 0; c < P; ++c) v += u[c] * u[c];
+        if (!isfinite(m) || !isfinite(v)) { rc = ORC_ERR_NUMERIC; goto done; }
+        *mean = m; *var = v;
+    }
+done:
+    free(C); free(A);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- a7 ---- */
+/* interp_tair.py:1099-1146 (_gwr_series): z = x' (X'WX)^-1 X'W with
+ * X = [1 | model_x].  The reference inverts the raw 6x6 with np.linalg.inv
+ * (:1136); here the five predictor columns are centred / scaled first (z is
+ * invariant to it) and the SPD system is solved by Cholesky. */
+int orc_gwr_hat(int k, const double *X5, const double *w, const double *x5, double *z)
+{
+    enum { P = 6 };
+    double mu[5], sc[5], x0[P], M[P * P], a[P];
+    if (k < 1) return ORC_ERR_RANGE;
+    for (int c = 0; c < 5; ++c) {
+        double m = 0, s = 0;
+        for (int i = 0; i < k; ++i) m += X5[i * 5 + c];
+        m /= k;
+        for (int i = 0; i < k; ++i) { double t = fabs(X5[i * 5 + c] - m); if (t > s) s = t; }
+        if (!(s > 0.0)) s = 1.0;
+        mu[c] = m; sc[c] = s;
+        x0[1 + c] = (x5[c] - m) / s;
+    }
+    x0[0] = 1.0;
+    memset(M, 0, sizeof M);
+    for (int i = 0; i < k; ++i) {
+        double r[P];
+        r[0] = 1.0;
+        for (int c = 0; c < 5; ++c) r[1 + c] = (X5[i * 5 + c] - mu[c]) / sc[c];
+        for (int c = 0; c < P; ++c)
+            for (int d = 0; d <= c; ++d) M[c * P + d] += w[i] * r[c] * r[d];
+    }
+    for (int c = 0; c < P; ++c) for (int d = c + 1; d < P; ++d) M[c * P + d] = M[d * P + c];
+    if (chol_lower(M, P)) return ORC_ERR_NUMERIC;
+    memcpy(a, x0, sizeof a);
+    fwd_solve(M, P, a); bwd_solve_t(M, P, a);
+    for (int i = 0; i < k; ++i) {
+        double t = a[0];
+        for (int c = 0; c < 5; ++c) t += a[1 + c] * ((X5[i * 5 + c] - mu[c]) / sc[c]);
+        z[i] = w[i] * t;
+        if (!isfinite(z[i])) return ORC_ERR_NUMERIC;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------ orchestration ---- */
+static int db_kmax(const orc_db *db)
+{
+    double m = 0;
+    for (int64_t i = 0; i < 12 * db->n; ++i) {
+        if (isfinite(db->optim_nnghs[i]) && db->optim_nnghs[i] > m) m = db->optim_nnghs[i];
+        if (isfinite(db->optim_nnghs_anom[i]) && db->optim_nnghs_anom[i] > m) m = db->optim_nnghs_anom[i];
+    }
+    return (int)nearbyint(m);
+}
+
+/* nearest-station list of one (point, variable): computed once and reused by
+ * all months, as the reference's point cache does (station_select.py:62-119) */
+typedef struct {
+    int32_t idx[ORC_MAXK + 1];
+    double dist[ORC_MAXK + 1];
+    int64_t n;
+} near_t;
+
+static int krig_with_near(const orc_db *db, const orc_params *p, const orc_pt *pt,
+                          const near_t *nr, int mth, int nnghs, const double *vario,
+                          double *mean, double *var, int *nnghs_used, int32_t *ngh_idx)
+{
+    int32_t idx[ORC_MAXK]; double dist[ORC_MAXK], wgt[ORC_MAXK];
+    int m0 = mth - 1, rc;
+    int64_t n = db->n;
+    if (nnghs <= 0) { /* interp_tair.py:888-890 -> :821-835 */
+        rc = orc_select(nr->idx, nr->dist, nr->n, p->init_nnghs, idx, dist, wgt);
+        if (rc) return rc;
+        rc = orc_smooth_nnghs(db->optim_nnghs + m0 * n, idx, wgt, p->init_nnghs, &nnghs);
+        if (rc) return rc;
+    }
+    if (nnghs < 1 || nnghs > ORC_MAXK) return ORC_ERR_RANGE;
+    rc = orc_select(nr->idx, nr->dist, nr->n, nnghs, idx, dist, wgt); /* :892 */
+    if (rc) return rc;
+    double vp[3];
+    if (vario == NULL) { /* :894-895 */
+        rc = orc_smooth_vario(db->vario_nug + m0 * n, db->vario_psill + m0 * n,
+                              db->vario_rng + m0 * n, idx, wgt, nnghs, vp);
+        if (rc) return rc;
+    } else {
+        vp[0] = vario[0]; vp[1] = vario[1]; vp[2] = vario[2];
+    }
+    double lo[ORC_MAXK], la[ORC_MAXK], el[ORC_MAXK], ls[ORC_MAXK], y[ORC_MAXK];
+    for (int i = 0; i < nnghs; ++i) { /* :899-906 */
+        int32_t j = idx[i];
+        lo[i] = db->lon[j]; la[i] = db->lat[j]; el[i] = db->elev[j];
+        ls[i] = db->lst[m0 * n + j]; y[i] = db->norm[m0 * n + j];
+    }
+    if (nnghs_used) *nnghs_used = nnghs;
+    if (ngh_idx) memcpy(ngh_idx, idx, sizeof(int32_t) * (size_t)nnghs);
+    return orc_uk(nnghs, lo, la, el, ls, y, pt->lon, pt->lat, pt->elev, pt->lst[m0],
+                  vp[0], vp[1], vp[2], mean, var);
+}
+
+static int gwr_with_near(const orc_db *db, const orc_params *p, const orc_pt *pt,
+                         double pt_norm, const near_t *nr, int mth, int nnghs,
+                         double *out, int scatter, int *nnghs_used, double *z_out,
+                         int32_t *ngh_idx)
+{
+    int32_t idx[ORC_MAXK]; double dist[ORC_MAXK], wgt[ORC_MAXK], z[ORC_MAXK];
+    double X5[ORC_MAXK * 5], x5[5];
+    int m0 = mth - 1, rc;
+    int64_t n = db->n;
+    if (nnghs <= 0) { /* interp_tair.py:290-293 -> :245-259 */
+        rc = orc_select(nr->idx, nr->dist, nr->n, p->init_nnghs, idx, dist, wgt);
+        if (rc) return rc;
+        rc = orc_smooth_nnghs(db->optim_nnghs_anom + m0 * n, idx, wgt, p->init_nnghs, &nnghs);
+        if (rc) return rc;
+    }
+    if (nnghs < 1 || nnghs > ORC_MAXK) return ORC_ERR_RANGE;
+    rc = orc_select(nr->idx, nr->dist, nr->n, nnghs, idx, dist, wgt); /* :295 */
+    if (rc) return rc;
+    for (int i = 0; i < nnghs; ++i) { /* :303-304, GWR_TREND_VARS :47 */
+        int32_t j = idx[i];
+        X5[i * 5 + 0] = db->lon[j]; X5[i * 5 + 1] = db->lat[j]; X5[i * 5 + 2] = db->elev[j];
+        X5[i * 5 + 3] = db->tdi[j]; X5[i * 5 + 4] = db->lst[m0 * n + j];
+    }
+    x5[0] = pt->lon; x5[1] = pt->lat; x5[2] = pt->elev; x5[3] = pt->tdi; x5[4] = pt->lst[m0];
+    rc = orc_gwr_hat(nnghs, X5, wgt, x5, z);
+    if (rc) return rc;
+    if (nnghs_used) *nnghs_used = nnghs;
+    if (z_out) memcpy(z_out, z, sizeof(double) * (size_t)nnghs);
+    if (ngh_idx) memcpy(ngh_idx, idx, sizeof(int32_t) * (size_t)nnghs);
+    if (out == NULL) return ORC_OK;
+    /* :300, :1143, :312 -- obs is f4, promoted to f8 by the subtraction */
+    int64_t o = 0;
+    for (int64_t d = 0; d < db->ndays; ++d) {
+        if (db->day_month[d] != mth) continue;
+        const float *row = db->obs + d * n;
+        double s = 0.0;
+        for (int i = 0; i < nnghs; ++i)
+            s += z[i] * ((double)row[idx[i]] - db->norm[m0 * n + idx[i]]);
+        s += pt_norm;
+        if (!isfinite(s)) return ORC_ERR_NUMERIC;
+        if (scatter) out[d] = s; else out[o++] = s;
+    }
+    return ORC_OK;
+}
+
+static int64_t pick_ksel(const orc_db *db, const orc_params *p, int nnghs)
+{
+    int km = nnghs > 0 ? nnghs : db_kmax(db);
+    if (km < p->init_nnghs) km = p->init_nnghs;
+    if (km > ORC_MAXK) km = ORC_MAXK;
+    return km + 1;
+}
+
+int orc_krig(const orc_db *db, const orc_params *p, const orc_pt *pt, int mth,
+             int nnghs, const double *vario, int32_t excl, int rm_zero_dist,
+             double *mean, double *var, int *nnghs_used, int32_t *ngh_idx)
+{
+    near_t nr;
+    nr.n = orc_nearest(db, pt->lat, pt->lon, excl, rm_zero_dist, pick_ksel(db, p, nnghs),
+                       nr.idx, nr.dist);
+    return krig_with_near(db, p, pt, &nr, mth, nnghs, vario, mean, var, nnghs_used, ngh_idx);
+}
+
+int orc_gwr_mth(const orc_db *db, const orc_params *p, const orc_pt *pt,
+                double pt_norm, int mth, int nnghs, int32_t excl, int rm_zero_dist,
+                double *out, int *nnghs_used, double *z, int32_t *ngh_idx)
+{
+    near_t nr;
+    nr.n = orc_nearest(db, pt->lat, pt->lon, excl, rm_zero_dist, pick_ksel(db, p, nnghs),
+                       nr.idx, nr.dist);
+    return gwr_with_near(db, p, pt, pt_norm, &nr, mth, nnghs, out, 0, nnghs_used, z, ngh_idx);
+}
+
+static int interp_with_ksel(const orc_db *db, const orc_params *p, const orc_pt *pt,
+                            int32_t excl, int rm_zero_dist, int64_t ksel,
+                            double *daily, double *norms, double *se)
+{
+    near_t nr;
+    nr.n = orc_nearest(db, pt->lat, pt->lon, excl, rm_zero_dist, ksel, nr.idx, nr.dist);
+    for (int mth = 1; mth <= 12; ++mth) { /* interp_tair.py:429-437 */
+        double mean, var;
+        int rc = krig_with_near(db, p, pt, &nr, mth, 0, NULL, &mean, &var, NULL, NULL);
+        if (rc) return rc;
+        norms[mth - 1] = mean;
+        se[mth - 1] = var >= 0 ? sqrt(var) : 0.0; /* std_err_ci :816 */
+        if (daily) {
+            rc = gwr_with_near(db, p, pt, mean, &nr, mth, 0, daily, 1, NULL, NULL, NULL);
+            if (rc) return rc;
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_interp(const orc_db *db, const orc_params *p, const orc_pt *pt, int32_t excl,
+               int rm_zero_dist, double *daily, double *norms, double *se)
+{
+    return interp_with_ksel(db, p, pt, excl, rm_zero_dist, pick_ksel(db, p, 0),
+                            daily, norms, se);
+}
+
+/* ---------------------------------------------------------------- a9 ---- */
+/* interp_tair.py:143-197.  Sequential: earlier fixes feed later windows. */
+int orc_fixer(double *tmin, double *tmax, int64_t ndays, int tail, int32_t *ninvalid)
+{
+    int32_t ninv = 0;
+    /* the list of invalid days is taken BEFORE any fix (:173) */
+    unsigned char *inv = malloc((size_t)ndays);
+    for (int64_t d = 0; d < ndays; ++d) { inv[d] = tmin[d] >= tmax[d]; ninv += inv[d]; }
+    for (int64_t x = 0; x < ndays; ++x) {
+        if (!inv[x]) continue;
+        double tavg = (tmin[x] + tmax[x]) / 2.0;
+        int64_t s = x - tail, e = x + tail + 1;
+        if (s < 0) s = 0;
+        if (e > ndays) e = ndays;
+        double sum = 0.0; int64_t cnt = 0;
+        for (int64_t d = s; d < e; ++d)
+            if (tmin[d] < tmax[d]) { sum += tmax[d] - tmin[d]; ++cnt; }
+        if (cnt == 0) { free(inv); return ORC_ERR_FIXER; }
+        double half = (sum / (double)cnt) / 2.0;
+        tmin[x] = tavg - half;
+        tmax[x] = tavg + half;
+    }
+    free(inv);
+    *ninvalid = ninv;
+    return ORC_OK;
+}
+
+/* interp_tair.py:583-590 with the masks of :468-481: per (year, month) means
+ * over the normals period, then the mean over years for each month. */
+void orc_recompute_norms(const double *daily, int64_t ndays, const int32_t *day_month,
+                         const int32_t *day_year, int yr0, int yr1, double *norms)
+{
+    int ymin = 1 << 30, ymax = -(1 << 30);
+    for (int64_t d = 0; d < ndays; ++d)
+        if (day_year[d] >= yr0 && day_year[d] <= yr1) {
+            if (day_year[d] < ymin) ymin = day_year[d];
+            if (day_year[d] > ymax) ymax = day_year[d];
+        }
+    if (ymin > ymax) { for (int m = 0; m < 12; ++m) norms[m] = NAN; return; }
+    int ny = ymax - ymin + 1;
+    double *sum = calloc((size_t)ny * 12, sizeof(double));
+    int64_t *cnt = calloc((size_t)ny * 12, sizeof(int64_t));
+    for (int64_t d = 0; d < ndays; ++d) {
+        int y = day_year[d];
+        if (y < yr0 || y > yr1) continue;
+        int c = (y - ymin) * 12 + day_month[d] - 1;
+        sum[c] += daily[d]; cnt[c]++;
+    }
+    for (int m = 0; m < 12; ++m) {
+        double s = 0.0;
+        for (int y = 0; y < ny; ++y) s += sum[y * 12 + m] / (double)cnt[y * 12 + m];
+        norms[m] = s / ny;
+    }
+    free(sum); free(cnt);
+}
+
+/* --------------------------------------------------------------- a12 ---- */
+/* step25:163-164: np.round(x, 2) / np.float32(0.01) assigned into int16:
+ * rint(x*100)/100 (half-even), divided by float32(0.01) widened to f8, C cast
+ * (truncation toward zero). */
+void orc_pack_i16(const double *x, int64_t n, int16_t *out)
+{
+    const double scale = (double)0.01f;
+    for (int64_t i = 0; i < n; ++i) {
+        double r = nearbyint(x[i] * 100.0) / 100.0;
+        out[i] = (int16_t)(r / scale);
+    }
+}
+
+/* ----------------------------------------------------- step25:126-172 ---- */
+int orc_interp_grid(const orc_db *tmin, const orc_db *tmax, const orc_params *p,
+                    int Y, int X, const uint8_t *mask, const double *lat,
+                    const double *lon, const float *elev, const float *tdi,
+                    const float *lst_night, const float *lst_day,
+                    float *norm_tmin, float *se_tmin, float *norm_tmax, float *se_tmax,
+                    int16_t *daily_tmin, int16_t *daily_tmax, int32_t *ninvalid,
+                    int32_t *status, int nthreads)
+{
+    const int64_t ncell = (int64_t)Y * X;
+    const int with_daily = daily_tmin != NULL || daily_tmax != NULL;
+    const int64_t ndays = with_daily ? (tmin ? tmin->ndays : tmax->ndays) : 0;
+    const int64_t ksel_n = tmin ? pick_ksel(tmin, p, 0) : 0;
+    const int64_t ksel_x = tmax ? pick_ksel(tmax, p, 0) : 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        double *dn = with_daily ? malloc(sizeof(double) * (size_t)ndays) : NULL;
+        double *dx = with_daily ? malloc(sizeof(double) * (size_t)ndays) : NULL;
+        int16_t *pk = with_daily ? malloc(sizeof(int16_t) * (size_t)ndays) : NULL;
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t c = 0; c < ncell; ++c) {
+            if (!mask[c]) continue;
+            int r = (int)(c / X), q = (int)(c % X);
+            orc_pt pt;
+            double nn[12], sn[12], nx[12], sx[12];
+            int rc = ORC_OK;
+            int32_t ninv = 0;
+            pt.lat = lat[r]; pt.lon = lon[q];
+            pt.elev = (double)elev[c]; pt.tdi = (double)tdi[c];
+            if (tmin) { /* interp_tair.py:560-566 */
+                for (int m = 0; m < 12; ++m) pt.lst[m] = (double)lst_night[m * ncell + c];
+                rc = interp_with_ksel(tmin, p, &pt, -1, 0, ksel_n, daily_tmin ? dn : NULL, nn, sn);
+            }
+            if (!rc && tmax) { /* :569-575 */
+                for (int m = 0; m < 12; ++m) pt.lst[m] = (double)lst_day[m * ncell + c];
+                rc = interp_with_ksel(tmax, p, &pt, -1, 0, ksel_x, daily_tmax ? dx : NULL, nx, sx);
+            }
+            if (!rc && daily_tmin && daily_tmax) { /* :579-590 */
+                rc = orc_fixer(dn, dx, ndays, p->fixer_tail, &ninv);
+                if (!rc && ninv > 0) {
+                    orc_recompute_norms(dn, ndays, tmin->day_month, tmin->day_year,
+                                        p->norm_yr0, p->norm_yr1, nn);
+                    orc_recompute_norms(dx, ndays, tmin->day_month, tmin->day_year,
+                                        p->norm_yr0, p->norm_yr1, nx);
+                }
+            }
+            if (status) status[c] = rc;
+            if (rc) continue; /* step25:154-160: leave fill values */
+            for (int m = 0; m < 12; ++m) { /* step25:166-172 */
+                if (tmin) { norm_tmin[m * ncell + c] = (float)nn[m]; se_tmin[m * ncell + c] = (float)sn[m]; }
+                if (tmax) { norm_tmax[m * ncell + c] = (float)nx[m]; se_tmax[m * ncell + c] = (float)sx[m]; }
+            }
+            if (ninvalid) ninvalid[c] = ninv;
+            if (daily_tmin) {
+                orc_pack_i16(dn, ndays, pk);
+                for (int64_t d = 0; d < ndays; ++d) daily_tmin[d * ncell + c] = pk[d];
+            }
+            if (daily_tmax) {
+                orc_pack_i16(dx, ndays, pk);
+                for (int64_t d = 0; d < ndays; ++d) daily_tmax[d * ncell + c] = pk[d];
+            }
+        }
+        free(dn); free(dx); free(pk);
+    }
+    return ORC_OK;
+}

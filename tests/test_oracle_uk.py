@@ -1,0 +1,90 @@
+"""Known-answer properties that pin the universal-kriging restatement (orc_uk)
+without gstat.  PARITY UNPINNED vs gstat itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+
+
+def _nbhd(seed, k=60):
+    r = np.random.default_rng(seed)
+    lon = r.uniform(-111.5, -110.5, k)
+    lat = r.uniform(44.5, 45.5, k)
+    elev = r.uniform(900, 2600, k)
+    lst = -5 - 0.006 * elev + r.normal(0, 1, k)
+    y = 12 - 0.0065 * elev + 0.35 * lst + r.normal(0, 0.8, k)
+    pt = (-111.02, 45.03, 1800.0, -14.0)
+    return lon, lat, elev, lst, y, pt
+
+
+def test_ellip_dist_known_values(orc):
+    # textbook WGS84: one degree of latitude / longitude at 45N
+    assert abs(orc.ellip_dist(-110, 44.5, -110, 45.5) - 111.132) < 0.01
+    assert abs(orc.ellip_dist(-110.5, 45, -109.5, 45) - 78.847) < 0.01
+    assert orc.ellip_dist(-110, 45, -110, 45) == 0.0
+    # not the haversine of selection (two distance definitions)
+    assert abs(orc.grt_circle_dist(-110, 45, -109, 46) - 135.78628245) < 1e-6
+    assert abs(orc.ellip_dist(-110, 45, -109, 46) - orc.grt_circle_dist(-110, 45, -109, 46)) > 0.05
+
+
+def test_linear_trend_reproduced(orc):
+    lon, lat, elev, lst, _, pt = _nbhd(0)
+    coef = np.array([3.0, 0.2, -0.4, -0.005, 0.3])
+    y = coef[0] + coef[1] * lon + coef[2] * lat + coef[3] * elev + coef[4] * lst
+    want = coef[0] + coef[1] * pt[0] + coef[2] * pt[1] + coef[3] * pt[2] + coef[4] * pt[3]
+    for nug, psill, rng in ((0.3, 0.8, 40.0), (0.0, 1.0, 10.0), (0.5, 0.0, 0.0)):
+        rc, mean, var = orc.uk(lon, lat, elev, lst, y, pt, nug, psill, rng)
+        assert rc == 0 and abs(mean - want) < 1e-8 and var >= 0
+
+
+def test_pure_nugget_is_ols(orc):
+    lon, lat, elev, lst, y, pt = _nbhd(1)
+    X = np.column_stack([np.ones(lon.size), lon - lon.mean(), lat - lat.mean(), elev - elev.mean(), lst - lst.mean()])
+    x0 = np.array([1, pt[0] - lon.mean(), pt[1] - lat.mean(), pt[2] - elev.mean(), pt[3] - lst.mean()])
+    beta = np.linalg.lstsq(X, y, rcond=None)[0]
+    s2 = 0.7
+    want_var = s2 * (1 + x0 @ np.linalg.solve(X.T @ X, x0))
+    for nug, psill in ((0.7, 0.0), (0.2, 0.5)):          # range == 0 -> vgm(psill+nug, "Nug")
+        rc, mean, var = orc.uk(lon, lat, elev, lst, y, pt, nug, psill, 0.0)
+        assert rc == 0 and abs(mean - x0 @ beta) < 1e-9 and abs(var - want_var) < 1e-9
+
+
+def test_exact_interpolator_on_station(orc):
+    lon, lat, elev, lst, y, _ = _nbhd(2)
+    j = 7
+    rc, mean, var = orc.uk(lon, lat, elev, lst, y, (lon[j], lat[j], elev[j], lst[j]), 0.3, 0.8, 40.0)
+    assert rc == 0 and abs(mean - y[j]) < 1e-9 and abs(var) < 1e-9
+
+
+def test_affine_invariance(orc):
+    lon, lat, elev, lst, y, pt = _nbhd(3)
+    rc, m0, v0 = orc.uk(lon, lat, elev, lst, y, pt, 0.3, 0.8, 40.0)
+    rc, m1, v1 = orc.uk(lon, lat, 3.28 * elev + 100, 1.8 * lst + 32, y,
+                        (pt[0], pt[1], 3.28 * pt[2] + 100, 1.8 * pt[3] + 32), 0.3, 0.8, 40.0)
+    assert abs(m0 - m1) < 1e-9 and abs(v0 - v1) < 1e-9
+
+
+@pytest.mark.parametrize("k", [35, 57, 101, 147])
+def test_gls_equals_augmented_system(orc, k):
+    import make_golden
+    lon, lat, elev, lst, y, pt = _nbhd(10 + k, k)
+    for nug, psill, rng in ((0.3, 0.8, 40.0), (0.1, 2.0, 80.0), (0.6, 0.2, 10.0)):
+        rc, mean, var = orc.uk(lon, lat, elev, lst, y, pt, nug, psill, rng)
+        m2, v2 = make_golden.uk_numpy(lon, lat, elev, lst, y, pt, nug, psill, rng)
+        assert rc == 0 and abs(mean - m2) < 1e-8 and abs(var - v2) < 1e-8
+
+
+def test_range_to_infinity_monotone(orc):
+    lon, lat, elev, lst, y, pt = _nbhd(4)
+    vs = [orc.uk(lon, lat, elev, lst, y, pt, 0.0, 1.0, r)[2] for r in (10.0, 100.0, 1000.0, 1e4)]
+    assert all(a > b for a, b in zip(vs, vs[1:])) and vs[-1] < 0.05
+
+
+def test_singular_system_reports_numeric(orc):
+    lon, lat, elev, lst, y, pt = _nbhd(5)
+    lon[1], lat[1] = lon[0], lat[0]          # duplicate location, no nugget on the off-diagonal
+    rc, _, _ = orc.uk(lon, lat, elev, lst, y, pt, 0.0, 1.0, 40.0)
+    assert rc == 4
