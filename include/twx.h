@@ -1,0 +1,200 @@
+/*
+ * twx.h -- C ABI of libtwxhip.so: the MI355X (gfx950) implementation of the
+ * TopoWx moving-window regression-kriging / GWR interpolation hot path.
+ *
+ * The reference (jaredwo/topowx) has no FFI: its seam is a set of Python
+ * classes called once per grid cell.  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = call-level failure
+ *     (twx_last_error() has the text); it never throws and never exits.
+ *   - per-cell / per-point failures are NOT call failures: they are reported in
+ *     the caller's status[] array with the TWX_CELL_* codes below and the
+ *     corresponding outputs are left untouched (the reference's worker catches
+ *     the exception and leaves fill values, step25:154-160).
+ *   - the library owns device memory behind the opaque context; the caller
+ *     owns every buffer it passes.  "host" buffers are plain host memory;
+ *     the *_dev entry takes device pointers and a hipStream_t and is
+ *     asynchronous on that stream.
+ *   - one context per GPU; calls on one context must be serialised by the
+ *     caller, different contexts are independent.
+ *   - months are 1..12; variables are TWX_TMIN / TWX_TMAX.
+ */
+#ifndef TWX_H
+#define TWX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWX_TMIN 0
+#define TWX_TMAX 1
+#define TWX_VAR_TMIN_BIT 1
+#define TWX_VAR_TMAX_BIT 2
+
+/* largest supported neighbourhood (the reference ladder tops out at 147,
+ * step21:198); larger smoothed bandwidths give TWX_CELL_RANGE */
+#define TWX_MAX_NNGHS 153
+
+/* per-cell status codes */
+#define TWX_CELL_OK 0
+#define TWX_CELL_FEW_STATIONS 1 /* IndexError at station_select.py:164 */
+#define TWX_CELL_NNGHS 2        /* "Cannot determine the optimal # of neighbors" interp_tair.py:252,829 */
+#define TWX_CELL_VARIO 3        /* "Cannot determine variogram params!" interp_tair.py:843 */
+#define TWX_CELL_NUMERIC 4      /* FloatingPointError (np.seterr, step25:319) / singular kriging system */
+#define TWX_CELL_FIXER 5        /* 'No valid tmin/tmax in window' interp_tair.py:192 */
+#define TWX_CELL_RANGE 6        /* bandwidth above TWX_MAX_NNGHS */
+#define TWX_CELL_MASKED (-1)    /* cell outside the interpolation mask: nothing computed */
+
+/* netCDF4 default fill values the reference worker pre-fills with (step25:73-88) */
+#define TWX_FILL_I2 ((int16_t)-32767)
+#define TWX_FILL_F4 9.969209968386869e36f
+#define TWX_FILL_I4 ((int32_t)-2147483647)
+
+typedef struct twx_ctx twx_ctx;
+
+/* Algorithm constants (module constants / hard-coded arguments in the reference) */
+typedef struct {
+    int32_t init_nnghs;      /* DFLT_INIT_NNGHS = 100, interp_tair.py:51 */
+    int32_t fixer_tail;      /* tmin_tmax_fixer(tail=15), interp_tair.py:143 */
+    int32_t norm_yr0;        /* 1981, interp_tair.py:468 */
+    int32_t norm_yr1;        /* 2010 */
+    int32_t tile_cells;      /* edge (cells) of the square candidate tile; 0 = default 8 */
+    int32_t batch_cells;     /* cells per device batch; 0 = default */
+    int32_t reserved[2];
+} twx_params;
+
+/* Station table of ONE variable (replaces StationSerialDataDb.stns +
+ * StationSelect's isnan(bad) mask: station_data.py:126-183,609,
+ * interp_tair.py:483-487).  Good stations only, sorted by station id.  All
+ * columns fp64 host arrays; NaN = missing (station_data.py:159-164). */
+typedef struct {
+    int64_t n;
+    const double *lon, *lat, *elev, *tdi;              /* [n] */
+    const double *lst, *norm;                          /* [12][n] */
+    const double *optim_nnghs, *optim_nnghs_anom;      /* [12][n] */
+    const double *vario_nug, *vario_psill, *vario_rng; /* [12][n] */
+    const float *obs; /* [ndays][n] (time, station_id) as in the netCDF var
+                         (station_data.py:578, post_infill.py:33); NULL = normals only */
+} twx_station_table;
+
+/* A point to interpolate to (replaces the structured scalar of
+ * build_empty_pt, interp_tair.py:200-213); lst = LST of the variable asked for */
+typedef struct {
+    double lon, lat, elev, tdi;
+    double lst[12];
+} twx_pt;
+
+/* Predictor planes of a grid of cells in their native dtypes (replaces the
+ * f8[32,Y,X] wrk_chk the coordinator sends, tiling.py:190-213 / step25:136-144).
+ * lat is north-up (descending), one value per row; lon one value per column. */
+typedef struct {
+    int32_t Y, X;
+    const uint8_t *mask;    /* [Y][X] nonzero = interpolate */
+    const double *lat;      /* [Y] */
+    const double *lon;      /* [X] */
+    const float *elev;      /* [Y][X] */
+    const float *tdi;       /* [Y][X] */
+    const int32_t *climdiv; /* [Y][X]; carried for format parity, never read (interp_tair.py:563 is dead) */
+    const float *lst_night; /* [12][Y][X]  -> Tmin predictor (interp_tair.py:562) */
+    const float *lst_day;   /* [12][Y][X]  -> Tmax predictor (interp_tair.py:571) */
+} twx_grid;
+
+/* Outputs of a grid call in the dtypes / layout of the reference's result
+ * arrays (step25:68-88,163-172).  Any pointer may be NULL.  Buffers must be
+ * pre-filled by the caller (fill values); failed and masked cells are not
+ * written. */
+typedef struct {
+    float *norm_tmin, *se_tmin; /* [12][Y][X] */
+    float *norm_tmax, *se_tmax; /* [12][Y][X] */
+    int16_t *daily_tmin;        /* [ndays][Y][X], degC * 100 (step25:163) */
+    int16_t *daily_tmax;
+    int32_t *ninvalid;          /* [Y][X] days fixed by tmin_tmax_fixer */
+    int32_t *status;            /* [Y][X] TWX_CELL_* */
+} twx_grid_out;
+
+/* Device time of the kernels of the last grid call, measured with HIP events on
+ * the call's stream (ms); filled when the call has completed. */
+typedef struct {
+    float tile_cand_ms, select_ms, uk_ms, gwr_ms, daily_ms, fix_ms, total_ms;
+    int64_t cells;        /* unmasked cells processed */
+    int64_t uk_solves;    /* (cell, month, variable) kriging systems solved */
+    int64_t uk_launches;  /* kernel launches of the kriging kernel */
+} twx_timing;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int twx_create(int device, const twx_params *params, twx_ctx **out);
+void twx_destroy(twx_ctx *ctx);
+const char *twx_last_error(const twx_ctx *ctx);
+const char *twx_version(void);
+
+/* day axis of the observation matrix: replaces StationSerialDataDb.days /
+ * mth_idx (station_data.py:570-576) and PtInterpTair's normals masks
+ * (interp_tair.py:468-481) */
+int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const int32_t *day_year);
+
+/* replaces StationSerialDataDb(...) + StationSelect(stn_da, isnan(bad))
+ * (interp_tair.py:483-487); uploads and re-lays the table and obs matrix */
+int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *tbl);
+
+/* ---- per-point entries (host buffers) ----------------------------------- */
+/* StationSelect.set_ngh_stns (station_select.py:121-192).  excl: station index
+ * to drop (stns_rm) or -1, per point, may be NULL.  Outputs [npts][k] in
+ * ascending station-index (= id) order. */
+int twx_knn(twx_ctx *ctx, int var, int64_t npts, const double *lon, const double *lat,
+            int32_t k, const int32_t *excl, int rm_zero_dist, int32_t *idx, double *dist,
+            double *wgt, int32_t *status);
+
+/* KrigTair.krig(pt, mth, nnghs=None, vario_params=None, stns_rm=None)
+ * (interp_tair.py:853-926) for npts independent (point, month) pairs.
+ * nnghs: NULL or entries <= 0 -> smoothed from neighbours (:821-835);
+ * vario: NULL or NaN nugget -> smoothed (:837-851).
+ * ngh_idx (optional) [npts][TWX_MAX_NNGHS]: neighbours used, ascending, -1 padded. */
+int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                    const int32_t *nnghs, const double *vario /*[npts][3]*/,
+                    const int32_t *excl, int rm_zero_dist, double *mean, double *variance,
+                    int32_t *nnghs_used, int32_t *ngh_idx, int32_t *status);
+
+/* GwrTairAnom.gwr_mth(pt, mth, nnghs=None, stns_rm=None) (interp_tair.py:261-314).
+ * pt_norm = pt[normMM].  out[npts][ld]: the days of mth in chronological order. */
+int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const double *pt_norm,
+                   const int32_t *mth, const int32_t *nnghs, const int32_t *excl,
+                   int rm_zero_dist, double *out, int64_t ld, int32_t *nnghs_used,
+                   int32_t *status);
+
+/* InterpTair.interp(pt, stns_rm) (interp_tair.py:396-439): 12 x (krig, gwr).
+ * daily [npts][ndays] degC (NULL = normals only), norms/se [npts][12]. */
+int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,
+                      const int32_t *excl, int rm_zero_dist, double *daily, double *norms,
+                      double *se, int32_t *status);
+
+/* tmin_tmax_fixer + normals recompute (interp_tair.py:143-197,579-590) on
+ * nseries independent [ndays] degC series, in place.  norm_* [nseries][12] are
+ * overwritten only for series with ninvalid > 0 (may be NULL). */
+int twx_fix_pair(twx_ctx *ctx, int64_t nseries, double *tmin, double *tmax, int32_t *ninvalid,
+                 double *norm_tmin, double *norm_tmax, int32_t *status);
+
+/* int16 packing of daily degC (step25:44,163-164) */
+int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out);
+
+/* ---- grid entries: the step25 worker loop (step25:126-172) ---------------- */
+/* vars: TWX_VAR_*_BIT mask.  With both variables and daily outputs the
+ * Tmin>=Tmax fixer runs as in PtInterpTair.interp_pt (interp_tair.py:526-592). */
+int twx_interp_grid(twx_ctx *ctx, const twx_grid *grid, const twx_grid_out *out, int vars);
+
+/* same, but every pointer in grid / out is a DEVICE pointer and the work is
+ * enqueued on hip_stream (a hipStream_t; NULL = default stream).  Inputs must
+ * stay valid until the stream has drained. */
+int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *grid_dev, const twx_grid_out *out_dev,
+                        int vars, void *hip_stream);
+
+/* kernel times of the last grid call (synchronises on its events) */
+int twx_get_timing(twx_ctx *ctx, twx_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWX_H */

@@ -1,0 +1,333 @@
+"""ctypes binding of libtwxhip.so (include/twx.h) -- the only compute path.
+
+There is NO CPU fallback: if the shared library is missing or no GPU is visible
+the loader / ``Context`` raise.  (The CPU oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import stationdb as sdb
+from .dates import MONTH, YEAR
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtwxhip.so")
+
+TMIN, TMAX = 0, 1
+VAR_TMIN_BIT, VAR_TMAX_BIT = 1, 2
+MAX_NNGHS = 153
+FILL_I2 = np.int16(-32767)
+FILL_F4 = np.float32(9.969209968386869e36)
+FILL_I4 = np.int32(-2147483647)
+
+CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)",
+               2: "Cannot determine the optimal # of neighbors to use!",
+               3: "Cannot determine variogram params!",
+               4: "floating point error / singular kriging system",
+               5: "No valid tmin/tmax in window", 6: "bandwidth above the supported maximum",
+               -1: "masked"}
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_sp = C.POINTER(C.c_int16)
+_bp = C.POINTER(C.c_uint8)
+
+
+class TwxParams(C.Structure):
+    _fields_ = [("init_nnghs", C.c_int32), ("fixer_tail", C.c_int32), ("norm_yr0", C.c_int32),
+                ("norm_yr1", C.c_int32), ("tile_cells", C.c_int32), ("batch_cells", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class TwxStationTable(C.Structure):
+    _fields_ = [("n", C.c_int64), ("lon", _dp), ("lat", _dp), ("elev", _dp), ("tdi", _dp),
+                ("lst", _dp), ("norm", _dp), ("optim_nnghs", _dp), ("optim_nnghs_anom", _dp),
+                ("vario_nug", _dp), ("vario_psill", _dp), ("vario_rng", _dp), ("obs", _fp)]
+
+
+class TwxPt(C.Structure):
+    _fields_ = [("lon", C.c_double), ("lat", C.c_double), ("elev", C.c_double), ("tdi", C.c_double),
+                ("lst", C.c_double * 12)]
+
+
+PT_DTYPE = np.dtype([("lon", "f8"), ("lat", "f8"), ("elev", "f8"), ("tdi", "f8"), ("lst", "f8", (12,))])
+assert PT_DTYPE.itemsize == C.sizeof(TwxPt)
+
+
+class TwxGrid(C.Structure):
+    _fields_ = [("Y", C.c_int32), ("X", C.c_int32), ("mask", C.c_void_p), ("lat", C.c_void_p),
+                ("lon", C.c_void_p), ("elev", C.c_void_p), ("tdi", C.c_void_p), ("climdiv", C.c_void_p),
+                ("lst_night", C.c_void_p), ("lst_day", C.c_void_p)]
+
+
+class TwxGridOut(C.Structure):
+    _fields_ = [("norm_tmin", C.c_void_p), ("se_tmin", C.c_void_p), ("norm_tmax", C.c_void_p),
+                ("se_tmax", C.c_void_p), ("daily_tmin", C.c_void_p), ("daily_tmax", C.c_void_p),
+                ("ninvalid", C.c_void_p), ("status", C.c_void_p)]
+
+
+class TwxTiming(C.Structure):
+    _fields_ = [("tile_cand_ms", C.c_float), ("select_ms", C.c_float), ("uk_ms", C.c_float),
+                ("gwr_ms", C.c_float), ("daily_ms", C.c_float), ("fix_ms", C.c_float),
+                ("total_ms", C.c_float), ("cells", C.c_int64), ("uk_solves", C.c_int64),
+                ("uk_launches", C.c_int64)]
+
+
+EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
+           "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
+           "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing")
+
+_LIB = None
+
+
+class TwxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtwxhip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TwxError("%s not found: build it with ./build.sh (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.twx_last_error.restype = C.c_char_p
+        L.twx_version.restype = C.c_char_p
+        L.twx_last_error.argtypes = [C.c_void_p]
+        L.twx_destroy.argtypes = [C.c_void_p]
+        L.twx_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def station_columns(stn_da):
+    """Good stations (isnan(bad), interp_tair.py:483-487) as contiguous fp64 SoA."""
+    stns = stn_da.stns
+    good = np.isnan(stns[sdb.BAD])
+    stns = stns[good]
+    ids = stns[sdb.STN_ID]
+    if ids.size > 1 and not np.all(ids[1:] > ids[:-1]):
+        raise ValueError("station table must be sorted by station_id")
+    cols = {k: np.ascontiguousarray(stns[n], np.float64) for k, n in
+            (("lon", sdb.LON), ("lat", sdb.LAT), ("elev", sdb.ELEV), ("tdi", sdb.TDI))}
+    for key, namer in sdb.MONTHLY_FIELDS:
+        cols[key] = np.ascontiguousarray(np.stack([stns[namer(m)] for m in range(1, 13)]), np.float64)
+    return good, ids, cols
+
+
+class Context(object):
+    """One GPU context (twx_create / twx_destroy)."""
+
+    def __init__(self, device=0, init_nnghs=100, fixer_tail=15, norm_years=(1981, 2010), tile_cells=0,
+                 batch_cells=0):
+        self.lib = load()
+        prm = TwxParams(init_nnghs, fixer_tail, norm_years[0], norm_years[1], tile_cells, batch_cells)
+        h = C.c_void_p()
+        rc = self.lib.twx_create(C.c_int(device), C.byref(prm), C.byref(h))
+        if rc != 0:
+            raise TwxError("twx_create failed (%d): no usable MI355X / HIP device %d; there is no CPU fallback"
+                           % (rc, device))
+        self.h = h
+        self.ndays = 0
+        self.good = {}
+        self.ids = {}
+        self.nstn = {}
+        self.id_to_idx = {}
+        self.mth_days = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.twx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TwxError("%s failed: %s" % (what, self.lib.twx_last_error(self.h).decode()))
+
+    # ---- model state ------------------------------------------------------------
+    def set_days(self, days):
+        dm = np.ascontiguousarray(days[MONTH], np.int32)
+        dy = np.ascontiguousarray(days[YEAR], np.int32)
+        self._chk(self.lib.twx_set_days(self.h, C.c_int64(dm.size), _p(dm, _ip), _p(dy, _ip)), "twx_set_days")
+        self.ndays = dm.size
+        self.mth_days = [int((dm == m).sum()) for m in range(1, 13)]
+
+    def set_stations(self, var, stn_da, with_obs=True):
+        good, ids, cols = station_columns(stn_da)
+        obs = None
+        if with_obs and stn_da.var is not None:
+            if self.ndays != stn_da.days.size:
+                self.set_days(stn_da.days)
+            obs = np.ascontiguousarray(np.asarray(stn_da.var)[:, good], np.float32)
+        t = TwxStationTable()
+        t.n = ids.size
+        for k in ("lon", "lat", "elev", "tdi", "lst", "norm", "optim_nnghs", "optim_nnghs_anom",
+                  "vario_nug", "vario_psill", "vario_rng"):
+            setattr(t, k, _p(cols[k], _dp))
+        t.obs = _p(obs, _fp)
+        self._chk(self.lib.twx_set_stations(self.h, C.c_int(var), C.byref(t)), "twx_set_stations")
+        self.good[var], self.ids[var], self.nstn[var] = good, ids, ids.size
+        self.id_to_idx[var] = {s: i for i, s in enumerate(ids)}
+
+    # ---- helpers -----------------------------------------------------------------
+    @staticmethod
+    def make_pts(lon, lat, elev, tdi, lst):
+        lon = np.atleast_1d(np.asarray(lon, np.float64))
+        pts = np.zeros(lon.size, PT_DTYPE)
+        pts["lon"], pts["lat"], pts["elev"], pts["tdi"] = lon, lat, elev, tdi
+        pts["lst"] = np.asarray(lst, np.float64).reshape(lon.size, 12)
+        return pts
+
+    @staticmethod
+    def _i32(a, n, default=None):
+        if a is None:
+            return None if default is None else np.full(n, default, np.int32)
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.int32), (n,)))
+
+    # ---- per-point entries ---------------------------------------------------------
+    def knn(self, var, lon, lat, k, excl=None, rm_zero_dist=False):
+        lon = np.ascontiguousarray(np.atleast_1d(lon), np.float64)
+        lat = np.ascontiguousarray(np.atleast_1d(lat), np.float64)
+        n = lon.size
+        idx = np.empty((n, k), np.int32)
+        dist = np.empty((n, k))
+        wgt = np.empty((n, k))
+        st = np.empty(n, np.int32)
+        ex = self._i32(excl, n)
+        self._chk(self.lib.twx_knn(self.h, C.c_int(var), C.c_int64(n), _p(lon, _dp), _p(lat, _dp), C.c_int32(k),
+                                   _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(idx, _ip), _p(dist, _dp),
+                                   _p(wgt, _dp), _p(st, _ip)), "twx_knn")
+        return idx, dist, wgt, st
+
+    def krig_points(self, var, pts, mth, nnghs=None, vario=None, excl=None, rm_zero_dist=False, want_idx=False):
+        pts = np.ascontiguousarray(pts, PT_DTYPE)
+        n = pts.size
+        mth = self._i32(mth, n)
+        nn = self._i32(nnghs, n)
+        ex = self._i32(excl, n)
+        vp = None
+        if vario is not None:
+            vp = np.ascontiguousarray(np.broadcast_to(np.asarray(vario, np.float64), (n, 3)))
+        mean = np.full(n, np.nan)
+        var_ = np.full(n, np.nan)
+        used = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        ngh = np.empty((n, MAX_NNGHS), np.int32) if want_idx else None
+        self._chk(self.lib.twx_krig_points(self.h, C.c_int(var), C.c_int64(n), _p(pts), _p(mth, _ip), _p(nn, _ip),
+                                           _p(vp, _dp), _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(mean, _dp),
+                                           _p(var_, _dp), _p(used, _ip), _p(ngh, _ip), _p(st, _ip)),
+                  "twx_krig_points")
+        return mean, var_, used, st, ngh
+
+    def gwr_points(self, var, pts, pt_norm, mth, nnghs=None, excl=None, rm_zero_dist=False):
+        pts = np.ascontiguousarray(pts, PT_DTYPE)
+        n = pts.size
+        mth = self._i32(mth, n)
+        nn = self._i32(nnghs, n)
+        ex = self._i32(excl, n)
+        pn = np.ascontiguousarray(np.broadcast_to(np.asarray(pt_norm, np.float64), (n,)))
+        ld = max(self.mth_days)
+        out = np.full((n, ld), np.nan)
+        used = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        self._chk(self.lib.twx_gwr_points(self.h, C.c_int(var), C.c_int64(n), _p(pts), _p(pn, _dp), _p(mth, _ip),
+                                          _p(nn, _ip), _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(out, _dp),
+                                          C.c_int64(ld), _p(used, _ip), _p(st, _ip)), "twx_gwr_points")
+        return out, used, st
+
+    def interp_points(self, var, pts, excl=None, rm_zero_dist=False, daily=True):
+        pts = np.ascontiguousarray(pts, PT_DTYPE)
+        n = pts.size
+        ex = self._i32(excl, n)
+        d = np.full((n, self.ndays), np.nan) if daily else None
+        norms = np.full((n, 12), np.nan)
+        se = np.full((n, 12), np.nan)
+        st = np.zeros(n, np.int32)
+        self._chk(self.lib.twx_interp_points(self.h, C.c_int(var), C.c_int64(n), _p(pts), _p(ex, _ip),
+                                             C.c_int(int(rm_zero_dist)), _p(d, _dp), _p(norms, _dp), _p(se, _dp),
+                                             _p(st, _ip)), "twx_interp_points")
+        return d, norms, se, st
+
+    def fix_pair(self, tmin, tmax):
+        tmin = np.array(np.atleast_2d(tmin), np.float64, order="C")
+        tmax = np.array(np.atleast_2d(tmax), np.float64, order="C")
+        n = tmin.shape[0]
+        if tmin.shape[1] != self.ndays:
+            raise ValueError("series length must equal the day axis set with set_days")
+        ninv = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        nmin = np.full((n, 12), np.nan)
+        nmax = np.full((n, 12), np.nan)
+        self._chk(self.lib.twx_fix_pair(self.h, C.c_int64(n), _p(tmin, _dp), _p(tmax, _dp), _p(ninv, _ip),
+                                        _p(nmin, _dp), _p(nmax, _dp), _p(st, _ip)), "twx_fix_pair")
+        return tmin, tmax, ninv, nmin, nmax, st
+
+    def pack_i16(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.empty(x.shape, np.int16)
+        self._chk(self.lib.twx_pack_i16(self.h, C.c_int64(x.size), _p(x, _dp), _p(out, _sp)), "twx_pack_i16")
+        return out
+
+    # ---- grid entries ------------------------------------------------------------------
+    @staticmethod
+    def grid_arrays(grid, rows=None, cols=None):
+        rs = rows if rows is not None else slice(None)
+        cs = cols if cols is not None else slice(None)
+        a = dict(lat=np.ascontiguousarray(grid["lat"][rs], np.float64),
+                 lon=np.ascontiguousarray(grid["lon"][cs], np.float64),
+                 mask=np.ascontiguousarray(grid["mask"][rs, cs], np.uint8),
+                 elev=np.ascontiguousarray(grid["elev"][rs, cs], np.float32),
+                 tdi=np.ascontiguousarray(grid["tdi"][rs, cs], np.float32),
+                 climdiv=np.ascontiguousarray(grid["climdiv"][rs, cs], np.int32),
+                 lst_night=np.ascontiguousarray(grid["lst_night"][:, rs, cs], np.float32),
+                 lst_day=np.ascontiguousarray(grid["lst_day"][:, rs, cs], np.float32))
+        return a
+
+    def interp_grid(self, grid, variables=("tmin", "tmax"), daily=False, rows=None, cols=None):
+        """step25 worker loop on host arrays; returns result arrays pre-filled with
+        the netCDF fill values the reference uses (step25:68-88)."""
+        a = self.grid_arrays(grid, rows, cols)
+        Y, X = a["mask"].shape
+        g = TwxGrid(Y, X, *[a[k].ctypes.data for k in ("mask", "lat", "lon", "elev", "tdi", "climdiv",
+                                                     "lst_night", "lst_day")])
+        out = {}
+        vars_mask = 0
+        for v, bit in (("tmin", VAR_TMIN_BIT), ("tmax", VAR_TMAX_BIT)):
+            if v not in variables:
+                continue
+            vars_mask |= bit
+            out["norm_" + v] = np.full((12, Y, X), FILL_F4, np.float32)
+            out["se_" + v] = np.full((12, Y, X), FILL_F4, np.float32)
+            if daily:
+                out["daily_" + v] = np.full((self.ndays, Y, X), FILL_I2, np.int16)
+        out["ninvalid"] = np.full((Y, X), FILL_I4, np.int32)
+        out["status"] = np.full((Y, X), -1, np.int32)
+        o = TwxGridOut(*[out[k].ctypes.data if k in out else None for k in
+                         ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax", "daily_tmin", "daily_tmax",
+                          "ninvalid", "status")])
+        self._chk(self.lib.twx_interp_grid(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask)), "twx_interp_grid")
+        return out
+
+    def interp_grid_dev(self, g, o, vars_mask, stream=0):
+        """Device-pointer entry (TwxGrid / TwxGridOut hold device addresses)."""
+        self._chk(self.lib.twx_interp_grid_dev(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask),
+                                               C.c_void_p(stream)), "twx_interp_grid_dev")
+
+    def timing(self):
+        t = TwxTiming()
+        self._chk(self.lib.twx_get_timing(self.h, C.byref(t)), "twx_get_timing")
+        return {k: getattr(t, k) for k, _ in TwxTiming._fields_}

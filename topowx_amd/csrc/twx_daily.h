@@ -1,0 +1,408 @@
+// twx_daily.h -- GWR hat rows, daily anomaly dot products, Tmin>=Tmax fixer and
+// int16 packing.
+#pragma once
+#include "twx_select.h"
+
+#define TWX_KZ 160   // z slots per (cell, month)
+
+struct DayAxis {
+    int ndays;
+    int moff[13];             // month-major offsets: days of month m are [moff[m-1], moff[m])
+    const int32_t *mm2chron;  // [ndays] month-major position -> chronological day
+    const int32_t *chron2mm;  // [ndays]
+    const int32_t *day_month; // [ndays] chronological, 1..12
+    const int32_t *day_year;  // [ndays]
+    int tail;
+    int norm_ny;              // years of the normals period present in the day axis (0 = none)
+    const int32_t *ym_start;  // [norm_ny * 12] first chronological day of (year, month)
+    const int32_t *ym_cnt;    // [norm_ny * 12] days of (year, month)
+};
+
+struct GwrWs {
+    double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank
+    double *zc;       // [ncell][12]          pt_norm - sum_j z_j norm_j
+    int32_t *gstat;   // [ncell]
+};
+
+// ---------------------------------------------------------------------------------
+// k_gwr_z: one wavefront per (cell, month).  _gwr_series (interp_tair.py:1099-1146):
+// z = x0' (X'WX)^-1 X'W with X = [1, lon, lat, elev, tdi, lst] of the ka nearest
+// stations and their own bisquare weights.  Predictor columns are shifted to the
+// cell and scaled (z is invariant to it), the 6x6 SPD system is Cholesky-solved
+// redundantly by every lane.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws, GwrWs gw,
+                                               const double *pt_norm_in)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wv;
+    if (item >= ws.ncell * 12) return;
+    const int64_t lc = item / 12;
+    const int m0 = (int)(item % 12);
+    const int64_t c = ws.cell0 + lc;
+    if (ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0) return;
+    const int ka = ws.ka[lc * 12 + m0];
+    if (ka <= 0) return;
+    const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    const double dbw = ws.near_dist[lc * ws.ksel + ka];
+    double row[3][6], w[3], nrm[3];
+    double mx[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int r = lane + 64 * s;
+        w[s] = 0.0; nrm[s] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) row[s][q] = 0.0;
+        if (r < ka) {
+            int j = ws.near_idx[lc * ws.ksel + r];
+            w[s] = bisq(ws.near_dist[lc * ws.ksel + r], dbw);
+            row[s][0] = 1.0;
+            row[s][1] = st.lon[j] - cv.lon; row[s][2] = st.lat[j] - cv.lat;
+            row[s][3] = st.elev[j] - cv.elev; row[s][4] = st.tdi[j] - cv.tdi;
+            row[s][5] = st.lst[m0 * n + j] - plst;
+            nrm[s] = st.norm[m0 * n + j];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) mx[q] = fmax(mx[q], fabs(row[s][1 + q]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double s = wave_max(mx[q]);
+        s = s > 0.0 ? 1.0 / s : 1.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) row[u][1 + q] *= s;
+    }
+    // M = X'WX (lower triangle, 21 sums)
+    double M[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) s += w[u] * row[u][a] * row[u][b];
+            M[a][b] = wave_sum(s);
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = M[i][j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) s -= M[i][p] * M[j][p];
+            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); }
+            else M[i][j] = s / M[j][j];
+        }
+    }
+    // a = M^-1 e1
+    double a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = (i == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < i; ++p) s -= M[i][p] * a[p];
+        a[i] = s / M[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = a[i];
+#pragma unroll
+        for (int p = i + 1; p < 6; ++p) s -= M[p][i] * a[p];
+        a[i] = s / M[i][i];
+    }
+    double zn = 0.0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        int r = lane + 64 * u;
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) t += a[q] * row[u][q];
+        double z = w[u] * t;
+        if (r < ka) {
+            gw.z[(lc * 12 + m0) * TWX_KZ + r] = z;
+            zn += z * nrm[u];
+            if (!finite_d(z)) bad = true;
+        }
+    }
+    zn = wave_sum(zn);
+    bad = __any(bad);
+    if (lane == 0) {
+        double pn = pt_norm_in ? pt_norm_in[c] : ws.uk_mean[lc * 12 + m0];
+        gw.zc[lc * 12 + m0] = pn - zn;
+        if (bad) gw.gstat[lc] = TWX_CELL_NUMERIC;
+    }
+}
+
+// value of one (cell, month-major day): sum_r z_r * obs[idx_r][dm] + zc, fixed
+// summation order (rank order, fma chain) so every kernel reproduces it bit for bit
+__device__ __forceinline__ double daily_value(const StnDev &st, const SelWs &ws, const GwrWs &gw,
+                                              int64_t lc, int m0, int ka, int ndays, int dm)
+{
+    const double *z = gw.z + (lc * 12 + m0) * TWX_KZ;
+    const int32_t *ni = ws.near_idx + lc * ws.ksel;
+    double acc = 0.0;
+    for (int r = 0; r < ka; ++r)
+        acc = fma(z[r], (double)st.obs[(size_t)ni[r] * ndays + dm], acc);
+    return acc + gw.zc[lc * 12 + m0];
+}
+
+// step25:163-164: np.round(x, 2) / np.float32(0.01) assigned into int16
+__device__ __forceinline__ int16_t pack_i16(double x)
+{
+    double r = rint(x * 100.0) / 100.0;
+    return (int16_t)(int)(r / (double)0.01f);
+}
+
+// ---------------------------------------------------------------------------------
+// k_daily_points: double degC output for point entries.  One workgroup per point,
+// threads over month-major days.  single_month != 0: out[c][ld] holds only the days
+// of the point's month (chronological within the month == month-major order).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_daily_points(StnDev st, CellSrc src, SelWs ws, GwrWs gw, DayAxis da,
+                                                      double *out, int64_t ld, int single_month)
+{
+    const int64_t lc = blockIdx.x;
+    if (lc >= ws.ncell) return;
+    const int64_t c = ws.cell0 + lc;
+    if (ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) return;
+    for (int m0 = 0; m0 < 12; ++m0) {
+        const int ka = ws.ka[lc * 12 + m0];
+        if (ka <= 0) continue;
+        for (int dm = da.moff[m0] + threadIdx.x; dm < da.moff[m0 + 1]; dm += blockDim.x) {
+            double v = daily_value(st, ws, gw, lc, m0, ka, da.ndays, dm);
+            if (single_month) out[c * ld + (dm - da.moff[m0])] = v;
+            else out[c * ld + da.mm2chron[dm]] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_daily_grid: (64-cell row strip) x (month) x (64 month-major days).  Lane = day
+// (coalesced obs reads), each wave walks 16 cells; results are staged in LDS and
+// written as 128-byte rows of the [ndays][Y][X] int16 output.  With both variables
+// present, cells having any day with tmin >= tmax are flagged for k_fix_cells.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
+                                                    GwrWs gn, GwrWs gx, int has_n, int has_x, DayAxis da,
+                                                    twx_grid_out out, int32_t *flag, int nblk_max)
+{
+    __shared__ int16_t s_v[2][64][66];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const SelWs &w0 = has_n ? wn : wx;
+    const int64_t strip = blockIdx.x;               // 64 consecutive local cells
+    const int m0 = blockIdx.y / nblk_max;
+    const int blk = blockIdx.y % nblk_max;
+    const int dm0 = da.moff[m0] + blk * 64;
+    if (dm0 >= da.moff[m0 + 1]) return;
+    const int dm = dm0 + lane;
+    const bool day_ok = dm < da.moff[m0 + 1];
+    const int64_t yx = (int64_t)src.Y * src.X;
+    for (int i = 0; i < 16; ++i) {
+        const int cl = wv * 16 + i;
+        const int64_t lc = strip * 64 + cl;
+        bool ok = lc < w0.ncell;
+        if (ok && has_n) ok = wn.cstat[lc] == 0 && wn.uk_stat[lc] == 0 && gn.gstat[lc] == 0;
+        if (ok && has_x) ok = wx.cstat[lc] == 0 && wx.uk_stat[lc] == 0 && gx.gstat[lc] == 0;
+        double vn = 0.0, vx = 0.0;
+        if (ok && day_ok) {
+            if (has_n) vn = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
+            if (has_x) vx = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
+            if (has_n && has_x && vn >= vx) flag[lc] = 1;
+        }
+        s_v[0][lane][cl] = (ok && day_ok) ? pack_i16(vn) : TWX_FILL_I2;
+        s_v[1][lane][cl] = (ok && day_ok) ? pack_i16(vx) : TWX_FILL_I2;
+    }
+    __syncthreads();
+    // write: each wave takes 16 days; lane = cell of the strip
+    const int64_t lc = strip * 64 + lane;
+    bool ok = lc < w0.ncell;
+    if (ok && has_n) ok = wn.cstat[lc] == 0 && wn.uk_stat[lc] == 0 && gn.gstat[lc] == 0;
+    if (ok && has_x) ok = wx.cstat[lc] == 0 && wx.uk_stat[lc] == 0 && gx.gstat[lc] == 0;
+    if (!ok) return;
+    const int64_t c = w0.cell0 + lc;
+    for (int i = 0; i < 16; ++i) {
+        const int dl = wv * 16 + i;
+        if (dm0 + dl >= da.moff[m0 + 1]) break;
+        const int64_t d = da.mm2chron[dm0 + dl];
+        if (has_n && out.daily_tmin) out.daily_tmin[d * yx + c] = s_v[0][dl][lane];
+        if (has_x && out.daily_tmax) out.daily_tmax[d * yx + c] = s_v[1][dl][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_fix_cells: tmin_tmax_fixer + normals recompute (interp_tair.py:143-197,579-590)
+// for the cells flagged by k_daily_grid.  One workgroup per flagged cell
+// (grid-stride): recompute both fp64 series chronologically into scratch, list the
+// invalid days (before any fix), fix them sequentially in day order (earlier fixes
+// feed later windows), recompute the normals, repack the changed days.
+// scratch: [gridDim][2][ndays] doubles; lists: [gridDim][ndays] int32.
+// Also used by twx_fix_pair (series given, no recompute): src_series != null.
+// ---------------------------------------------------------------------------------
+struct FixArgs {
+    const int32_t *cells;   // flagged local cells (grid mode) or null
+    int ncells;
+    double *scratch;        // [gridDim][2][ndays]
+    int32_t *lists;         // [gridDim][ndays]
+    double *series_min;     // twx_fix_pair: [nseries][ndays] in/out (chronological), else null
+    double *series_max;
+    double *norm_min_out;   // twx_fix_pair: [nseries][12] or null
+    double *norm_max_out;
+    int32_t *ninv_out;      // twx_fix_pair / points
+    int32_t *status_out;
+};
+
+__device__ void fix_series_block(double *tmin, double *tmax, int32_t *list, const DayAxis &da,
+                                 int *s_n, int *s_err, double *s_norm /*[2][12]*/)
+{
+    // ordered list of invalid days (taken BEFORE any fix, interp_tair.py:173)
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) { s_base = 0; *s_err = 0; }
+    __syncthreads();
+    for (int d0 = 0; d0 < da.ndays; d0 += 256) {
+        int d = d0 + t;
+        bool f = d < da.ndays && tmin[d] >= tmax[d];
+        unsigned long long b = __ballot(f);
+        int pre = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_cnt[w];
+        if (f) list[off + pre] = d;
+        __syncthreads();
+        if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    const int ninv = s_base;
+    if (t == 0) {
+        *s_n = ninv;
+        for (int q = 0; q < ninv; ++q) {
+            int x = list[q];
+            double tavg = (tmin[x] + tmax[x]) / 2.0;
+            int s = x - da.tail, e = x + da.tail + 1;
+            if (s < 0) s = 0;
+            if (e > da.ndays) e = da.ndays;
+            double sum = 0.0; int cnt = 0;
+            for (int d = s; d < e; ++d)
+                if (tmin[d] < tmax[d]) { sum += tmax[d] - tmin[d]; ++cnt; }
+            if (cnt == 0) { *s_err = 1; break; }
+            double half = (sum / (double)cnt) / 2.0;
+            tmin[x] = tavg - half;
+            tmax[x] = tavg + half;
+        }
+    }
+    __syncthreads();
+    if (ninv == 0 || *s_err) return;
+    // normals: mean over years of the per-(year, month) means, normals period only
+    // (interp_tair.py:468-481,583-590); the days of one (year, month) are contiguous
+    if (da.norm_ny <= 0) { if (t < 24) s_norm[t] = NAN; __syncthreads(); return; }
+    if (t < 24) {
+        const int v = t / 12, m = t % 12;
+        const double *ser = v ? tmax : tmin;
+        double acc = 0.0;
+        for (int y = 0; y < da.norm_ny; ++y) {
+            const int s0 = da.ym_start[y * 12 + m], n = da.ym_cnt[y * 12 + m];
+            double sum = 0.0;
+            for (int d = 0; d < n; ++d) sum += ser[s0 + d];
+            acc += sum / (double)n;
+        }
+        s_norm[t] = acc / (double)da.norm_ny;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_fix_cells(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
+                                                   GwrWs gn, GwrWs gx, DayAxis da, twx_grid_out out, FixArgs fa)
+{
+    __shared__ int s_n, s_err;
+    __shared__ double s_norm[24];
+    double *tmin = fa.scratch + (size_t)blockIdx.x * 2 * da.ndays;
+    double *tmax = tmin + da.ndays;
+    int32_t *list = fa.lists + (size_t)blockIdx.x * da.ndays;
+    const int64_t yx = (int64_t)src.Y * src.X;
+    for (int it = blockIdx.x; it < fa.ncells; it += gridDim.x) {
+        const int64_t lc = fa.cells[it];
+        const int64_t c = wn.cell0 + lc;
+        for (int dm = threadIdx.x; dm < da.ndays; dm += 256) {
+            int m0 = 0;
+            while (dm >= da.moff[m0 + 1]) ++m0;
+            int d = da.mm2chron[dm];
+            tmin[d] = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
+            tmax[d] = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
+        }
+        __syncthreads();
+        fix_series_block(tmin, tmax, list, da, &s_n, &s_err, s_norm);
+        const int ninv = s_n;
+        if (s_err) {
+            // the reference raises (interp_tair.py:192) -> the worker leaves fill values
+            if (threadIdx.x == 0) {
+                if (out.status) out.status[c] = TWX_CELL_FIXER;
+                if (out.ninvalid) out.ninvalid[c] = TWX_FILL_I4;
+            }
+            for (int m = threadIdx.x; m < 12; m += 256) {
+                if (out.norm_tmin) out.norm_tmin[m * yx + c] = TWX_FILL_F4;
+                if (out.se_tmin) out.se_tmin[m * yx + c] = TWX_FILL_F4;
+                if (out.norm_tmax) out.norm_tmax[m * yx + c] = TWX_FILL_F4;
+                if (out.se_tmax) out.se_tmax[m * yx + c] = TWX_FILL_F4;
+            }
+            for (int d = threadIdx.x; d < da.ndays; d += 256) {
+                if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = TWX_FILL_I2;
+                if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = TWX_FILL_I2;
+            }
+        } else {
+            if (threadIdx.x == 0 && out.ninvalid) out.ninvalid[c] = ninv;
+            if (ninv > 0) {
+                for (int m = threadIdx.x; m < 12; m += 256) {
+                    if (out.norm_tmin) out.norm_tmin[m * yx + c] = (float)s_norm[m];
+                    if (out.norm_tmax) out.norm_tmax[m * yx + c] = (float)s_norm[12 + m];
+                }
+                for (int q = threadIdx.x; q < ninv; q += 256) {
+                    int d = list[q];
+                    if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(tmin[d]);
+                    if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = pack_i16(tmax[d]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// twx_fix_pair: series supplied by the caller
+__global__ __launch_bounds__(256) void k_fix_series(DayAxis da, FixArgs fa)
+{
+    __shared__ int s_n, s_err;
+    __shared__ double s_norm[24];
+    int32_t *list = fa.lists + (size_t)blockIdx.x * da.ndays;
+    for (int it = blockIdx.x; it < fa.ncells; it += gridDim.x) {
+        double *tmin = fa.series_min + (size_t)it * da.ndays;
+        double *tmax = fa.series_max + (size_t)it * da.ndays;
+        fix_series_block(tmin, tmax, list, da, &s_n, &s_err, s_norm);
+        if (threadIdx.x == 0) {
+            fa.ninv_out[it] = s_err ? 0 : s_n;
+            fa.status_out[it] = s_err ? TWX_CELL_FIXER : TWX_CELL_OK;
+        }
+        if (!s_err && s_n > 0 && threadIdx.x < 12) {
+            if (fa.norm_min_out) fa.norm_min_out[it * 12 + threadIdx.x] = s_norm[threadIdx.x];
+            if (fa.norm_max_out) fa.norm_max_out[it * 12 + threadIdx.x] = s_norm[12 + threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_pack(const double *x, int64_t n, int16_t *out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pack_i16(x[i]);
+}
+
+// compact flagged cells into a list (order irrelevant)
+__global__ void k_compact_flags(const int32_t *flag, int64_t n, int32_t *list, int32_t *count)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) list[atomicAdd(count, 1)] = (int32_t)i;
+}

@@ -1,0 +1,822 @@
+// twx_hip.hip -- host side of libtwxhip.so: the C ABI of include/twx.h on top of
+// the gfx950 kernels in twx_select.h / twx_uk.h / twx_daily.h / twx_out.h.
+//
+// Plain HIP runtime only (no torch, no CPU fallback): every entry point either
+// runs the kernels on the context's GPU or fails with a negative status.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "twx.h"
+#include "twx_daily.h"
+#include "twx_out.h"
+#include "twx_uk.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct VarData {
+    int n = 0, kmax = 0;
+    bool has_obs = false;
+    DevBuf cols, obs;
+    StnDev dev{};
+};
+
+struct Work {
+    DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat;
+    int cmax = 512;
+    SelWs ws{};
+    GwrWs gw{};
+    void release()
+    {
+        for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat})
+            b->release();
+    }
+};
+
+enum { EV_TILE = 0, EV_SELECT, EV_UK, EV_GWR, EV_DAILY, EV_FIX, EV_NKIND };
+
+struct EvPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct twx_ctx {
+    int device = 0;
+    twx_params p{};
+    VarData var[2];
+    Work work[2];
+    // day axis
+    int64_t ndays = 0;
+    std::vector<int32_t> day_month, day_year, mm2chron, chron2mm;
+    DevBuf day_dev;
+    DayAxis da{};
+    // scratch for the point entries / fixer
+    DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list;
+    std::string err;
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    twx_timing timing{};
+    int64_t t_cells = 0, t_solves = 0, t_launches = 0;
+    hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
+    bool have_total = false;
+};
+
+namespace {
+
+int fail(twx_ctx *ctx, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return -1;
+}
+
+#define HIPCHK(call)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail(ctx, #call, e_);                   \
+    } while (0)
+
+struct EvScope {
+    twx_ctx *ctx; hipStream_t s; size_t i;
+    EvScope(twx_ctx *c, hipStream_t st, int kind) : ctx(c), s(st)
+    {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            EvPair e{};
+            (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+            ctx->ev_pool.push_back(e);
+        }
+        i = ctx->ev_used++;
+        ctx->ev_pool[i].kind = kind;
+        (void)hipEventRecord(ctx->ev_pool[i].a, s);
+    }
+    ~EvScope() { (void)hipEventRecord(ctx->ev_pool[i].b, s); }
+};
+
+template <class T> T *carve(char *&cur, size_t count)
+{
+    T *r = reinterpret_cast<T *>(cur);
+    cur += (count * sizeof(T) + 255) / 256 * 256;
+    return r;
+}
+
+// ---- workspace of one (batch, variable) ---------------------------------------------
+int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile0, int64_t ntile, int ksel,
+                 int nblocks_tile, bool need_gwr)
+{
+    Work &w = ctx->work[v];
+    const int n = ctx->var[v].n;
+    HIPCHK(w.cand.ensure((size_t)ntile * w.cmax * 4));
+    HIPCHK(w.ncand.ensure((size_t)ntile * 4));
+    HIPCHK(w.small.ensure(256));
+    HIPCHK(w.dscratch.ensure((size_t)nblocks_tile * n * 4));
+    HIPCHK(w.near_idx.ensure((size_t)ncell * ksel * 4));
+    HIPCHK(w.near_dist.ensure((size_t)ncell * ksel * 8));
+    HIPCHK(w.nnear.ensure((size_t)ncell * 4));
+    HIPCHK(w.kk.ensure((size_t)ncell * 48));
+    HIPCHK(w.ka.ensure((size_t)ncell * 48));
+    HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
+    HIPCHK(w.cstat.ensure((size_t)ncell * 4));
+    HIPCHK(w.kmaxc.ensure((size_t)ncell * 4));
+    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 8 * 4));
+    HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
+    HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
+    HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
+    if (need_gwr) {
+        HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
+        HIPCHK(w.zc.ensure((size_t)ncell * 96));
+        HIPCHK(w.gstat.ensure((size_t)ncell * 4));
+    }
+    SelWs &s = w.ws;
+    s.ksel = ksel; s.cmax = w.cmax; s.init_nnghs = ctx->p.init_nnghs;
+    s.cell0 = cell0; s.ncell = ncell; s.tile0 = tile0; s.ntile = ntile;
+    s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
+    s.ncand_max = w.small.as<int32_t>();          // [0]
+    s.bucket_cnt = w.small.as<int32_t>() + 8;     // [8..15]
+    s.dscratch = w.dscratch.as<float>();
+    s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
+    s.nnear = w.nnear.as<int32_t>(); s.kk = w.kk.as<int32_t>(); s.ka = w.ka.as<int32_t>();
+    s.vario = w.vario.as<double>(); s.cstat = w.cstat.as<int32_t>(); s.kmaxc = w.kmaxc.as<int32_t>();
+    s.bucket_cells = w.bucket_cells.as<int32_t>();
+    s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
+    w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
+    return 0;
+}
+
+template <int NB>
+void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt);
+}
+
+// tile candidates -> per-cell selection -> kriging, for one (batch, variable)
+int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_t ncell, int64_t tile0,
+                  int64_t ntile, int ksel, bool need_gwr, hipStream_t stream)
+{
+    Work &w = ctx->work[v];
+    const StnDev &st = ctx->var[v].dev;
+    const int nblk = (int)std::min<int64_t>(ntile, 2048);
+    for (;;) {
+        if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr)) return -1;
+        HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
+        {
+            EvScope ev(ctx, stream, EV_TILE);
+            hipLaunchKernelGGL(k_tile_cand, dim3(nblk), dim3(256), 0, stream, st, src, w.ws);
+        }
+        int32_t cmax_seen = 0;
+        HIPCHK(hipMemcpyAsync(&cmax_seen, w.ws.ncand_max, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (cmax_seen <= w.cmax) break;
+        if (cmax_seen > 4096) return fail(ctx, "candidate list of a tile exceeds 4096 stations (station density too high for tile_cells)");
+        w.cmax = (cmax_seen + 127) / 128 * 128;
+    }
+    {
+        size_t lds = (size_t)4 * w.cmax * sizeof(double);
+        if (lds > 32768)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EvScope ev(ctx, stream, EV_SELECT);
+        hipLaunchKernelGGL(k_select, dim3((unsigned)((ncell + 3) / 4)), dim3(256), lds, stream, st, src, w.ws);
+    }
+    if (!src.do_krig) return 0;
+    int32_t cnt[8];
+    HIPCHK(hipMemcpyAsync(cnt, w.ws.bucket_cnt, sizeof cnt, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    {
+        EvScope ev(ctx, stream, EV_UK);
+        for (int b = 0; b < 7; ++b) {
+            if (cnt[b] <= 0) continue;
+            const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell;
+            switch (b + 4) {
+            case 4: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 5: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 6: launch_uk<6>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 7: launch_uk<7>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 8: launch_uk<8>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 9: launch_uk<9>(st, src, w.ws, cells, cnt[b], stream); break;
+            default: launch_uk<10>(st, src, w.ws, cells, cnt[b], stream); break;
+            }
+            ctx->t_launches++;
+            ctx->t_solves += (int64_t)cnt[b] * (src.mth ? 1 : 12);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pick_ksel(const twx_ctx *ctx, int v, int kextra)
+{
+    int k = std::max(ctx->p.init_nnghs, std::max(ctx->var[v].kmax, kextra));
+    k = std::min(k, TWX_MAX_NNGHS) + 1;
+    return std::min(k, TWX_KSEL_MAX);
+}
+
+int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, hipStream_t stream)
+{
+    Work &w = ctx->work[v];
+    HIPCHK(hipMemsetAsync(w.gstat.p, 0, (size_t)w.ws.ncell * 4, stream));
+    EvScope ev(ctx, stream, EV_GWR);
+    int64_t items = w.ws.ncell * 12;
+    hipLaunchKernelGGL(k_gwr_z, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, ctx->var[v].dev, src, w.ws,
+                       w.gw, pt_norm_dev);
+    return 0;
+}
+
+int check_var(twx_ctx *ctx, int v, bool need_obs)
+{
+    if (v < 0 || v > 1) return fail(ctx, "var must be TWX_TMIN or TWX_TMAX");
+    if (ctx->var[v].n <= 0) return fail(ctx, "no station table set for this variable (twx_set_stations)");
+    if (need_obs && !ctx->var[v].has_obs) return fail(ctx, "this entry needs observations (station table was set with obs == NULL)");
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+const char *twx_version(void) { return "topowx_amd libtwxhip 0.1 (gfx950)"; }
+
+const char *twx_last_error(const twx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int twx_create(int device, const twx_params *params, twx_ctx **out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2; // no GPU: fail loudly, no CPU path
+    if (device < 0 || device >= ndev) return -3;
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    twx_ctx *ctx = new twx_ctx();
+    ctx->device = device;
+    if (params) ctx->p = *params;
+    if (ctx->p.init_nnghs <= 0) ctx->p.init_nnghs = 100;
+    if (ctx->p.fixer_tail <= 0) ctx->p.fixer_tail = 15;
+    if (ctx->p.norm_yr0 == 0 && ctx->p.norm_yr1 == 0) { ctx->p.norm_yr0 = 1981; ctx->p.norm_yr1 = 2010; }
+    if (ctx->p.tile_cells <= 0) ctx->p.tile_cells = 8;
+    if (ctx->p.init_nnghs > TWX_MAX_NNGHS) { delete ctx; return -5; }
+    (void)hipEventCreate(&ctx->ev_total_a);
+    (void)hipEventCreate(&ctx->ev_total_b);
+    *out = ctx;
+    return 0;
+}
+
+void twx_destroy(twx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int v = 0; v < 2; ++v) { ctx->var[v].cols.release(); ctx->var[v].obs.release(); ctx->work[v].release(); }
+    for (DevBuf *b : {&ctx->day_dev, &ctx->pt_in, &ctx->pt_aux, &ctx->pt_out, &ctx->fix_scratch, &ctx->fix_lists,
+                      &ctx->flags, &ctx->flag_list})
+        b->release();
+    for (auto &e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (ctx->ev_total_a) (void)hipEventDestroy(ctx->ev_total_a);
+    if (ctx->ev_total_b) (void)hipEventDestroy(ctx->ev_total_b);
+    delete ctx;
+}
+
+int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const int32_t *day_year)
+{
+    if (!ctx) return -1;
+    if (ndays <= 0 || !day_month || !day_year) return fail(ctx, "twx_set_days: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    for (int v = 0; v < 2; ++v)
+        if (ctx->var[v].has_obs) return fail(ctx, "twx_set_days must be called before twx_set_stations with observations");
+    ctx->ndays = ndays;
+    ctx->day_month.assign(day_month, day_month + ndays);
+    ctx->day_year.assign(day_year, day_year + ndays);
+    ctx->mm2chron.resize(ndays); ctx->chron2mm.resize(ndays);
+    DayAxis &da = ctx->da;
+    int pos = 0;
+    for (int m = 1; m <= 12; ++m) {
+        da.moff[m - 1] = pos;
+        for (int64_t d = 0; d < ndays; ++d) {
+            if (day_month[d] < 1 || day_month[d] > 12) return fail(ctx, "twx_set_days: month outside 1..12");
+            if (day_month[d] == m) { ctx->mm2chron[pos] = (int32_t)d; ctx->chron2mm[d] = pos; ++pos; }
+        }
+    }
+    da.moff[12] = pos;
+    // (year, month) runs of the normals period (interp_tair.py:468-481)
+    int y0 = 1 << 30, y1 = -(1 << 30);
+    for (int64_t d = 0; d < ndays; ++d)
+        if (day_year[d] >= ctx->p.norm_yr0 && day_year[d] <= ctx->p.norm_yr1) { y0 = std::min(y0, day_year[d]); y1 = std::max(y1, day_year[d]); }
+    int ny = y0 <= y1 ? y1 - y0 + 1 : 0;
+    std::vector<int32_t> ys((size_t)ny * 12, 0), yc((size_t)ny * 12, 0);
+    for (int64_t d = ndays - 1; d >= 0; --d) {
+        int y = day_year[d];
+        if (ny == 0 || y < y0 || y > y1) continue;
+        size_t s = (size_t)(y - y0) * 12 + (day_month[d] - 1);
+        ys[s] = (int32_t)d; yc[s]++;
+    }
+    size_t total = (size_t)ndays * 4 * 4 + (size_t)ny * 12 * 8 + 4096;
+    HIPCHK(ctx->day_dev.ensure(total));
+    char *cur = ctx->day_dev.as<char>();
+    int32_t *d_mm2c = carve<int32_t>(cur, ndays), *d_c2mm = carve<int32_t>(cur, ndays);
+    int32_t *d_dm = carve<int32_t>(cur, ndays), *d_dy = carve<int32_t>(cur, ndays);
+    int32_t *d_ys = carve<int32_t>(cur, (size_t)ny * 12 + 1), *d_yc = carve<int32_t>(cur, (size_t)ny * 12 + 1);
+    HIPCHK(hipMemcpy(d_mm2c, ctx->mm2chron.data(), ndays * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_c2mm, ctx->chron2mm.data(), ndays * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_dm, day_month, ndays * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_dy, day_year, ndays * 4, hipMemcpyHostToDevice));
+    if (ny) {
+        HIPCHK(hipMemcpy(d_ys, ys.data(), ys.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_yc, yc.data(), yc.size() * 4, hipMemcpyHostToDevice));
+    }
+    da.ndays = (int)ndays; da.mm2chron = d_mm2c; da.chron2mm = d_c2mm; da.day_month = d_dm; da.day_year = d_dy;
+    da.tail = ctx->p.fixer_tail; da.norm_ny = ny; da.ym_start = d_ys; da.ym_cnt = d_yc;
+    return 0;
+}
+
+int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
+{
+    if (!ctx) return -1;
+    if (var < 0 || var > 1 || !t || t->n <= 0) return fail(ctx, "twx_set_stations: bad arguments");
+    if (t->n > (1 << 24)) return fail(ctx, "twx_set_stations: too many stations");
+    HIPCHK(hipSetDevice(ctx->device));
+    VarData &vd = ctx->var[var];
+    const size_t n = (size_t)t->n;
+    // one allocation: 4 static + 7 monthly + 4 trig columns
+    const size_t ncol = 4 + 7 * 12 + 4;
+    std::vector<double> host(ncol * n);
+    double *h = host.data();
+    auto put = [&](const double *srcp, size_t cnt) { std::memcpy(h, srcp, cnt * 8); h += cnt; };
+    put(t->lon, n); put(t->lat, n); put(t->elev, n); put(t->tdi, n);
+    put(t->lst, 12 * n); put(t->norm, 12 * n); put(t->optim_nnghs, 12 * n); put(t->optim_nnghs_anom, 12 * n);
+    put(t->vario_nug, 12 * n); put(t->vario_psill, 12 * n); put(t->vario_rng, 12 * n);
+    const double r = 3.14159265358979323846 / 180.0;
+    for (size_t i = 0; i < n; ++i) h[i] = std::sin(t->lat[i] * r / 2.0);
+    for (size_t i = 0; i < n; ++i) h[n + i] = std::cos(t->lat[i] * r / 2.0);
+    for (size_t i = 0; i < n; ++i) h[2 * n + i] = std::sin(t->lon[i] * r / 2.0);
+    for (size_t i = 0; i < n; ++i) h[3 * n + i] = std::cos(t->lon[i] * r / 2.0);
+    double km = 0;
+    for (size_t i = 0; i < 12 * n; ++i) {
+        if (std::isfinite(t->optim_nnghs[i])) km = std::max(km, t->optim_nnghs[i]);
+        if (std::isfinite(t->optim_nnghs_anom[i])) km = std::max(km, t->optim_nnghs_anom[i]);
+    }
+    HIPCHK(vd.cols.ensure(host.size() * 8));
+    HIPCHK(hipMemcpy(vd.cols.p, host.data(), host.size() * 8, hipMemcpyHostToDevice));
+    const double *d = vd.cols.as<double>();
+    StnDev &s = vd.dev;
+    s.n = (int)n; s.kmax = (int)std::lrint(std::min(km, 1.0e6));
+    s.lon = d; s.lat = d + n; s.elev = d + 2 * n; s.tdi = d + 3 * n;
+    const double *mcol = d + 4 * n;
+    s.lst = mcol; s.norm = mcol + 12 * n; s.optim = mcol + 24 * n; s.optim_anom = mcol + 36 * n;
+    s.nug = mcol + 48 * n; s.psill = mcol + 60 * n; s.rng = mcol + 72 * n;
+    const double *tcol = mcol + 84 * n;
+    s.sph = tcol; s.cph = tcol + n; s.slh = tcol + 2 * n; s.clh = tcol + 3 * n;
+    s.obs = nullptr;
+    vd.n = (int)n; vd.kmax = s.kmax; vd.has_obs = false;
+    if (t->obs) {
+        if (ctx->ndays <= 0) return fail(ctx, "twx_set_stations: call twx_set_days before passing observations");
+        const size_t nd = (size_t)ctx->ndays;
+        // (time, station) -> [station][month-major day]: days become the contiguous axis
+        std::vector<float> tr(n * nd);
+        const size_t B = 64;
+        for (size_t j0 = 0; j0 < n; j0 += B)
+            for (size_t p0 = 0; p0 < nd; p0 += B)
+                for (size_t p = p0; p < std::min(nd, p0 + B); ++p) {
+                    const float *row = t->obs + (size_t)ctx->mm2chron[p] * n;
+                    for (size_t j = j0; j < std::min(n, j0 + B); ++j) tr[j * nd + p] = row[j];
+                }
+        HIPCHK(vd.obs.ensure(tr.size() * 4));
+        HIPCHK(hipMemcpy(vd.obs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
+        s.obs = vd.obs.as<float>();
+        vd.has_obs = true;
+    }
+    return 0;
+}
+
+// ---- point entries -------------------------------------------------------------------
+namespace {
+struct PtDev {
+    twx_pt *pts = nullptr;
+    int32_t *mth = nullptr, *nnghs = nullptr, *excl = nullptr;
+    double *vario = nullptr, *pt_norm = nullptr;
+};
+
+int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *lon, const double *lat,
+                  const int32_t *mth, const int32_t *nnghs, const double *vario, const int32_t *excl,
+                  const double *pt_norm, PtDev &pd)
+{
+    size_t bytes = (size_t)npts * (sizeof(twx_pt) + 3 * 4 + 4 * 8) + 4096;
+    HIPCHK(ctx->pt_in.ensure(bytes));
+    char *cur = ctx->pt_in.as<char>();
+    pd.pts = carve<twx_pt>(cur, npts);
+    std::vector<twx_pt> tmp;
+    if (!pts) {
+        tmp.resize(npts);
+        std::memset(tmp.data(), 0, npts * sizeof(twx_pt));
+        for (int64_t i = 0; i < npts; ++i) { tmp[i].lon = lon[i]; tmp[i].lat = lat[i]; }
+        pts = tmp.data();
+    }
+    HIPCHK(hipMemcpy(pd.pts, pts, npts * sizeof(twx_pt), hipMemcpyHostToDevice));
+    if (mth) { pd.mth = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.mth, mth, npts * 4, hipMemcpyHostToDevice)); }
+    if (nnghs) { pd.nnghs = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.nnghs, nnghs, npts * 4, hipMemcpyHostToDevice)); }
+    if (excl) { pd.excl = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.excl, excl, npts * 4, hipMemcpyHostToDevice)); }
+    if (vario) { pd.vario = carve<double>(cur, npts * 3); HIPCHK(hipMemcpy(pd.vario, vario, npts * 24, hipMemcpyHostToDevice)); }
+    if (pt_norm) { pd.pt_norm = carve<double>(cur, npts); HIPCHK(hipMemcpy(pd.pt_norm, pt_norm, npts * 8, hipMemcpyHostToDevice)); }
+    return 0;
+}
+
+CellSrc point_src(const PtDev &pd, int rm_zero, int do_krig, int do_anom)
+{
+    CellSrc s{};
+    s.mode = 1; s.pts = pd.pts; s.excl = pd.excl; s.mth = pd.mth; s.nnghs_in = pd.nnghs; s.vario_in = pd.vario;
+    s.rm_zero = rm_zero; s.do_krig = do_krig; s.do_anom = do_anom;
+    return s;
+}
+
+int max_k(const int32_t *nnghs, int64_t n)
+{
+    int m = 0;
+    if (nnghs) for (int64_t i = 0; i < n; ++i) m = std::max(m, nnghs[i]);
+    return m;
+}
+}  // namespace
+
+int twx_knn(twx_ctx *ctx, int var, int64_t npts, const double *lon, const double *lat, int32_t k,
+            const int32_t *excl, int rm_zero_dist, int32_t *idx, double *dist, double *wgt, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (check_var(ctx, var, false)) return -1;
+    if (npts <= 0 || !lon || !lat || !idx || k < 1 || k >= TWX_KSEL_MAX) return fail(ctx, "twx_knn: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, nullptr, lon, lat, nullptr, nullptr, nullptr, excl, nullptr, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 0, 0);
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, k + 1, false, nullptr)) return -1;
+    size_t ob = (size_t)npts * k * (4 + 8 + 8) + (size_t)npts * 4 + 4096;
+    HIPCHK(ctx->pt_out.ensure(ob));
+    char *cur = ctx->pt_out.as<char>();
+    int32_t *d_idx = carve<int32_t>(cur, npts * k);
+    double *d_dist = carve<double>(cur, npts * k), *d_wgt = carve<double>(cur, npts * k);
+    int32_t *d_st = carve<int32_t>(cur, npts);
+    hipLaunchKernelGGL(k_sorted_neighbours, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, nullptr, src,
+                       ctx->work[var].ws, (int)k, (int)k, d_idx, d_dist, d_wgt, d_st);
+    HIPCHK(hipMemcpy(idx, d_idx, npts * k * 4, hipMemcpyDeviceToHost));
+    if (dist) HIPCHK(hipMemcpy(dist, d_dist, npts * k * 8, hipMemcpyDeviceToHost));
+    if (wgt) HIPCHK(hipMemcpy(wgt, d_wgt, npts * k * 8, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, d_st, npts * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                    const int32_t *nnghs, const double *vario, const int32_t *excl, int rm_zero_dist,
+                    double *mean, double *variance, int32_t *nnghs_used, int32_t *ngh_idx, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (check_var(ctx, var, false)) return -1;
+    if (npts <= 0 || !pts || !mth || !mean || !variance || !status) return fail(ctx, "twx_krig_points: bad arguments");
+    for (int64_t i = 0; i < npts; ++i)
+        if (mth[i] < 1 || mth[i] > 12) return fail(ctx, "twx_krig_points: month outside 1..12");
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, vario, excl, nullptr, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 1, 0);
+    const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, false, nullptr)) return -1;
+    const int ld = TWX_MAX_NNGHS;
+    size_t ob = (size_t)npts * (8 + 8 + 4 + 4) + (size_t)npts * ld * 4 + 4096;
+    HIPCHK(ctx->pt_out.ensure(ob));
+    char *cur = ctx->pt_out.as<char>();
+    double *d_mean = carve<double>(cur, npts), *d_var = carve<double>(cur, npts);
+    int32_t *d_used = carve<int32_t>(cur, npts), *d_st = carve<int32_t>(cur, npts);
+    int32_t *d_ngh = carve<int32_t>(cur, npts * ld);
+    hipLaunchKernelGGL(k_finalize_krig_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, src,
+                       ctx->work[var].ws, d_mean, d_var, d_used, d_st);
+    std::vector<double> hm(npts), hv(npts);
+    HIPCHK(hipMemcpy(status, d_st, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hm.data(), d_mean, npts * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hv.data(), d_var, npts * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i)
+        if (status[i] == 0) { mean[i] = hm[i]; variance[i] = hv[i]; }
+    if (nnghs_used) HIPCHK(hipMemcpy(nnghs_used, d_used, npts * 4, hipMemcpyDeviceToHost));
+    if (ngh_idx) {
+        hipLaunchKernelGGL(k_sorted_neighbours, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, nullptr, src,
+                           ctx->work[var].ws, 0, ld, d_ngh, (double *)nullptr, (double *)nullptr, (int32_t *)nullptr);
+        HIPCHK(hipMemcpy(ngh_idx, d_ngh, npts * ld * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const double *pt_norm,
+                   const int32_t *mth, const int32_t *nnghs, const int32_t *excl, int rm_zero_dist,
+                   double *out, int64_t ld, int32_t *nnghs_used, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (check_var(ctx, var, true)) return -1;
+    if (npts <= 0 || !pts || !mth || !pt_norm || !out || !status) return fail(ctx, "twx_gwr_points: bad arguments");
+    int maxd = 0;
+    for (int m = 0; m < 12; ++m) maxd = std::max(maxd, ctx->da.moff[m + 1] - ctx->da.moff[m]);
+    for (int64_t i = 0; i < npts; ++i) {
+        if (mth[i] < 1 || mth[i] > 12) return fail(ctx, "twx_gwr_points: month outside 1..12");
+        if (ctx->da.moff[mth[i]] - ctx->da.moff[mth[i] - 1] > ld) return fail(ctx, "twx_gwr_points: ld smaller than the days of the month");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, pt_norm, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 0, 1);
+    const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, true, nullptr)) return -1;
+    if (run_gwr(ctx, var, src, pd.pt_norm, nullptr)) return -1;
+    Work &w = ctx->work[var];
+    HIPCHK(ctx->pt_out.ensure((size_t)npts * ld * 8 + 4096));
+    double *d_out = ctx->pt_out.as<double>();
+    HIPCHK(hipMemset(d_out, 0, (size_t)npts * ld * 8));
+    hipLaunchKernelGGL(k_daily_points, dim3((unsigned)npts), dim3(256), 0, nullptr, ctx->var[var].dev, src, w.ws, w.gw,
+                       ctx->da, d_out, ld, 1);
+    std::vector<int32_t> cs(npts), gs(npts), ka((size_t)npts * 12);
+    HIPCHK(hipMemcpy(cs.data(), w.ws.cstat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gs.data(), w.gw.gstat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ka.data(), w.ws.ka, npts * 48, hipMemcpyDeviceToHost));
+    std::vector<double> ho((size_t)npts * ld);
+    HIPCHK(hipMemcpy(ho.data(), d_out, ho.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i) {
+        status[i] = cs[i] ? cs[i] : gs[i];
+        if (nnghs_used) nnghs_used[i] = status[i] ? 0 : ka[i * 12 + mth[i] - 1];
+        if (status[i] == 0) std::memcpy(out + i * ld, ho.data() + i * ld, (size_t)ld * 8);
+    }
+    return 0;
+}
+
+int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *excl,
+                      int rm_zero_dist, double *daily, double *norms, double *se, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (check_var(ctx, var, daily != nullptr)) return -1;
+    if (npts <= 0 || !pts || !norms || !se || !status) return fail(ctx, "twx_interp_points: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, nullptr, nullptr, nullptr, excl, nullptr, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 1, daily ? 1 : 0);
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, pick_ksel(ctx, var, 0), daily != nullptr, nullptr)) return -1;
+    Work &w = ctx->work[var];
+    const int64_t nd = ctx->ndays;
+    size_t ob = (size_t)npts * (96 * 2 + 4) + (daily ? (size_t)npts * nd * 8 : 0) + 4096;
+    HIPCHK(ctx->pt_out.ensure(ob));
+    char *cur = ctx->pt_out.as<char>();
+    double *d_norm = carve<double>(cur, npts * 12), *d_se = carve<double>(cur, npts * 12);
+    int32_t *d_st = carve<int32_t>(cur, npts);
+    double *d_daily = daily ? carve<double>(cur, npts * nd) : nullptr;
+    hipLaunchKernelGGL(k_finalize_interp_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, w.ws,
+                       d_norm, d_se, d_st);
+    std::vector<int32_t> gs(npts, 0);
+    if (daily) {
+        if (run_gwr(ctx, var, src, nullptr, nullptr)) return -1;
+        hipLaunchKernelGGL(k_daily_points, dim3((unsigned)npts), dim3(256), 0, nullptr, ctx->var[var].dev, src, w.ws,
+                           w.gw, ctx->da, d_daily, nd, 0);
+        HIPCHK(hipMemcpy(gs.data(), w.gw.gstat, npts * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<double> hn((size_t)npts * 12), hs((size_t)npts * 12);
+    HIPCHK(hipMemcpy(status, d_st, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hn.data(), d_norm, hn.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hs.data(), d_se, hs.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i) {
+        if (status[i] == 0 && gs[i]) status[i] = gs[i];
+        if (status[i]) continue;
+        std::memcpy(norms + i * 12, hn.data() + i * 12, 96);
+        std::memcpy(se + i * 12, hs.data() + i * 12, 96);
+        if (daily) HIPCHK(hipMemcpy(daily + i * nd, d_daily + i * nd, (size_t)nd * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int twx_fix_pair(twx_ctx *ctx, int64_t nseries, double *tmin, double *tmax, int32_t *ninvalid, double *norm_tmin,
+                 double *norm_tmax, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (nseries <= 0 || !tmin || !tmax || !ninvalid || !status) return fail(ctx, "twx_fix_pair: bad arguments");
+    if (ctx->ndays <= 0) return fail(ctx, "twx_fix_pair: call twx_set_days first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nd = (size_t)ctx->ndays;
+    const int nblk = (int)std::min<int64_t>(nseries, 1024);
+    HIPCHK(ctx->fix_scratch.ensure((size_t)nseries * nd * 16 + (size_t)nseries * (8 + 192) + 4096));
+    HIPCHK(ctx->fix_lists.ensure((size_t)nblk * nd * 4));
+    char *cur = ctx->fix_scratch.as<char>();
+    FixArgs fa{};
+    fa.ncells = (int)nseries;
+    fa.series_min = carve<double>(cur, nseries * nd); fa.series_max = carve<double>(cur, nseries * nd);
+    fa.norm_min_out = carve<double>(cur, nseries * 12); fa.norm_max_out = carve<double>(cur, nseries * 12);
+    fa.ninv_out = carve<int32_t>(cur, nseries); fa.status_out = carve<int32_t>(cur, nseries);
+    fa.lists = ctx->fix_lists.as<int32_t>();
+    HIPCHK(hipMemcpy(fa.series_min, tmin, nseries * nd * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(fa.series_max, tmax, nseries * nd * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fix_series, dim3(nblk), dim3(256), 0, nullptr, ctx->da, fa);
+    HIPCHK(hipMemcpy(ninvalid, fa.ninv_out, nseries * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, fa.status_out, nseries * 4, hipMemcpyDeviceToHost));
+    std::vector<double> a((size_t)nseries * nd), b((size_t)nseries * nd), nn((size_t)nseries * 12), nx((size_t)nseries * 12);
+    HIPCHK(hipMemcpy(a.data(), fa.series_min, a.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), fa.series_max, b.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nn.data(), fa.norm_min_out, nn.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nx.data(), fa.norm_max_out, nx.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nseries; ++i) {
+        if (status[i]) continue; // the reference raises: the caller's series stay as they were
+        std::memcpy(tmin + i * nd, a.data() + i * nd, nd * 8);
+        std::memcpy(tmax + i * nd, b.data() + i * nd, nd * 8);
+        if (ninvalid[i] > 0) {
+            if (norm_tmin) std::memcpy(norm_tmin + i * 12, nn.data() + i * 12, 96);
+            if (norm_tmax) std::memcpy(norm_tmax + i * 12, nx.data() + i * 12, 96);
+        }
+    }
+    return 0;
+}
+
+int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out)
+{
+    if (!ctx) return -1;
+    if (n <= 0 || !x || !out) return fail(ctx, "twx_pack_i16: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(ctx->pt_out.ensure((size_t)n * 10 + 512));
+    char *cur = ctx->pt_out.as<char>();
+    double *dx = carve<double>(cur, n);
+    int16_t *dout = carve<int16_t>(cur, n);
+    HIPCHK(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dx, n, dout);
+    HIPCHK(hipMemcpy(out, dout, n * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- grid entries ----------------------------------------------------------------------
+int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int vars, void *hip_stream)
+{
+    if (!ctx) return -1;
+    if (!g || !o || g->Y <= 0 || g->X <= 0 || !g->mask || !g->lat || !g->lon || !g->elev || !g->tdi)
+        return fail(ctx, "twx_interp_grid: bad grid");
+    const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
+    if (!has_n && !has_x) return fail(ctx, "twx_interp_grid: no variable requested");
+    const bool daily = (has_n && o->daily_tmin) || (has_x && o->daily_tmax);
+    if (has_n && (check_var(ctx, TWX_TMIN, daily) || !g->lst_night)) return ctx->err.empty() ? fail(ctx, "lst_night missing") : -1;
+    if (has_x && (check_var(ctx, TWX_TMAX, daily) || !g->lst_day)) return ctx->err.empty() ? fail(ctx, "lst_day missing") : -1;
+    if (daily && has_n && has_x && (!o->daily_tmin || !o->daily_tmax))
+        return fail(ctx, "twx_interp_grid: with both variables and daily output both daily buffers are needed (fixer)");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const int ts = ctx->p.tile_cells;
+    const int Y = g->Y, X = g->X;
+    const int ntx = (X + ts - 1) / ts;
+    int64_t batch = ctx->p.batch_cells > 0 ? ctx->p.batch_cells : (daily ? 32768 : 262144);
+    int band = (int)std::max<int64_t>(ts, batch / X / ts * ts);
+    ctx->ev_used = 0; ctx->t_cells = 0; ctx->t_solves = 0; ctx->t_launches = 0;
+    HIPCHK(hipEventRecord(ctx->ev_total_a, stream));
+    ctx->have_total = true;
+    for (int r0 = 0; r0 < Y; r0 += band) {
+        const int r1 = std::min(Y, r0 + band);
+        const int64_t cell0 = (int64_t)r0 * X, ncell = (int64_t)(r1 - r0) * X;
+        const int64_t tile0 = (int64_t)(r0 / ts) * ntx, ntile = (int64_t)((r1 - r0 + ts - 1) / ts) * ntx;
+        CellSrc src[2];
+        for (int v = 0; v < 2; ++v) {
+            if (!(v == 0 ? has_n : has_x)) continue;
+            CellSrc &s = src[v];
+            s = CellSrc{};
+            s.mode = 0; s.Y = Y; s.X = X; s.ts = ts; s.ntx = ntx;
+            s.mask = g->mask; s.lat = g->lat; s.lon = g->lon; s.elev = g->elev; s.tdi = g->tdi;
+            s.lst = v == 0 ? g->lst_night : g->lst_day;
+            s.do_krig = 1; s.do_anom = daily ? 1 : 0;
+            if (run_select_uk(ctx, v, s, cell0, ncell, tile0, ntile, pick_ksel(ctx, v, 0), daily, stream)) return -1;
+            if (daily && run_gwr(ctx, v, s, nullptr, stream)) return -1;
+        }
+        const CellSrc &s0 = has_n ? src[0] : src[1];
+        hipLaunchKernelGGL(k_finalize_grid, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, s0,
+                           ctx->work[0].ws, ctx->work[1].ws, (int)has_n, (int)has_x, *o, 1);
+        ctx->t_cells += ncell;
+        if (daily) {
+            int maxd = 0;
+            for (int m = 0; m < 12; ++m) maxd = std::max(maxd, ctx->da.moff[m + 1] - ctx->da.moff[m]);
+            const int nblk = (maxd + 63) / 64;
+            HIPCHK(ctx->flags.ensure((size_t)ncell * 4 + 256));
+            HIPCHK(ctx->flag_list.ensure((size_t)ncell * 4 + 256));
+            HIPCHK(hipMemsetAsync(ctx->flags.p, 0, (size_t)ncell * 4 + 256, stream));
+            int32_t *d_flag = ctx->flags.as<int32_t>();
+            int32_t *d_count = d_flag + ncell;
+            {
+                EvScope ev(ctx, stream, EV_DAILY);
+                hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
+                                   stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
+                                   ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk);
+            }
+            if (has_n && has_x) {
+                hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_flag,
+                                   ncell, ctx->flag_list.as<int32_t>(), d_count);
+                int32_t nflag = 0;
+                HIPCHK(hipMemcpyAsync(&nflag, d_count, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                if (nflag > 0) {
+                    const int nb = std::min(nflag, 1024);
+                    HIPCHK(ctx->fix_scratch.ensure((size_t)nb * 2 * ctx->ndays * 8));
+                    HIPCHK(ctx->fix_lists.ensure((size_t)nb * ctx->ndays * 4));
+                    FixArgs fa{};
+                    fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells = nflag;
+                    fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
+                    EvScope ev(ctx, stream, EV_FIX);
+                    hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
+                                       ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
+                }
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev_total_b, stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int twx_interp_grid(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int vars)
+{
+    if (!ctx) return -1;
+    if (!g || !o || g->Y <= 0 || g->X <= 0) return fail(ctx, "twx_interp_grid: bad grid");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t yx = (size_t)g->Y * g->X, nd = (size_t)ctx->ndays;
+    const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
+    DevBuf in, outb;
+    size_t ib = yx * (1 + 4 + 4 + 24 * 4) + (size_t)(g->Y + g->X) * 8 + 8192;
+    size_t ob = yx * (4 * 48 + 8) + ((o->daily_tmin ? 1 : 0) + (o->daily_tmax ? 1 : 0)) * yx * nd * 2 + 8192;
+    int rc = -1;
+    twx_grid gd = *g;
+    twx_grid_out od{};
+    do {
+        if (in.ensure(ib) != hipSuccess || outb.ensure(ob) != hipSuccess) { fail(ctx, "twx_interp_grid: device allocation failed"); break; }
+        char *cur = in.as<char>();
+        auto up = [&](const void *h, size_t bytes) -> void * {
+            if (!h) return nullptr;
+            void *d = carve<char>(cur, bytes);
+            return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? d : nullptr;
+        };
+        gd.mask = (const uint8_t *)up(g->mask, yx);
+        gd.lat = (const double *)up(g->lat, (size_t)g->Y * 8);
+        gd.lon = (const double *)up(g->lon, (size_t)g->X * 8);
+        gd.elev = (const float *)up(g->elev, yx * 4);
+        gd.tdi = (const float *)up(g->tdi, yx * 4);
+        gd.climdiv = nullptr;
+        gd.lst_night = has_n ? (const float *)up(g->lst_night, yx * 48) : nullptr;
+        gd.lst_day = has_x ? (const float *)up(g->lst_day, yx * 48) : nullptr;
+        char *oc = outb.as<char>();
+        struct Item { void *host; void *dev; size_t bytes; };
+        std::vector<Item> items;
+        auto mk = [&](void *h, size_t bytes) -> void * {
+            if (!h) return nullptr;
+            void *d = carve<char>(oc, bytes);
+            items.push_back({h, d, bytes});
+            return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? d : nullptr;  // keep the caller's fill values
+        };
+        od.norm_tmin = (float *)mk(o->norm_tmin, yx * 48); od.se_tmin = (float *)mk(o->se_tmin, yx * 48);
+        od.norm_tmax = (float *)mk(o->norm_tmax, yx * 48); od.se_tmax = (float *)mk(o->se_tmax, yx * 48);
+        od.daily_tmin = (int16_t *)mk(o->daily_tmin, yx * nd * 2); od.daily_tmax = (int16_t *)mk(o->daily_tmax, yx * nd * 2);
+        od.ninvalid = (int32_t *)mk(o->ninvalid, yx * 4); od.status = (int32_t *)mk(o->status, yx * 4);
+        if (twx_interp_grid_dev(ctx, &gd, &od, vars, nullptr)) break;
+        if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "twx_interp_grid: kernel execution failed", hipGetLastError()); break; }
+        bool ok = true;
+        for (auto &it : items) ok = ok && hipMemcpy(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) { fail(ctx, "twx_interp_grid: copy back failed"); break; }
+        rc = 0;
+    } while (0);
+    in.release(); outb.release();
+    return rc;
+}
+
+int twx_get_timing(twx_ctx *ctx, twx_timing *t)
+{
+    if (!ctx || !t) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    float acc[EV_NKIND] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        HIPCHK(hipEventSynchronize(ctx->ev_pool[i].b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b));
+        acc[ctx->ev_pool[i].kind] += ms;
+    }
+    twx_timing r{};
+    r.tile_cand_ms = acc[EV_TILE]; r.select_ms = acc[EV_SELECT]; r.uk_ms = acc[EV_UK];
+    r.gwr_ms = acc[EV_GWR]; r.daily_ms = acc[EV_DAILY]; r.fix_ms = acc[EV_FIX];
+    if (ctx->have_total) {
+        HIPCHK(hipEventSynchronize(ctx->ev_total_b));
+        HIPCHK(hipEventElapsedTime(&r.total_ms, ctx->ev_total_a, ctx->ev_total_b));
+    }
+    r.cells = ctx->t_cells; r.uk_solves = ctx->t_solves; r.uk_launches = ctx->t_launches;
+    *t = r;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// twx_select.h -- candidate tiles and per-cell station selection kernels.
+//
+// Reference behaviour (station_select.py:72-192): for every point, haversine to
+// ALL N stations, argsort, take the k nearest, bandwidth = distance of the
+// (k+1)-th, bisquare weights.  On the GPU the all-stations pass is done once per
+// TILE of cells: the triangle inequality on the sphere bounds which stations can
+// be among the KSEL nearest of any cell of the tile, so each cell only ranks the
+// tile's candidate list (a few hundred stations) -- with results identical to the
+// full sort.
+#pragma once
+#include "twx_device.h"
+
+// Workspace of one (batch, variable)
+struct SelWs {
+    int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
+    int cmax;            // candidate slots per tile
+    int init_nnghs;
+    int64_t cell0;       // first global cell id of the batch
+    int64_t ncell;       // cells in the batch
+    int64_t tile0;       // first tile id of the batch
+    int64_t ntile;
+    int32_t *cand;       // [ntile][cmax] station indices, ascending
+    int32_t *ncand;      // [ntile]
+    int32_t *ncand_max;  // [1]
+    float *dscratch;     // [gridDim][n] centre distances
+    int32_t *near_idx;   // [ncell][ksel] by rank (nearest first), -1 padded
+    double *near_dist;   // [ncell][ksel]
+    int32_t *nnear;      // [ncell]
+    int32_t *kk;         // [ncell][12] kriging bandwidth (0 = month not requested)
+    int32_t *ka;         // [ncell][12] GWR bandwidth
+    double *vario;       // [ncell][12][3]
+    int32_t *cstat;      // [ncell] selection-stage status
+    int32_t *kmaxc;      // [ncell] largest kk / ka of the cell
+    int32_t *bucket_cnt; // [8]
+    int32_t *bucket_cells; // [8][ncell]
+    double *uk_mean;     // [ncell][12]
+    double *uk_var;      // [ncell][12]
+    int32_t *uk_stat;    // [ncell]
+};
+
+// ---------------------------------------------------------------------------------
+// k_tile_cand: one workgroup per tile (grid-stride).  Distances from the tile
+// centre to every station (a1), bisection for a radius T holding >= KSEL stations,
+// candidates = stations within T + 2 * (centre -> farthest cell) (+ margin).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs ws)
+{
+    __shared__ int s_cnt[4];
+    __shared__ int s_any;
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float *dsc = ws.dscratch + (int64_t)blockIdx.x * st.n;
+
+    for (int64_t tl = blockIdx.x; tl < ws.ntile; tl += gridDim.x) {
+        const int64_t tile = ws.tile0 + tl;
+        double clon, clat, hd = 0.0;
+        int excl = -1;
+        int any = 1;
+        if (src.mode == 1) {
+            clon = src.pts[tile].lon; clat = src.pts[tile].lat;
+            excl = src.excl ? src.excl[tile] : -1;
+        } else {
+            int ty = (int)(tile / src.ntx), tx = (int)(tile % src.ntx);
+            int r0 = ty * src.ts, r1 = min(r0 + src.ts, src.Y) - 1;
+            int q0 = tx * src.ts, q1 = min(q0 + src.ts, src.X) - 1;
+            clat = 0.5 * (src.lat[r0] + src.lat[r1]);
+            clon = 0.5 * (src.lon[q0] + src.lon[q1]);
+            hd = fmax(fmax(hav_km(clon, clat, src.lon[q0], src.lat[r0]), hav_km(clon, clat, src.lon[q1], src.lat[r0])),
+                      fmax(hav_km(clon, clat, src.lon[q0], src.lat[r1]), hav_km(clon, clat, src.lon[q1], src.lat[r1])));
+            // skip tiles without a single unmasked cell
+            if (t == 0) s_any = 0;
+            __syncthreads();
+            int mine = 0;
+            int nr = r1 - r0 + 1, nq = q1 - q0 + 1;
+            for (int i = t; i < nr * nq; i += 256)
+                mine |= src.mask[(int64_t)(r0 + i / nq) * src.X + (q0 + i % nq)] != 0;
+            if (mine) s_any = 1;
+            __syncthreads();
+            any = s_any;
+        }
+        if (!any) {
+            if (t == 0) ws.ncand[tl] = 0;
+            __syncthreads();
+            continue;
+        }
+        // distances (float is enough for a conservative bound; margin below)
+        float dmax = 0.f;
+        int nvalid = 0;
+        for (int j = t; j < st.n; j += 256) {
+            double d = hav_km(clon, clat, st.lon[j], st.lat[j]);
+            float f = (float)d;
+            if (j == excl || (src.rm_zero && d == 0.0)) f = -1.f; // dropped (point mode)
+            else { dmax = fmaxf(dmax, f); ++nvalid; }
+            dsc[j] = f;
+        }
+        dmax = (float)wave_max((double)dmax);
+        nvalid = wave_sum_i(nvalid);
+        __shared__ float s_dmax[4];
+        if (lane == 0) { s_dmax[wv] = dmax; s_cnt[wv] = nvalid; }
+        __syncthreads();
+        dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        nvalid = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+        float T;
+        if (nvalid <= ws.ksel) {
+            T = 3.0e38f;
+        } else {
+            float lo = 0.f, hi = dmax;
+            for (int it = 0; it < 24; ++it) {
+                float mid = 0.5f * (lo + hi);
+                int c = 0;
+                for (int j = t; j < st.n; j += 256) { float f = dsc[j]; c += (f >= 0.f && f <= mid); }
+                c = wave_sum_i(c);
+                if (lane == 0) s_cnt[wv] = c;
+                __syncthreads();
+                c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                __syncthreads();
+                if (c >= ws.ksel) hi = mid; else lo = mid;
+            }
+            T = hi;
+        }
+        const float R = (T > 1.0e38f) ? T : (T * 1.000001f + 2.02f * (float)hd + 0.05f);
+        // ordered compaction
+        if (t == 0) s_base = 0;
+        __syncthreads();
+        for (int j0 = 0; j0 < st.n; j0 += 256) {
+            int j = j0 + t;
+            bool f = false;
+            if (j < st.n) { float d = dsc[j]; f = (d >= 0.f && d <= R); }
+            unsigned long long b = __ballot(f);
+            int pre = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[wv] = __popcll(b);
+            __syncthreads();
+            int off = s_base;
+            for (int w = 0; w < wv; ++w) off += s_cnt[w];
+            if (f && off + pre < ws.cmax) ws.cand[tl * ws.cmax + off + pre] = j;
+            __syncthreads();
+            if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            __syncthreads();
+        }
+        if (t == 0) {
+            ws.ncand[tl] = s_base;
+            atomicMax(ws.ncand_max, s_base);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_select: one wavefront per cell (4 cells per workgroup).
+//   a1/a2  distances to the tile's candidates, rank by counting (ties -> smaller
+//          station index), nearest list by rank
+//   a3     nnghs / nnghs_anom = int(rint(weighted mean of neighbours' optimum))
+//   a4     variogram parameters = weighted means over Select(nnghs)
+// Dynamic LDS: 4 * cmax doubles.
+// ---------------------------------------------------------------------------------
+struct SmoothOut { int status; int k; };
+
+__device__ __forceinline__ double bisq(double d, double dbw)
+{
+    double r = d / dbw;
+    double u = 1.0 - r * r;
+    return u * u;
+}
+
+// weighted mean of field[idx] over the k nearest with finite field, weights of Select(k)
+// (station_select.py:164-169).  All lanes return the same values.
+__device__ __forceinline__ int smooth3(const double *snd, const int *sidx, int nnear, int k,
+                                       const double *f0, const double *f1, const double *f2,
+                                       int lane, double out[3])
+{
+    if (k >= nnear) return TWX_CELL_FEW_STATIONS;
+    const double dbw = snd[k];
+    if (!(dbw > 0.0)) return TWX_CELL_NUMERIC;
+    double n0 = 0, n1 = 0, n2 = 0, den = 0;
+    int cnt = 0;
+    for (int r = lane; r < k; r += 64) {
+        int j = sidx[r];
+        double v0 = f0[j];
+        if (finite_d(v0)) {
+            double w = bisq(snd[r], dbw);
+            n0 += v0 * w; den += w; ++cnt;
+            if (f1) { n1 += f1[j] * w; n2 += f2[j] * w; }
+        }
+    }
+    n0 = wave_sum(n0); den = wave_sum(den); cnt = wave_sum_i(cnt);
+    if (f1) { n1 = wave_sum(n1); n2 = wave_sum(n2); }
+    if (cnt == 0) return -1; // caller maps to NNGHS / VARIO
+    if (!(den != 0.0)) return TWX_CELL_NUMERIC;
+    out[0] = n0 / den; out[1] = n1 / den; out[2] = n2 / den;
+    return TWX_CELL_OK;
+}
+
+__global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws)
+{
+    extern __shared__ double s_dyn[];
+    __shared__ double s_nd[4][TWX_KSEL_MAX];
+    __shared__ int s_ni[4][TWX_KSEL_MAX];
+    __shared__ int s_np[4][TWX_KSEL_MAX];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t lc = (int64_t)blockIdx.x * 4 + wv;        // local cell
+    const bool in_range = lc < ws.ncell;
+    const int64_t c = ws.cell0 + (in_range ? lc : 0);       // global cell id
+    const bool valid = in_range && cell_valid(src, c);
+    double *sd = s_dyn + (size_t)wv * ws.cmax;
+    double *snd = s_nd[wv];
+    int *sni = s_ni[wv];
+    int *snp = s_np[wv];
+
+    int ncand = 0;
+    const int32_t *cand = nullptr;
+    CellVals cv = {0, 0, 0, 0};
+    int excl = -1;
+    if (valid) {
+        int64_t tl = cell_tile(src, c) - ws.tile0;
+        ncand = min(ws.ncand[tl], ws.cmax);
+        cand = ws.cand + tl * ws.cmax;
+        cv = cell_load(src, c);
+        if (src.mode == 1 && src.excl) excl = src.excl[c];
+    }
+    // phase 1: distances
+    int nv = 0;
+    for (int j = lane; j < ncand; j += 64) {
+        int s = cand[j];
+        double d = hav_km(cv.lon, cv.lat, st.lon[s], st.lat[s]);
+        if (s == excl || (src.rm_zero && d == 0.0)) d = INFINITY; else ++nv;
+        sd[j] = d;
+    }
+    for (int r = lane; r < TWX_KSEL_MAX; r += 64) snp[r] = -1;
+    nv = wave_sum_i(nv);
+    __syncthreads();
+    // phase 2: rank by counting
+    for (int j = lane; j < ncand; j += 64) {
+        double dj = sd[j];
+        if (dj == INFINITY) continue;
+        int rank = 0;
+        for (int i = 0; i < ncand; ++i) {
+            double di = sd[i];
+            rank += (di < dj) || (di == dj && i < j);
+        }
+        if (rank < ws.ksel) snp[rank] = j;
+    }
+    __syncthreads();
+    const int nnear = min(nv, ws.ksel);
+    for (int r = lane; r < TWX_KSEL_MAX; r += 64) {
+        int p = (r < nnear) ? snp[r] : -1;
+        int s = p >= 0 ? cand[p] : -1;
+        double d = p >= 0 ? sd[p] : INFINITY;
+        snd[r] = d; sni[r] = s;
+        if (valid && r < ws.ksel) {
+            ws.near_idx[lc * ws.ksel + r] = s;
+            ws.near_dist[lc * ws.ksel + r] = d;
+        }
+    }
+    __syncthreads();
+    if (!in_range) return;
+    if (!valid) {
+        if (lane == 0) { ws.cstat[lc] = TWX_CELL_MASKED; ws.kmaxc[lc] = 0; ws.nnear[lc] = 0; }
+        return;
+    }
+    // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
+    int status = TWX_CELL_OK, kkmax = 0;
+    const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
+    const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
+    const size_t n = (size_t)st.n;
+    for (int m0 = 0; m0 < 12; ++m0) {
+        int k = 0, kan = 0;
+        double vp[3] = {0, 0, 0};
+        if ((only == 0 || only == m0 + 1) && status == TWX_CELL_OK) {
+            double tmp[3];
+            if (src.do_krig) {
+                // KrigTair.__get_nnghs (interp_tair.py:821-835)
+                if (k_in > 0) k = k_in;
+                else {
+                    int rc = smooth3(snd, sni, nnear, ws.init_nnghs, st.optim + m0 * n, nullptr, nullptr, lane, tmp);
+                    if (rc == -1) rc = TWX_CELL_NNGHS;
+                    if (rc) status = rc; else k = (int)rint(tmp[0]);
+                }
+                if (!status && (k < 1 || k > TWX_MAX_NNGHS)) status = TWX_CELL_RANGE;
+                // KrigTair.__get_vario_params (interp_tair.py:837-851), weights of Select(k)
+                if (!status) {
+                    bool given = src.mode == 1 && src.vario_in && finite_d(src.vario_in[c * 3]);
+                    if (given) {
+                        vp[0] = src.vario_in[c * 3]; vp[1] = src.vario_in[c * 3 + 1]; vp[2] = src.vario_in[c * 3 + 2];
+                        if (k >= nnear) status = TWX_CELL_FEW_STATIONS;
+                    } else {
+                        int rc = smooth3(snd, sni, nnear, k, st.nug + m0 * n, st.psill + m0 * n, st.rng + m0 * n, lane, vp);
+                        if (rc == -1) rc = TWX_CELL_VARIO;
+                        if (rc) status = rc;
+                    }
+                }
+            }
+            // GwrTairAnom.__get_nnghs (interp_tair.py:245-259)
+            if (!status && src.do_anom) {
+                if (k_in > 0) kan = k_in;
+                else {
+                    int rc = smooth3(snd, sni, nnear, ws.init_nnghs, st.optim_anom + m0 * n, nullptr, nullptr, lane, tmp);
+                    if (rc == -1) rc = TWX_CELL_NNGHS;
+                    if (rc) status = rc; else kan = (int)rint(tmp[0]);
+                }
+                if (!status && (kan < 1 || kan > TWX_MAX_NNGHS)) status = TWX_CELL_RANGE;
+                if (!status && kan >= nnear) status = TWX_CELL_FEW_STATIONS;
+                if (!status && !(snd[kan] > 0.0)) status = TWX_CELL_NUMERIC;
+            }
+        }
+        if (status) { k = 0; kan = 0; }
+        kkmax = max(kkmax, k);
+        if (lane == 0) {
+            ws.kk[lc * 12 + m0] = k;
+            ws.ka[lc * 12 + m0] = kan;
+            ws.vario[(lc * 12 + m0) * 3 + 0] = vp[0];
+            ws.vario[(lc * 12 + m0) * 3 + 1] = vp[1];
+            ws.vario[(lc * 12 + m0) * 3 + 2] = vp[2];
+        }
+    }
+    if (lane == 0) {
+        ws.cstat[lc] = status;
+        ws.nnear[lc] = nnear;
+        ws.uk_stat[lc] = TWX_CELL_OK;
+        ws.kmaxc[lc] = status ? 0 : kkmax;
+        if (!status && kkmax > 0) {
+            int nb = (kkmax + 7 + 15) / 16;
+            if (nb < 4) nb = 4;
+            int pos = atomicAdd(&ws.bucket_cnt[nb - 4], 1);
+            ws.bucket_cells[(int64_t)(nb - 4) * ws.ncell + pos] = (int32_t)lc;
+        }
+    }
+}
