@@ -1,0 +1,235 @@
+"""GPU parity: libtwxhip (through the C ABI) vs the CPU oracle and the golden
+vectors.  Tolerance from BASELINE.json: 1e-4 degC on temperatures, integer
+indices / bandwidths / ninvalid bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # degC (north_star)
+
+
+@pytest.fixture(scope="module")
+def env(orc, golden, golden_case):
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    yield dict(lib=_lib, ctx=ctx, grid=grid, tmin=tmin, tmax=tmax, dbn=orc.Db(tmin), dbx=orc.Db(tmax),
+               prm=orc.params())
+    ctx.close()
+
+
+def _pts(ctx, grid, cells, var):
+    r, c = cells[:, 0], cells[:, 1]
+    lst = grid["lst_night" if var == "tmin" else "lst_day"][:, r, c].T
+    return ctx.make_pts(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], lst)
+
+
+def test_knn_matches_reference_station_select(env, golden):
+    ctx, lib = env["ctx"], env["lib"]
+    for k in (35, 100, 147):
+        for rmz in (0, 1):
+            sel = np.nonzero((golden["sel_k"] == k) & (golden["sel_rmz"] == rmz))[0]
+            idx, dist, wgt, st = ctx.knn(lib.TMIN, golden["sel_lon"][sel], golden["sel_lat"][sel], k,
+                                         excl=golden["sel_excl"][sel], rm_zero_dist=bool(rmz))
+            assert np.all(st == 0)
+            assert np.array_equal(idx, golden["sel_idx"][sel][:, :k])         # bit-exact
+            np.testing.assert_allclose(dist, golden["sel_dist"][sel][:, :k], rtol=1e-12, atol=1e-10)
+            np.testing.assert_allclose(wgt, golden["sel_wgt"][sel][:, :k], rtol=1e-10, atol=1e-12)
+
+
+def test_krig_points_golden(env, golden):
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    pts = _pts(ctx, grid, golden["kr_cell"], "tmin")
+    mean, var, used, st, ngh = ctx.krig_points(lib.TMIN, pts, golden["kr_mth"], want_idx=True)
+    assert np.all(st == 0)
+    assert np.array_equal(used, golden["kr_nnghs"])
+    assert np.abs(mean - golden["kr_mean"]).max() < TOL
+    assert np.abs(var - golden["kr_var"]).max() < TOL
+    # neighbours used == oracle's (ascending station index)
+    for i in range(pts.size):
+        r, c = golden["kr_cell"][i]
+        rc, idx, _, _ = __import__("oracle.pyoracle", fromlist=["x"]).select(env["dbn"], grid["lat"][r], grid["lon"][c], int(used[i]))
+        assert np.array_equal(ngh[i, :used[i]], idx)
+        assert np.all(ngh[i, used[i]:] == -1)
+
+
+def test_krig_points_explicit_arguments(env, golden, orc):
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    pts = _pts(ctx, grid, np.tile(golden["krx_cell"], (4, 1)), "tmin")
+    nan = np.nan
+    mean, var, used, st, _ = ctx.krig_points(
+        lib.TMIN, pts, 3, nnghs=[57, 40, 0, 0],
+        vario=[[nan, nan, nan], [0.2, 1.1, 35.0], [0.3, 0.9, 0.0], [nan, nan, nan]],
+        excl=[-1, -1, -1, int(golden["krx_rm"])])
+    assert np.all(st == 0)
+    np.testing.assert_allclose(np.column_stack([mean, var]), golden["krx"], atol=TOL, rtol=0)
+    assert used[0] == 57 and used[1] == 40
+
+
+def test_grid_normals_vs_oracle(env, orc):
+    ctx, grid = env["ctx"], env["grid"]
+    rs, cs = slice(3, 43), slice(50, 90)      # 40x40 cells, not aligned to the 8-cell tiles
+    want = orc.interp_grid(env["dbn"], env["dbx"], env["prm"], grid, daily=False, nthreads=8, rows=rs, cols=cs)
+    got = ctx.interp_grid(grid, daily=False, rows=rs, cols=cs)
+    assert np.array_equal(got["status"], want["status"]) and np.all(got["status"] == 0)
+    for k in ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax"):
+        assert np.abs(got[k].astype(np.float64) - want[k]).max() < TOL, k
+    assert np.all(got["ninvalid"] == 0)
+
+
+def test_grid_mask_and_fill_values(env, orc):
+    ctx, lib = env["ctx"], env["lib"]
+    grid = dict(env["grid"])
+    mask = np.zeros_like(grid["mask"])
+    mask[5:9, 5:30:3] = 1
+    grid["mask"] = mask
+    rs, cs = slice(0, 16), slice(0, 40)
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
+    m = mask[rs, cs] != 0
+    assert np.all(got["status"][~m] == -1) and np.all(got["status"][m] == 0)
+    assert np.all(got["norm_tmin"][:, ~m] == lib.FILL_F4) and np.all(got["se_tmin"][:, ~m] == lib.FILL_F4)
+    assert np.all(got["ninvalid"][~m] == lib.FILL_I4)
+    want = orc.interp_grid(env["dbn"], None, env["prm"], grid, rows=rs, cols=cs)
+    assert np.abs(got["norm_tmin"][:, m].astype(np.float64) - want["norm_tmin"][:, m]).max() < TOL
+
+
+def test_gwr_points_golden(env, golden, orc):
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    cells = golden["it_cell"]
+    pts = _pts(ctx, grid, cells, "tmin")
+    for m in (1, 2, 7):
+        pn = golden["it_norms"][:, m - 1]
+        out, used, st = ctx.gwr_points(lib.TMIN, pts, pn, m)
+        assert np.all(st == 0)
+        idx = env["tmin"].mth_idx[m]
+        np.testing.assert_allclose(out[:, :idx.size], golden["it_daily"][:, idx], atol=TOL, rtol=0)
+        for i in range(pts.size):
+            rc, _, ka, _, _ = orc.gwr_mth(env["dbn"], env["prm"], orc.make_pt(pts["lon"][i], pts["lat"][i], pts["elev"][i],
+                                                                          pts["tdi"][i], pts["lst"][i]), 0.0, m)
+            assert used[i] == ka
+
+
+def test_interp_points_golden_and_xval(env, golden):
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    d, norms, se, st = ctx.interp_points(lib.TMIN, _pts(ctx, grid, golden["it_cell"], "tmin"))
+    assert np.all(st == 0)
+    assert np.abs(norms - golden["it_norms"]).max() < TOL and np.abs(se - golden["it_se"]).max() < TOL
+    assert np.abs(d - golden["it_daily"]).max() < TOL
+    # leave-one-out (XvalTairOverall.run_interp, optimize.py:579-604)
+    c, j = env["dbn"].cols, golden["xv_idx"]
+    pts = ctx.make_pts(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j].T)
+    d, norms, se, st = ctx.interp_points(lib.TMIN, pts, excl=j, rm_zero_dist=True)
+    assert np.all(st == 0)
+    assert np.abs(norms - golden["xv_norms"]).max() < TOL and np.abs(d - golden["xv_daily"]).max() < TOL
+
+
+@pytest.mark.parametrize("lowered", [False, True])
+def test_grid_daily_with_fixer_vs_oracle(env, orc, golden_case, lowered):
+    import make_golden
+    lib, grid = env["lib"], env["grid"]
+    tmax = make_golden.lowered_tmax(golden_case[2]) if lowered else golden_case[2]
+    ctx = lib.Context()
+    ctx.set_stations(lib.TMIN, golden_case[1])
+    ctx.set_stations(lib.TMAX, tmax)
+    dbx = orc.Db(tmax)
+    rs, cs = slice(60, 70), slice(11, 24)
+    want = orc.interp_grid(env["dbn"], dbx, env["prm"], grid, daily=True, nthreads=8, rows=rs, cols=cs)
+    got = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    ctx.close()
+    assert np.array_equal(got["status"], want["status"]) and np.all(got["status"] == 0)
+    assert np.array_equal(got["ninvalid"], want["ninvalid"])            # exact
+    assert (want["ninvalid"].max() > 0) == lowered
+    for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+        assert np.abs(got[k].astype(np.float64) - want[k]).max() < TOL, k
+    for k in ("daily_tmin", "daily_tmax"):
+        dd = np.abs(got[k].astype(int) - want[k].astype(int))
+        assert dd.max() <= 1 and (dd == 0).mean() > 0.9999          # +-1 LSB at a rounding boundary at most
+
+
+def test_interp_pt_goldens_through_grid(env, golden, golden_case):
+    """PtInterpTair.interp_pt goldens (reference orchestration incl. fixer)."""
+    import make_golden
+    lib, grid = env["lib"], env["grid"]
+    ctx = lib.Context()
+    ctx.set_stations(lib.TMIN, golden_case[1])
+    ctx.set_stations(lib.TMAX, make_golden.lowered_tmax(golden_case[2]))
+    from oracle import pyoracle
+    for i, (r, c) in enumerate(golden["lo_cell"]):
+        got = ctx.interp_grid(grid, daily=True, rows=slice(r, r + 1), cols=slice(c, c + 1))
+        assert got["status"][0, 0] == 0 and got["ninvalid"][0, 0] == golden["lo_ninv"][i]
+        assert np.abs(got["norm_tmin"][:, 0, 0] - golden["lo_nmin"][i]).max() < TOL
+        assert np.abs(got["norm_tmax"][:, 0, 0] - golden["lo_nmax"][i]).max() < TOL
+        for v, key in (("tmin", "lo_tmin"), ("tmax", "lo_tmax")):
+            dd = np.abs(got["daily_" + v][:, 0, 0].astype(int) - pyoracle.pack_i16(golden[key][i]).astype(int))
+            assert dd.max() <= 1 and (dd == 0).mean() > 0.999
+    ctx.close()
+
+
+def test_fix_pair_and_pack(env, golden, orc):
+    ctx = env["ctx"]
+    nd = ctx.ndays
+    a = np.tile(golden["fx_in_min"], (1, 3))[:, :nd]
+    b = np.tile(golden["fx_in_max"], (1, 3))[:, :nd]
+    fa, fb, ninv, nmin, nmax, st = ctx.fix_pair(a, b)
+    for i in range(a.shape[0]):
+        rc, oa, ob, on = orc.fixer(a[i], b[i])
+        assert st[i] == rc == 0 and ninv[i] == on
+        np.testing.assert_allclose(fa[i], oa, atol=1e-12, rtol=0)
+        np.testing.assert_allclose(fb[i], ob, atol=1e-12, rtol=0)
+        if on > 0:
+            np.testing.assert_allclose(nmin[i], orc.recompute_norms(oa, env["dbn"].day_month, env["dbn"].day_year), atol=1e-10)
+    # window without a valid day: the reference raises (interp_tair.py:192)
+    z = np.zeros((1, nd))
+    _, _, _, _, _, st = ctx.fix_pair(z, z - 1.0)
+    assert st[0] == 5
+    assert np.array_equal(ctx.pack_i16(golden["pk_in"]), golden["pk_out"])     # bit-exact
+
+
+def test_failure_statuses(env, orc):
+    """Cells the reference would abandon keep their fill values (step25:154-160)."""
+    from topowx_amd import stationdb as sdb, synth
+    lib, grid = env["lib"], env["grid"]
+    # (1) fewer than init_nnghs+1 stations -> IndexError in the reference
+    few = synth.make_stations(grid["bbox"], 60, 5, "tmin")
+    ctx = lib.Context()
+    ctx.set_stations(lib.TMIN, few, with_obs=False)
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=slice(0, 4), cols=slice(0, 4))
+    want = orc.interp_grid(orc.Db(few), None, env["prm"], grid, rows=slice(0, 4), cols=slice(0, 4))
+    assert np.all(got["status"] == 1) and np.array_equal(got["status"], want["status"])
+    assert np.all(got["norm_tmin"] == lib.FILL_F4)
+    # (2) no finite optim_nnghs among the neighbours
+    st = synth.make_stations(grid["bbox"], 300, 6, "tmin")
+    st.stns[sdb.get_optim_varname(5)][:] = np.nan
+    ctx.set_stations(lib.TMIN, st, with_obs=False)
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=slice(0, 2), cols=slice(0, 2))
+    want = orc.interp_grid(orc.Db(st), None, env["prm"], grid, rows=slice(0, 2), cols=slice(0, 2))
+    assert np.all(got["status"] == 2) and np.array_equal(got["status"], want["status"])
+    # (3) no finite variogram parameters
+    st = synth.make_stations(grid["bbox"], 300, 6, "tmin")
+    st.stns[sdb.get_krigparam_varname(2, sdb.VARIO_NUG)][:] = np.nan
+    ctx.set_stations(lib.TMIN, st, with_obs=False)
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=slice(0, 2), cols=slice(0, 2))
+    assert np.all(got["status"] == 3)
+    # (4) duplicate station location, zero nugget -> singular kriging matrix
+    st = synth.make_stations(grid["bbox"], 300, 6, "tmin")
+    j = np.argmin((st.stns[sdb.LON] - grid["lon"][0]) ** 2 + (st.stns[sdb.LAT] - grid["lat"][0]) ** 2)
+    i = (j + 1) % st.stns.size
+    st.stns[sdb.LON][i], st.stns[sdb.LAT][i] = st.stns[sdb.LON][j], st.stns[sdb.LAT][j]
+    pts = ctx.make_pts(grid["lon"][0], grid["lat"][0], 1500.0, 30.0, np.zeros(12))
+    ctx.set_stations(lib.TMIN, st, with_obs=False)
+    _, _, _, s4, _ = ctx.krig_points(lib.TMIN, pts, 1, nnghs=40, vario=[0.0, 1.0, 40.0])
+    assert s4[0] == 4
+    ctx.close()
+
+
+def test_cell_on_station_is_exact_interpolator(env):
+    ctx, lib = env["ctx"], env["lib"]
+    c = env["dbn"].cols
+    j = 17
+    pts = ctx.make_pts(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+    mean, var, _, st, _ = ctx.krig_points(lib.TMIN, pts, 6)
+    # pair distances are kept in fp32 registers on the GPU: exactness holds to ~1e-7 degC
+    assert st[0] == 0 and abs(mean[0] - c["norm"][5, j]) < 1e-6 and abs(var[0]) < 1e-6

@@ -1,0 +1,79 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every
+symbol include/twx.h declares, and fails loudly without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from topowx_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call([os.path.join(ROOT, "build.sh")])
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "twx.h")).read()
+    declared = set(re.findall(r"\b(twx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"twx_ctx"}
+    assert declared == set(built.EXPORTS)
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.twx_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.twx_version()         # pure host call, no GPU needed
+
+
+def test_struct_layouts_match_header(built):
+    # sizes the C side compiles to (LP64): any drift between twx.h and _lib.py shows here
+    assert ctypes.sizeof(built.TwxParams) == 32
+    assert ctypes.sizeof(built.TwxStationTable) == 8 * 13
+    assert ctypes.sizeof(built.TwxPt) == 8 * 16 == built.PT_DTYPE.itemsize
+    assert ctypes.sizeof(built.TwxGrid) == 8 + 8 * 8
+    assert ctypes.sizeof(built.TwxGridOut) == 8 * 8
+    assert ctypes.sizeof(built.TwxTiming) == 4 * 7 + 4 + 8 * 3
+
+
+def test_no_gpu_fails_loudly(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(built.TwxError):
+        built.Context()
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "topowx_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "twx_oracle" not in src and "libtwxoracle" not in src, f
+
+
+def test_days_metadata():
+    import datetime as dt
+    from topowx_amd.dates import MONTH, YEAR, get_days_metadata, get_mth_metadata
+    d = get_days_metadata(dt.date(1948, 1, 1), dt.date(2016, 12, 31))
+    assert d.size == 25203
+    cnt = [int((d[MONTH] == m).sum()) for m in range(1, 13)]
+    assert min(cnt) == 1950 and max(cnt) == 2139
+    assert d[YEAR][0] == 1948 and d.YMD[-1] == 20161231
+    assert get_mth_metadata(1981, 2010).size == 360
+
+
+def test_synth_is_deterministic():
+    from topowx_amd import synth
+    g1, a1, _ = synth.make_case("C1")
+    g2, a2, _ = synth.make_case("C1")
+    assert np.array_equal(g1["elev"], g2["elev"]) and a1.stns.tobytes() == a2.stns.tobytes()
+    assert g1["lat"][0] > g1["lat"][-1]                      # north-up (step25:113-116)
+    assert a1.stns.size == 500
