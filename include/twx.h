@@ -37,7 +37,7 @@ extern "C" {
 
 /* largest supported neighbourhood (the reference ladder tops out at 147,
  * step21:198); larger smoothed bandwidths give TWX_CELL_RANGE */
-#define TWX_MAX_NNGHS 153
+#define TWX_MAX_NNGHS 152
 
 /* per-cell status codes */
 #define TWX_CELL_OK 0

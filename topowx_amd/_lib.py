@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libtwxhip.so")
 
 TMIN, TMAX = 0, 1
 VAR_TMIN_BIT, VAR_TMAX_BIT = 1, 2
-MAX_NNGHS = 153
+MAX_NNGHS = 152
 FILL_I2 = np.int16(-32767)
 FILL_F4 = np.float32(9.969209968386869e36)
 FILL_I4 = np.int32(-2147483647)

@@ -142,7 +142,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
     HIPCHK(w.cstat.ensure((size_t)ncell * 4));
     HIPCHK(w.kmaxc.ensure((size_t)ncell * 4));
-    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 8 * 4));
+    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 7 * 4));
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
@@ -202,6 +202,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         hipLaunchKernelGGL(k_select, dim3((unsigned)((ncell + 3) / 4)), dim3(256), lds, stream, st, src, w.ws);
     }
     if (!src.do_krig) return 0;
+    hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     int32_t cnt[8];
     HIPCHK(hipMemcpyAsync(cnt, w.ws.bucket_cnt, sizeof cnt, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -209,7 +210,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         EvScope ev(ctx, stream, EV_UK);
         for (int b = 0; b < 7; ++b) {
             if (cnt[b] <= 0) continue;
-            const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell;
+            const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell * 12;
             switch (b + 4) {
             case 4: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
             case 5: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
@@ -220,7 +221,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
             default: launch_uk<10>(st, src, w.ws, cells, cnt[b], stream); break;
             }
             ctx->t_launches++;
-            ctx->t_solves += (int64_t)cnt[b] * (src.mth ? 1 : 12);
+            ctx->t_solves += (int64_t)cnt[b];
         }
     }
     HIPCHK(hipGetLastError());

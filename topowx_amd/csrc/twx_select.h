@@ -32,7 +32,7 @@ struct SelWs {
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *kmaxc;      // [ncell] largest kk / ka of the cell
     int32_t *bucket_cnt; // [8]
-    int32_t *bucket_cells; // [8][ncell]
+    int32_t *bucket_cells; // [7][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
@@ -318,11 +318,35 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
         ws.nnear[lc] = nnear;
         ws.uk_stat[lc] = TWX_CELL_OK;
         ws.kmaxc[lc] = status ? 0 : kkmax;
-        if (!status && kkmax > 0) {
-            int nb = (kkmax + 7 + 15) / 16;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_bucket_items: counting sort of the (cell, month) kriging items by matrix size.
+// NB = ceil((k + 8) / 16) block rows: k C rows + 7 RHS rows at the fixed rows
+// NP-7..NP-1, with the last C column kept out of the 4-column panel that holds the
+// first RHS column.  LDS counters per workgroup, one global atomic per (workgroup,
+// bucket).  Order inside a bucket is irrelevant (items are independent).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
+{
+    __shared__ int s_cnt[8], s_base[8];
+    const int t = threadIdx.x;
+    if (t < 8) s_cnt[t] = 0;
+    __syncthreads();
+    const int64_t item = (int64_t)blockIdx.x * 256 + t;
+    int nb = -1, rank = 0;
+    if (item < ws.ncell * 12) {
+        const int64_t lc = item / 12;
+        const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
+        if (k > 0) {
+            nb = (k + 8 + 15) / 16;
             if (nb < 4) nb = 4;
-            int pos = atomicAdd(&ws.bucket_cnt[nb - 4], 1);
-            ws.bucket_cells[(int64_t)(nb - 4) * ws.ncell + pos] = (int32_t)lc;
+            rank = atomicAdd(&s_cnt[nb - 4], 1);
         }
     }
+    __syncthreads();
+    if (t < 7 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
+    __syncthreads();
+    if (nb >= 4) ws.bucket_cells[(int64_t)(nb - 4) * ws.ncell * 12 + s_base[nb - 4] + rank] = (int32_t)item;
 }

@@ -1,253 +1,326 @@
 // twx_uk.h -- universal-kriging kernel.
 //
-// One 256-thread workgroup per cell, twelve months in sequence.  For month m with
-// k = nnghs_m neighbours (the k nearest, in rank order) the bordered matrix
+// One 256-thread workgroup per (cell, month) item; items are bucketed by their own
+// neighbourhood size k so that every launch runs a kernel specialised (template NB)
+// for NP = 16*NB >= k + 7 rows.  The bordered matrix
 //
 //        M = [ C   B ]      C = k x k covariance, B = [1 x1 x2 x3 x4 | y | c0]
 //            [ B'  0 ]
 //
 // is held ENTIRELY IN REGISTERS, distributed 2-D block-cyclically over the 16x16
 // thread grid: thread (tr, tc) owns element (16a+tr, 16b+tc) of every 16x16 block
-// (a >= b).  k right-looking Cholesky steps eliminate the C part; what is left in
-// the trailing 7x7 block is -B'C^-1 B, i.e. every inner product the GLS predictor
-// needs (X'C^-1X, X'C^-1y, X'C^-1c0, c0'C^-1c0, c0'C^-1y) -- no triangular solves.
-// Each step broadcasts one scaled column through a double-buffered LDS vector
-// (one workgroup barrier per step); all register indexing is compile-time.
+// (a >= b).  Right-looking Cholesky eliminates the C part in PANELS of four
+// columns: the four columns of a panel live in exactly one wavefront (lanes =
+// 4 columns x 16 rows), which factorises them with lane shuffles only, publishes
+// the four scaled columns through a double-buffered LDS slab, and after ONE
+// workgroup barrier every thread applies the rank-4 update to its own elements
+// (all register indices compile-time).  What is left in the trailing 7x7 block is
+// -B'C^-1 B, i.e. every inner product the GLS predictor needs (X'C^-1X, X'C^-1y,
+// X'C^-1c0, c0'C^-1c0, c0'C^-1y) -- no triangular solves.  The seven RHS rows sit
+// at the fixed rows NP-7..NP-1 so the Schur complement lands in a fixed block.
 //
-// The pair distances h_ij (sp/gstat WGS84 great-circle, B.1) depend only on the
-// cell's neighbour list, not on the month, so every thread computes the h of its
-// own elements once per cell and keeps them in registers; a month only
-// re-evaluates psill*exp(-h/range).  The seven RHS rows sit at the fixed rows
-// NP-7..NP-1 of the padded matrix so the Schur complement lands in a fixed block.
+// Pair distances h_ij (sp/gstat WGS84 great-circle, B.1) come from per-station
+// half-angle sines/cosines staged in LDS: six angle-addition products in fp64
+// (they carry the cancellation), then an fp32 tail (asin series, flattening
+// correction) -- relative error ~3e-7 on h, far inside the 1e-4 degC parity bar.
 #pragma once
 #include "twx_select.h"
 
+#include <type_traits>
+
 __device__ __forceinline__ constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+// compile-time loop: the body gets the index as an integral_constant, so every
+// register-array subscript is a constant by construction (a "#pragma unroll" on the
+// outer block-column loop is refused by the optimizer for the larger NB)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
 
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
     // v_rsq_f64 seed + two Newton steps: full fp64 accuracy
     double y = __builtin_amdgcn_rsq(d);
     double h = 0.5 * d;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
     return y;
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, (NB >= 8 ? 2 : (NB >= 6 ? 3 : 4)))
-void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *cell_list, int ncells)
+__device__ __forceinline__ double readlane_d(double v, int lane /*wave-uniform*/)
 {
-    constexpr int NP = NB * 16, BR = NP - 7, NT = NB * (NB + 1) / 2;
-    __shared__ double s_col[2][NP];
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// exp(x) for x <= 0: fp64 range reduction, v_exp_f32 on the fraction (rel. err ~1e-7)
+__device__ __forceinline__ double exp_neg_fast(double x)
+{
+    double t = x * 1.4426950408889634;          // log2(e)
+    double n = rint(t);
+    float f = (float)(t - n);
+    float e = __builtin_amdgcn_exp2f(f);
+    int ni = (int)fmax(n, -1000.0);
+    return ldexp((double)e, ni);
+}
+
+// WGS84 great-circle distance of a station pair from half-angle sin/cos (km).
+// fp64 for the six products and S (cancellation), fp32 for the rest.
+__device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double sl1, double cl1,
+                                                 double sp2, double cp2, double sl2, double cl2)
+{
+    double sG = fma(sp1, cp2, -(cp1 * sp2)), cG = fma(cp1, cp2, sp1 * sp2);
+    double sF = fma(sp1, cp2, cp1 * sp2), cF = fma(cp1, cp2, -(sp1 * sp2));
+    double sL = fma(sl1, cl2, -(cl1 * sl2)), cL = fma(cl1, cl2, sl1 * sl2);
+    double sG2 = sG * sG, cG2 = cG * cG, sF2 = sF * sF, cF2 = cF * cF, sL2 = sL * sL, cL2 = cL * cL;
+    double Sd = fma(sG2, cL2, cF2 * sL2);
+    if (Sd > 0.01) { // > ~1300 km: accurate slow path
+        double Cd = fma(cG2, cL2, sF2 * sL2);
+        double w = atan(sqrt(Sd / Cd));
+        double R = sqrt(Sd * Cd) / w;
+        double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
+        return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
+    }
+    float S = (float)Sd;
+    if (!(S > 0.f)) return 0.f;
+    float C = 1.f - S;
+    float rs = __builtin_amdgcn_sqrtf(S);
+    // asin(x)/x as a series in x^2 = S
+    float P = fmaf(S, fmaf(S, fmaf(S, fmaf(S, fmaf(S, 0.022372159f, 0.030381944f), 0.044642857f), 0.075f), 0.16666667f), 1.0f);
+    float w = rs * P;                                   // half central angle
+    float R = __builtin_amdgcn_sqrtf(C) * __builtin_amdgcn_rcpf(P);
+    float H1 = (3.f * R - 1.f) * __builtin_amdgcn_rcpf(2.f * C);
+    float H2 = (3.f * R + 1.f) * __builtin_amdgcn_rcpf(2.f * S);
+    float corr = (float)TWX_WGS84_F * (H1 * (float)sF2 * (float)cG2 - H2 * (float)cF2 * (float)sG2);
+    return 2.f * (float)TWX_WGS84_A * w * (1.f + corr);
+}
+
+// waves per SIMD the register budget is sized for (min == max so that the compiler
+// does not spill the register-resident matrix to chase a higher occupancy)
+#define TWX_UK_WAVES(NB) ((NB) >= 8 ? 2 : ((NB) >= 7 ? 3 : 4))
+
+template <int NB>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
+void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
+{
+    constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
+    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * 4];          // four scaled columns of the current panel, [row][4]
     __shared__ double s_B[7][NP];
-    __shared__ double s_sph[NP], s_cph[NP], s_slh[NP], s_clh[NP];
-    __shared__ double s_h0[NP];
-    __shared__ double s_xs[3][NP];     // lon, lat, elev of the neighbours, minus the cell's
-    __shared__ int s_idx[NP];
+    __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
     __shared__ double s_red[4][4];
     __shared__ double s_S[49];
     __shared__ int s_err;
 
-    const int t = threadIdx.x, tr = t & 15, tc = t >> 4, lane = t & 63, wv = t >> 6;
-    if ((int)blockIdx.x >= ncells) return;
-    const int64_t lc = cell_list[blockIdx.x];
+    const int t = threadIdx.x, tr = t & 15, tc = t >> 4, lane = t & 63, wv = t >> 6, tcl = lane >> 4;
+    if ((int)blockIdx.x >= nitems) return;
+    const int item = item_list[blockIdx.x];
+    const int64_t lc = item / 12;
+    const int m0 = item % 12;
     const int64_t c = ws.cell0 + lc;
-    const int kmaxc = ws.kmaxc[lc];
-    const CellVals cv = cell_load(src, c);
+    const int k = ws.kk[lc * 12 + m0];
     const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    const double nug = ws.vario[(lc * 12 + m0) * 3 + 0];
+    const double psill = ws.vario[(lc * 12 + m0) * 3 + 1];
+    const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
+    const double c00 = nug + psill;
+    const double irng = rng == 0.0 ? 0.0 : -1.0 / rng;
+    const int nbk = (k + 15) >> 4;               // block rows holding C rows
 
-    // ---- per-cell staging: neighbour trig, coordinates, cell->station distance ----
-    for (int i = t; i < NP; i += 256) {
-        int j = (i < kmaxc) ? ws.near_idx[lc * ws.ksel + i] : -1;
-        s_idx[i] = j;
-        if (j >= 0) {
-            s_sph[i] = st.sph[j]; s_cph[i] = st.cph[j]; s_slh[i] = st.slh[j]; s_clh[i] = st.clh[j];
-            double lo = st.lon[j], la = st.lat[j];
-            s_xs[0][i] = lo - cv.lon; s_xs[1][i] = la - cv.lat; s_xs[2][i] = st.elev[j] - cv.elev;
-            s_h0[i] = ellip_km(cv.lon, cv.lat, lo, la);
-        } else {
-            s_sph[i] = 0; s_cph[i] = 1; s_slh[i] = 0; s_clh[i] = 1;
-            s_xs[0][i] = 0; s_xs[1][i] = 0; s_xs[2][i] = 0; s_h0[i] = 0;
+    // ---- staging: one neighbour per thread (NP <= 160 < 256) ------------------------------
+    double x0 = 0, x1 = 0, x2 = 0, x3 = 0, yv = 0, c0v = 0;
+    if (t < NP) {
+        double sp = 0, cp = 1, sl = 0, cl = 1;
+        if (t < k) {
+            const int j = ws.near_idx[lc * ws.ksel + t];
+            sp = st.sph[j]; cp = st.cph[j]; sl = st.slh[j]; cl = st.clh[j];
+            const double lo = st.lon[j], la = st.lat[j];
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
+            yv = st.norm[m0 * n + j];
+            // cell -> station: exact test for a coincident point (sp / gstat), else B.1
+            const double h0 = ellip_km(cv.lon, cv.lat, lo, la);
+            c0v = h0 == 0.0 ? c00 : (rng == 0.0 ? 0.0 : psill * exp(h0 * irng));
         }
+        s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
+    }
+    {
+        double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
+        if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
     }
     if (t == 0) s_err = 0;
     __syncthreads();
-
-    // ---- pair distances of this thread's elements (once per cell) -------------------
-    float H[NT];
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            const int i = 16 * a + tr, j = 16 * b + tc;
-            float h = 0.f;
-            if (i < kmaxc && j < kmaxc && i != j)
-                h = (float)ellip_pair(s_sph[i], s_cph[i], s_slh[i], s_clh[i], s_sph[j], s_cph[j], s_slh[j], s_clh[j]);
-            H[tri(a, b)] = h;
-        }
-    }
-
-    for (int m0 = 0; m0 < 12; ++m0) {
-        const int k = ws.kk[lc * 12 + m0];
-        if (k <= 0) continue;                       // uniform
-        const double nug = ws.vario[(lc * 12 + m0) * 3 + 0];
-        const double psill = ws.vario[(lc * 12 + m0) * 3 + 1];
-        const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
-        const double c00 = nug + psill;
-        const double irng = rng == 0.0 ? 0.0 : -1.0 / rng;
-        const double plst = cell_lst(src, c, m0);
-        const int nbk = (k + 15) >> 4;              // block rows holding C rows
-
-        // ---- RHS columns: trend (shifted to the cell, scaled), y, c0 ----------------
-        // NP <= 160 < 256: one neighbour per thread
-        double xl = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-        if (t < k) {
-            xl = st.lst[m0 * n + s_idx[t]] - plst;
-            e0 = fabs(s_xs[0][t]); e1 = fabs(s_xs[1][t]); e2 = fabs(s_xs[2][t]); e3 = fabs(xl);
-        }
-        e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
-        if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
-        __syncthreads();
+    if (t < NP) {
         double sc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double s = fmax(fmax(s_red[0][q], s_red[1][q]), fmax(s_red[2][q], s_red[3][q]));
             sc[q] = s > 0.0 ? 1.0 / s : 1.0;
         }
-        if (t < NP) {
-            bool in = t < k;
-            s_B[0][t] = in ? 1.0 : 0.0;
-            s_B[1][t] = in ? s_xs[0][t] * sc[0] : 0.0;
-            s_B[2][t] = in ? s_xs[1][t] * sc[1] : 0.0;
-            s_B[3][t] = in ? s_xs[2][t] * sc[2] : 0.0;
-            s_B[4][t] = in ? xl * sc[3] : 0.0;
-            s_B[5][t] = in ? st.norm[m0 * n + s_idx[t]] : 0.0;
-            double h0 = s_h0[t];
-            s_B[6][t] = in ? (h0 == 0.0 ? c00 : (rng == 0.0 ? 0.0 : psill * exp(h0 * irng))) : 0.0;
-        }
-        __syncthreads();
+        const bool in = t < k;
+        s_B[0][t] = in ? 1.0 : 0.0;
+        s_B[1][t] = x0 * sc[0]; s_B[2][t] = x1 * sc[1]; s_B[3][t] = x2 * sc[2]; s_B[4][t] = x3 * sc[3];
+        s_B[5][t] = yv; s_B[6][t] = c0v;
+    }
+    __syncthreads();
 
-        // ---- build this thread's elements -------------------------------------------
-        double A[NT];
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                const int i = 16 * a + tr, j = 16 * b + tc;
-                double v = 0.0;
-                if (i < k) {
-                    if (j < k) {
-                        float h = H[tri(a, b)];
-                        v = (i == j || h == 0.f) ? c00 : (rng == 0.0 ? 0.0 : psill * exp((double)h * irng));
+    // ---- build this thread's elements ---------------------------------------------------------
+    double A[NT];
+    sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        const int i = 16 * a + tr;
+        double spi = 0, cpi = 1, sli = 0, cli = 1;
+        if (a < nbk) { spi = s_trig[i * 4]; cpi = s_trig[i * 4 + 1]; sli = s_trig[i * 4 + 2]; cli = s_trig[i * 4 + 3]; }
+        sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            const int j = 16 * b + tc;
+            double v = 0.0;
+            if (a < nbk) {                                   // uniform
+                if (i < k && j < k) {
+                    if (i == j) v = c00;
+                    else {
+                        float h = ellip_pair_fast(spi, cpi, sli, cli, s_trig[j * 4], s_trig[j * 4 + 1],
+                                                  s_trig[j * 4 + 2], s_trig[j * 4 + 3]);
+                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * exp_neg_fast((double)h * irng));
                     }
-                } else if (a == NB - 1 && tr >= 9) {
-                    if (j < k) v = s_B[tr - 9][j];
                 }
-                A[tri(a, b)] = v;
             }
-        }
+            if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1
+            A[tri(a, b)] = v;
+        });
+    });
 
-        // ---- k elimination steps -------------------------------------------------------
-#pragma unroll
-        for (int bp = 0; bp < NB; ++bp) {
-            const int qn = min(16, k - 16 * bp);
-            if (qn > 0) {
-                for (int q = 0; q < qn; ++q) {
-                    const int p = 16 * bp + q;
-                    double *col = s_col[p & 1];
-                    if (wv == (q >> 2)) {           // the wave that owns column p
-                        double d = __shfl(A[tri(bp, bp)], ((q & 3) << 4) | q, 64);
-                        const bool bad = !(d > 0.0) || !finite_d(d);
-                        const double rinv = bad ? 0.0 : rsqrt_nr(d);
-                        if ((lane >> 4) == (q & 3)) {
-#pragma unroll
-                            for (int a = bp; a < NB; ++a) {
-                                if (a < nbk || a == NB - 1) {
-                                    double v = A[tri(a, bp)] * rinv;
-                                    if (a == bp && tr <= q) v = 0.0;
-                                    col[16 * a + tr] = v;
-                                }
+    // ---- elimination: panels of four columns ------------------------------------------------------
+    int pbuf = 0;
+    double lj0[NB], lj1[NB], lj2[NB], lj3[NB];
+    sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
+        constexpr int bp = decltype(bp_)::value;
+        const int ncb = k - 16 * bp;                         // C columns left in this block column
+        if (ncb > 0) {
+            const int npan = min(4, (ncb + 3) >> 2);
+            for (int s = 0; s < npan; ++s) {
+                const int ncol = min(4, ncb - 4 * s);        // real columns in this panel
+                double *pan = s_pan[pbuf];
+                if (wv == s) {                               // the wave holding the panel's columns
+                    sfor<0, 4>([&](auto cc_) __attribute__((always_inline)) {
+                        constexpr int cc = decltype(cc_)::value;
+                        if (cc < ncol) {                     // uniform
+                            const int q = 4 * s + cc;        // column within the block
+                            double d = readlane_d(A[tri(bp, bp)], 16 * cc + q);
+                            const bool bad = !(d > 0.0) || !finite_d(d);
+                            const double rinv = bad ? 0.0 : rsqrt_nr(d);
+                            if (bad && lane == 0) s_err = 1;
+                            // lanes of column cc: scale; rows at / above the diagonal -> 0
+                            if (tcl == cc) {
+                                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                                    constexpr int a = decltype(a_)::value;
+                                    A[tri(a, bp)] *= rinv;
+                                });
+                                if (tr <= q) A[tri(bp, bp)] = 0.0;
                             }
-                            if (bad && tr == 0) s_err = 1;
+                            // remaining panel columns: a(i, p') -= l(i, p) * l(p', p)
+                            if constexpr (cc < 3) {
+                                const double lpp = __shfl(A[tri(bp, bp)], 16 * cc + 4 * s + tcl, 64);
+                                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                                    constexpr int a = decltype(a_)::value;
+                                    const double li = __shfl(A[tri(a, bp)], 16 * cc + tr, 64);
+                                    A[tri(a, bp)] = fma(tcl > cc ? -li : 0.0, lpp, A[tri(a, bp)]);
+                                });
+                            }
+                        } else if (tcl == cc) {
+                            sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) { A[tri(decltype(a_)::value, bp)] = 0.0; });
                         }
-                    }
-                    __syncthreads();
-                    double li[NB], lj[NB];
-#pragma unroll
-                    for (int a = bp; a < NB; ++a) {
-                        if (a < nbk || a == NB - 1) { li[a] = col[16 * a + tr]; lj[a] = col[16 * a + tc]; }
-                        else { li[a] = 0.0; lj[a] = 0.0; }
-                    }
-#pragma unroll
-                    for (int a = bp; a < NB; ++a) {
-                        if (a < nbk || a == NB - 1) {
-#pragma unroll
-                            for (int b = bp; b <= a; ++b)
-                                A[tri(a, b)] = fma(-li[a], lj[b], A[tri(a, b)]);
-                        }
-                    }
+                    });
+                    sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                        constexpr int a = decltype(a_)::value;
+                        pan[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
+                    });
                 }
+                __syncthreads();
+                // rank-4 update of this thread's elements
+                sfor<bp, NB>([&](auto b_) __attribute__((always_inline)) {
+                    constexpr int b = decltype(b_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * 4]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * 4 + 2]);
+                    lj0[b] = u0.x; lj1[b] = u0.y; lj2[b] = u1.x; lj3[b] = u1.y;
+                });
+                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * 4]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * 4 + 2]);
+                    sfor<bp, a + 1>([&](auto b_) __attribute__((always_inline)) {
+                        constexpr int b = decltype(b_)::value;
+                        double acc = A[tri(a, b)];
+                        acc = fma(-u0.x, lj0[b], acc);
+                        acc = fma(-u0.y, lj1[b], acc);
+                        acc = fma(-u1.x, lj2[b], acc);
+                        acc = fma(-u1.y, lj3[b], acc);
+                        A[tri(a, b)] = acc;
+                    });
+                });
+                pbuf ^= 1;
             }
         }
+    });
 
-        // ---- Schur complement -> GLS predictor ----------------------------------------
-        if (tr >= 9 && tc >= 9) s_S[(tr - 9) * 7 + (tc - 9)] = -A[tri(NB - 1, NB - 1)];
-        __syncthreads();
-        if (t == 0) {
-            // N = X'C^-1X (5x5), r = X'C^-1y, q = X'C^-1c0, gg = c0'C^-1c0, gb = c0'C^-1y
-            double L[5][5], beta[5], u[5];
-            bool bad = s_err != 0;
+    // ---- Schur complement -> GLS predictor ----------------------------------------------------------
+    if (tr >= 9 && tc >= 9) s_S[(tr - 9) * 7 + (tc - 9)] = -A[tri(NB - 1, NB - 1)];
+    __syncthreads();
+    if (t == 0) {
+        // N = X'C^-1X (5x5), r = X'C^-1y, q = X'C^-1c0, gg = c0'C^-1c0, gb = c0'C^-1y
+        double L[5][5], beta[5], u[5];
+        bool bad = s_err != 0;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 5; ++i) {
 #pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    double s = s_S[i * 7 + j];
+            for (int j = 0; j <= i; ++j) {
+                double s = s_S[i * 7 + j];
 #pragma unroll
-                    for (int p = 0; p < j; ++p) s -= L[i][p] * L[j][p];
-                    if (i == j) { if (!(s > 0.0)) bad = true; L[i][i] = sqrt(s); }
-                    else L[i][j] = s / L[j][j];
-                }
+                for (int p = 0; p < j; ++p) s -= L[i][p] * L[j][p];
+                if (i == j) { if (!(s > 0.0)) bad = true; L[i][i] = sqrt(s); }
+                else L[i][j] = s / L[j][j];
             }
-            double mean = 0.0, var = 0.0;
-            {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {       // L z = r
-                    double s = s_S[i * 7 + 5];
-#pragma unroll
-                    for (int p = 0; p < i; ++p) s -= L[i][p] * beta[p];
-                    beta[i] = s / L[i][i];
-                }
-#pragma unroll
-                for (int i = 4; i >= 0; --i) {      // L' beta = z
-                    double s = beta[i];
-#pragma unroll
-                    for (int p = i + 1; p < 5; ++p) s -= L[p][i] * beta[p];
-                    beta[i] = s / L[i][i];
-                }
-                // x0 = [1, 0, 0, 0, 0] (trend columns are shifted to the cell)
-#pragma unroll
-                for (int i = 0; i < 5; ++i) u[i] = (i == 0 ? 1.0 : 0.0) - s_S[i * 7 + 6];
-                mean = s_S[6 * 7 + 5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) mean += u[i] * beta[i];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {       // L w = u
-                    double s = u[i];
-#pragma unroll
-                    for (int p = 0; p < i; ++p) s -= L[i][p] * u[p];
-                    u[i] = s / L[i][i];
-                }
-                var = c00 - s_S[48];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) var += u[i] * u[i];
-                if (!finite_d(mean) || !finite_d(var)) bad = true;
-            }
-            if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
-            ws.uk_mean[lc * 12 + m0] = mean;
-            ws.uk_var[lc * 12 + m0] = var;
-            s_err = 0;
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {       // L z = r
+            double s = s_S[i * 7 + 5];
+#pragma unroll
+            for (int p = 0; p < i; ++p) s -= L[i][p] * beta[p];
+            beta[i] = s / L[i][i];
+        }
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {      // L' beta = z
+            double s = beta[i];
+#pragma unroll
+            for (int p = i + 1; p < 5; ++p) s -= L[p][i] * beta[p];
+            beta[i] = s / L[i][i];
+        }
+        // x0 = [1, 0, 0, 0, 0] (trend columns are shifted to the cell)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) u[i] = (i == 0 ? 1.0 : 0.0) - s_S[i * 7 + 6];
+        double mean = s_S[6 * 7 + 5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) mean += u[i] * beta[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {       // L w = u
+            double s = u[i];
+#pragma unroll
+            for (int p = 0; p < i; ++p) s -= L[i][p] * u[p];
+            u[i] = s / L[i][i];
+        }
+        double var = c00 - s_S[48];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) var += u[i] * u[i];
+        if (!finite_d(mean) || !finite_d(var)) bad = true;
+        if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
+        ws.uk_mean[lc * 12 + m0] = mean;
+        ws.uk_var[lc * 12 + m0] = var;
     }
 }
