@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,14 +46,14 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig;
     int cmax = 512;
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig})
             b->release();
     }
 };
@@ -146,6 +147,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
+    HIPCHK(w.ctrig.ensure((size_t)ncell * 32));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
@@ -163,6 +165,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.vario = w.vario.as<double>(); s.cstat = w.cstat.as<int32_t>(); s.kmaxc = w.kmaxc.as<int32_t>();
     s.bucket_cells = w.bucket_cells.as<int32_t>();
     s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
+    s.ctrig = w.ctrig.as<double>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     return 0;
 }
@@ -170,7 +173,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
 template <int NB>
 void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt);
+    static const int ablate = getenv("TWX_UK_ABLATE") ? atoi(getenv("TWX_UK_ABLATE")) : 0;  // timing experiments only
+    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt, ablate);
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)

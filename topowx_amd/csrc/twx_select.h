@@ -36,6 +36,7 @@ struct SelWs {
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
+    double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
 };
 
 // ---------------------------------------------------------------------------------
@@ -317,6 +318,11 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
         ws.cstat[lc] = status;
         ws.nnear[lc] = nnear;
         ws.uk_stat[lc] = TWX_CELL_OK;
+        {
+            const double r = 3.14159265358979323846 / 180.0;
+            ws.ctrig[lc * 4 + 0] = sin(cv.lat * r / 2.0); ws.ctrig[lc * 4 + 1] = cos(cv.lat * r / 2.0);
+            ws.ctrig[lc * 4 + 2] = sin(cv.lon * r / 2.0); ws.ctrig[lc * 4 + 3] = cos(cv.lon * r / 2.0);
+        }
         ws.kmaxc[lc] = status ? 0 : kkmax;
     }
 }

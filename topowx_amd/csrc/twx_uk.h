@@ -59,46 +59,52 @@ __device__ __forceinline__ double readlane_d(double v, int lane /*wave-uniform*/
     return __hiloint2double(hi, lo);
 }
 
-// exp(x) for x <= 0: fp64 range reduction, v_exp_f32 on the fraction (rel. err ~1e-7)
-__device__ __forceinline__ double exp_neg_fast(double x)
+// psill * exp(-h / range) with the exponent carried as an fp32 hi/lo pair:
+// t = h * (chi + clo) = -h / range * log2(e); 2^t = 2^n * 2^f.  Relative error ~1e-7.
+__device__ __forceinline__ float exp2_neg_split(float h, float chi, float clo)
 {
-    double t = x * 1.4426950408889634;          // log2(e)
-    double n = rint(t);
-    float f = (float)(t - n);
+    float thi = h * chi;
+    float e1 = fmaf(h, chi, -thi);
+    float tlo = fmaf(h, clo, e1);
+    float n = rintf(thi);
+    float f = (thi - n) + tlo;
     float e = __builtin_amdgcn_exp2f(f);
-    int ni = (int)fmax(n, -1000.0);
-    return ldexp((double)e, ni);
+    return ldexpf(e, (int)fmaxf(n, -160.f));
 }
 
-// WGS84 great-circle distance of a station pair from half-angle sin/cos (km).
-// fp64 for the six products and S (cancellation), fp32 for the rest.
-__device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double sl1, double cl1,
-                                                 double sp2, double cp2, double sl2, double cl2)
+// WGS84 great-circle distance (sp / gstat) of two points from the
+// sines / cosines of their half latitudes and half longitudes plus cos(lat).
+// With F = (p1+p2)/2, G = (p1-p2)/2, L = (l1-l2)/2:
+//   S = sin^2 G cos^2 L + cos^2 F sin^2 L = sin^2 G + cos p1 cos p2 sin^2 L
+//   cos^2 F = cos p1 cos p2 + sin^2 G
+// so only sin G and sin L (the differences that cancel) need fp64; the asin
+// series and the flattening correction run in fp32 (relative error ~3e-7 on h).
+__device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double sl1, double cl1, double cph1,
+                                                 double sp2, double cp2, double sl2, double cl2, double cph2)
 {
-    double sG = fma(sp1, cp2, -(cp1 * sp2)), cG = fma(cp1, cp2, sp1 * sp2);
-    double sF = fma(sp1, cp2, cp1 * sp2), cF = fma(cp1, cp2, -(sp1 * sp2));
-    double sL = fma(sl1, cl2, -(cl1 * sl2)), cL = fma(cl1, cl2, sl1 * sl2);
-    double sG2 = sG * sG, cG2 = cG * cG, sF2 = sF * sF, cF2 = cF * cF, sL2 = sL * sL, cL2 = cL * cL;
-    double Sd = fma(sG2, cL2, cF2 * sL2);
+    const double sG = fma(sp1, cp2, -(cp1 * sp2));
+    const double sL = fma(sl1, cl2, -(cl1 * sl2));
+    const double cc = cph1 * cph2;
+    const double sG2 = sG * sG, sL2 = sL * sL;
+    const double Sd = fma(cc, sL2, sG2);
     if (Sd > 0.01) { // > ~1300 km: accurate slow path
-        double Cd = fma(cG2, cL2, sF2 * sL2);
+        const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
         double w = atan(sqrt(Sd / Cd));
         double R = sqrt(Sd * Cd) / w;
         double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
         return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
     }
-    float S = (float)Sd;
+    const float S = (float)Sd, g2 = (float)sG2, ccf = (float)cc;
     if (!(S > 0.f)) return 0.f;
-    float C = 1.f - S;
-    float rs = __builtin_amdgcn_sqrtf(S);
+    const float cF2 = ccf + g2, sF2 = 1.f - cF2, cG2 = 1.f - g2, C = 1.f - S;
+    const float rs = __builtin_amdgcn_sqrtf(S);
     // asin(x)/x as a series in x^2 = S
-    float P = fmaf(S, fmaf(S, fmaf(S, fmaf(S, fmaf(S, 0.022372159f, 0.030381944f), 0.044642857f), 0.075f), 0.16666667f), 1.0f);
-    float w = rs * P;                                   // half central angle
-    float R = __builtin_amdgcn_sqrtf(C) * __builtin_amdgcn_rcpf(P);
-    float H1 = (3.f * R - 1.f) * __builtin_amdgcn_rcpf(2.f * C);
-    float H2 = (3.f * R + 1.f) * __builtin_amdgcn_rcpf(2.f * S);
-    float corr = (float)TWX_WGS84_F * (H1 * (float)sF2 * (float)cG2 - H2 * (float)cF2 * (float)sG2);
-    return 2.f * (float)TWX_WGS84_A * w * (1.f + corr);
+    const float P = fmaf(S, fmaf(S, fmaf(S, fmaf(S, fmaf(S, 0.022372159f, 0.030381944f), 0.044642857f), 0.075f), 0.16666667f), 1.0f);
+    const float R3 = 3.f * __builtin_amdgcn_sqrtf(C) * __builtin_amdgcn_rcpf(P);
+    const float H1 = (R3 - 1.f) * __builtin_amdgcn_rcpf(2.f * C);
+    const float H2 = (R3 + 1.f) * __builtin_amdgcn_rcpf(2.f * S);
+    const float corr = (float)TWX_WGS84_F * (H1 * sF2 * cG2 - H2 * cF2 * g2);
+    return (2.f * (float)TWX_WGS84_A) * (rs * P) * (1.f + corr);
 }
 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
@@ -108,12 +114,13 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
 template <int NB>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
-void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
+void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems, int ablate)
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
     __shared__ __attribute__((aligned(16))) double s_pan[2][NP * 4];          // four scaled columns of the current panel, [row][4]
     __shared__ double s_B[7][NP];
     __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
+    __shared__ double s_cphi[NP];                // cos(lat) per neighbour
     __shared__ double s_red[4][4];
     __shared__ double s_S[49];
     __shared__ int s_err;
@@ -132,7 +139,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     const double psill = ws.vario[(lc * 12 + m0) * 3 + 1];
     const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
     const double c00 = nug + psill;
-    const double irng = rng == 0.0 ? 0.0 : -1.0 / rng;
+    const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
+    const float chi = (float)c2, clo = (float)(c2 - (double)chi);
     const int nbk = (k + 15) >> 4;               // block rows holding C rows
 
     // ---- staging: one neighbour per thread (NP <= 160 < 256) ------------------------------
@@ -145,11 +153,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
             const double lo = st.lon[j], la = st.lat[j];
             x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
             yv = st.norm[m0 * n + j];
-            // cell -> station: exact test for a coincident point (sp / gstat), else B.1
-            const double h0 = ellip_km(cv.lon, cv.lat, lo, la);
-            c0v = h0 == 0.0 ? c00 : (rng == 0.0 ? 0.0 : psill * exp(h0 * irng));
+            // cell -> station (B.1); a coincident point gets the full sill (exact interpolator)
+            const double *ct = ws.ctrig + lc * 4;
+            const float h0 = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0])),
+                                             sp, cp, sl, cl, fma(cp, cp, -(sp * sp)));
+            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+            c0v = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
         }
         s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
+        s_cphi[t] = fma(cp, cp, -(sp * sp));
     }
     {
         double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
@@ -176,8 +188,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
-        double spi = 0, cpi = 1, sli = 0, cli = 1;
-        if (a < nbk) { spi = s_trig[i * 4]; cpi = s_trig[i * 4 + 1]; sli = s_trig[i * 4 + 2]; cli = s_trig[i * 4 + 3]; }
+        double spi = 0, cpi = 1, sli = 0, cli = 1, cphi = 1;
+        if (a < nbk) { spi = s_trig[i * 4]; cpi = s_trig[i * 4 + 1]; sli = s_trig[i * 4 + 2]; cli = s_trig[i * 4 + 3]; cphi = s_cphi[i]; }
         sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 16 * b + tc;
@@ -186,9 +198,10 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 if (i < k && j < k) {
                     if (i == j) v = c00;
                     else {
-                        float h = ellip_pair_fast(spi, cpi, sli, cli, s_trig[j * 4], s_trig[j * 4 + 1],
-                                                  s_trig[j * 4 + 2], s_trig[j * 4 + 3]);
-                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * exp_neg_fast((double)h * irng));
+                        if (ablate & 2) { v = 0.001 * (double)((i * 7 + j) & 15); } else {
+                        const float h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1],
+                                                        s_trig[j * 4 + 2], s_trig[j * 4 + 3], s_cphi[j]);
+                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h, chi, clo)); }
                     }
                 }
             }
@@ -202,7 +215,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     double lj0[NB], lj1[NB], lj2[NB], lj3[NB];
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
-        const int ncb = k - 16 * bp;                         // C columns left in this block column
+        const int ncb = (ablate & 1) ? 0 : k - 16 * bp;      // C columns left (ablate: timing experiments only)
         if (ncb > 0) {
             const int npan = min(4, (ncb + 3) >> 2);
             for (int s = 0; s < npan; ++s) {
