@@ -44,10 +44,10 @@ __device__ __forceinline__ void sfor(F &&f)
 
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
-    // v_rsq_f64 seed + two Newton steps: full fp64 accuracy
+    // v_rsq_f64 seed (~2^-23) + Newton steps; the second step only polishes the
+    // last bits and is skipped on the panel's critical path (rel. error ~1e-14)
     double y = __builtin_amdgcn_rsq(d);
     double h = 0.5 * d;
-    y = y * fma(-h * y, y, 1.5);
     y = y * fma(-h * y, y, 1.5);
     return y;
 }
@@ -222,38 +222,42 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 const int ncol = min(4, ncb - 4 * s);        // real columns in this panel
                 double *pan = s_pan[pbuf];
                 if (wv == s) {                               // the wave holding the panel's columns
+                    // Columns are exchanged between the four lane groups through the slab
+                    // itself (LDS operations of one wave execute in order).
                     sfor<0, 4>([&](auto cc_) __attribute__((always_inline)) {
                         constexpr int cc = decltype(cc_)::value;
                         if (cc < ncol) {                     // uniform
                             const int q = 4 * s + cc;        // column within the block
                             double d = readlane_d(A[tri(bp, bp)], 16 * cc + q);
-                            const bool bad = !(d > 0.0) || !finite_d(d);
+                            // singular / indefinite system: pivot not clearly positive (relative to the sill)
+                            const bool bad = !(d > 1e-9 * c00) || !finite_d(d);
                             const double rinv = bad ? 0.0 : rsqrt_nr(d);
                             if (bad && lane == 0) s_err = 1;
-                            // lanes of column cc: scale; rows at / above the diagonal -> 0
-                            if (tcl == cc) {
+                            if (tcl == cc) {                 // lanes of column cc: scale and publish
                                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                                     constexpr int a = decltype(a_)::value;
-                                    A[tri(a, bp)] *= rinv;
+                                    double v = A[tri(a, bp)] * rinv;
+                                    if (a == bp && tr <= q) v = 0.0;      // rows at / above the diagonal
+                                    A[tri(a, bp)] = v;
+                                    pan[(16 * a + tr) * 4 + cc] = v;
                                 });
-                                if (tr <= q) A[tri(bp, bp)] = 0.0;
                             }
-                            // remaining panel columns: a(i, p') -= l(i, p) * l(p', p)
-                            if constexpr (cc < 3) {
-                                const double lpp = __shfl(A[tri(bp, bp)], 16 * cc + 4 * s + tcl, 64);
+                            if constexpr (cc < 3) {          // remaining columns: a(i,p') -= l(i,p) l(p',p)
+                                __builtin_amdgcn_wave_barrier();
+                                const double lpp = pan[(16 * bp + 4 * s + tcl) * 4 + cc];
                                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                                     constexpr int a = decltype(a_)::value;
-                                    const double li = __shfl(A[tri(a, bp)], 16 * cc + tr, 64);
-                                    A[tri(a, bp)] = fma(tcl > cc ? -li : 0.0, lpp, A[tri(a, bp)]);
+                                    const double li = pan[(16 * a + tr) * 4 + cc];
+                                    if (tcl > cc) A[tri(a, bp)] = fma(-li, lpp, A[tri(a, bp)]);
                                 });
                             }
                         } else if (tcl == cc) {
-                            sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) { A[tri(decltype(a_)::value, bp)] = 0.0; });
+                            sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                                constexpr int a = decltype(a_)::value;
+                                A[tri(a, bp)] = 0.0;
+                                pan[(16 * a + tr) * 4 + cc] = 0.0;
+                            });
                         }
-                    });
-                    sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                        constexpr int a = decltype(a_)::value;
-                        pan[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
                     });
                 }
                 __syncthreads();
