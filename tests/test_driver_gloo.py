@@ -1,0 +1,104 @@
+"""Multi-process tile partition + mosaic gather on CPU (gloo, world_size 2).
+
+The per-tile compute is the CPU oracle here (tests may use it as the checker); on
+the GPU box the same driver code runs with the HIP compute (topowx_amd.driver.gpu_compute)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_compute():
+    from oracle import pyoracle as orc
+    from topowx_amd import synth
+    grid = synth.make_grid("C1", nrows=24, ncols=36)
+    grid["mask"][:12, 12:24] = 0            # one empty tile: numbering must skip it
+    grid["mask"][14:20, 2:7] = 0
+    tmin = synth.make_stations(grid["bbox"], 220, 3, "tmin")
+    db = orc.Db(tmin)
+    prm = orc.params()
+
+    def compute(g, rows, cols):
+        return orc.interp_grid(db, None, prm, g, nthreads=1, rows=rows, cols=cols)
+    return grid, compute
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from topowx_amd import driver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid, compute = _oracle_compute()
+    tiles = driver.tile_list(grid["mask"], 12, 12)
+    assignment = driver.assign_tiles(tiles, world)
+    mine = driver.interp_tiles(grid, compute, assignment[rank], 12, 12)
+    mosaic = driver.gather_mosaic(mine, assignment, grid["mask"].shape, 12, 12, ("norm_tmin", "se_tmin"), rank, world)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "mosaic.npz"), **mosaic)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_partition_is_balanced_and_complete():
+    from topowx_amd import driver
+    rng = np.random.default_rng(0)
+    mask = rng.random((100, 150)) < 0.6
+    mask[:25, :50] = False
+    tiles = driver.tile_list(mask, 25, 50)
+    assert [t[0] for t in tiles] == list(range(len(tiles))) and len(tiles) == 11
+    for world in (1, 2, 4, 8):
+        a = driver.assign_tiles(tiles, world)
+        got = sorted(t for part in a for t in part)
+        assert got == sorted(tiles)
+        loads = [sum(t[3] for t in part) for part in a]
+        assert max(loads) - min(loads) <= max(t[3] for t in tiles)
+    assert driver.assign_tiles(tiles, 2) == driver.assign_tiles(tiles, 2)     # deterministic
+
+
+def test_two_rank_mosaic_equals_single_process(tmp_path):
+    from topowx_amd import driver
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "mosaic.npz"))
+    grid, compute = _oracle_compute()
+    want = compute(grid, slice(0, 24), slice(0, 36))
+    m = grid["mask"] != 0
+    assert m.sum() > 0 and (~m).sum() > 0
+    for key in ("norm_tmin", "se_tmin"):
+        assert np.array_equal(got[key][:, m], want[key][:, m])
+        assert np.all(got[key][:, ~m] == driver.FILL_F4)
+
+
+def test_tiler_work_chunk_layout():
+    """Plane order of the reference's wrk_chk (tiling.py:205-213, step25:136-144)."""
+    from topowx_amd import synth
+    from topowx_amd.interp import Tiler
+    grid = synth.make_grid("C1", nrows=20, ncols=30)
+    grid["mask"][:10, :10] = 0
+    t = Tiler(grid, 10, 10, 5, 5)
+    info = t.build_tile_grid_info()
+    assert info.ntiles == 5 and info.chks_per_tile == 4 and t.ntile_chks == 20
+    k, w = next(t)
+    assert k == 0 and w.shape == (32, 5, 5)
+    i, j = t.tile_rc[t.tile_ids[0]]
+    assert (i, j) == (0, 10)
+    assert w[0, 3, 0] == 3 and w[1, 0, 4] == 4 and np.all(w[2] == 1)
+    assert w[3, 0, 0] == grid["lat"][0] and w[3, -1, 0] == grid["lat"][4] and w[4, 0, -1] == grid["lon"][14]
+    assert np.array_equal(w[5], grid["elev"][0:5, 10:15].astype(np.float64))
+    assert np.array_equal(w[8 + 6], grid["lst_night"][6, 0:5, 10:15]) and np.array_equal(w[20 + 11], grid["lst_day"][11, 0:5, 10:15])
+    assert len(list(t)) == 19

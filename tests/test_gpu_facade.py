@@ -1,0 +1,99 @@
+"""GPU: the twx.interp facade classes against goldens of the reference's classes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case(golden_case):
+    return golden_case
+
+
+def _fill(pt, grid, r, c):
+    from topowx_amd import stationdb as sdb
+    pt[sdb.LAT], pt[sdb.LON] = grid["lat"][r], grid["lon"][c]
+    pt[sdb.ELEV], pt[sdb.TDI], pt[sdb.CLIMDIV] = grid["elev"][r, c], grid["tdi"][r, c], grid["climdiv"][r, c]
+    for m in range(1, 13):
+        pt["tmin%02d" % m] = grid["lst_night"][m - 1, r, c]
+        pt["tmax%02d" % m] = grid["lst_day"][m - 1, r, c]
+
+
+def test_station_select_krig_gwr_interp_classes(case, golden):
+    from topowx_amd import stationdb as sdb
+    from topowx_amd.interp import GwrTairAnom, InterpTair, KrigTair, StationSelect, build_empty_pt
+    grid, tmin, _ = case
+    good = np.isnan(tmin.stns[sdb.BAD])
+    slct = StationSelect(tmin, good)
+    ids = tmin.stns[sdb.STN_ID][good]
+    # StationSelect.set_ngh_stns
+    i = 0
+    slct.set_ngh_stns(golden["sel_lat"][i], golden["sel_lon"][i], int(golden["sel_k"][i]), load_obs=True, obs_mth=3)
+    k = int(golden["sel_k"][i])
+    assert np.array_equal(slct.ngh_stns[sdb.STN_ID], ids[golden["sel_idx"][i][:k]])
+    np.testing.assert_allclose(slct.ngh_wgt, golden["sel_wgt"][i][:k], rtol=1e-10)
+    assert slct.ngh_obs.shape == (tmin.mth_idx[3].size, k)
+    # KrigTair.krig / GwrTairAnom.gwr_mth / InterpTair.interp on the golden cells
+    krig, gwr = KrigTair(slct), GwrTairAnom(slct)
+    pt = build_empty_pt()
+    r, c = golden["it_cell"][0]
+    _fill(pt, grid, r, c)
+    for m in range(1, 13):
+        pt[sdb.get_lst_varname(m)] = pt["tmin%02d" % m]
+    j = np.nonzero((golden["kr_cell"] == golden["it_cell"][0]).all(axis=1))[0]
+    for q in j:
+        mean, var = krig.krig(pt, int(golden["kr_mth"][q]))
+        assert abs(mean - golden["kr_mean"][q]) < 1e-4 and abs(var - golden["kr_var"][q]) < 1e-4
+        se, ci = krig.std_err_ci(mean, var)
+        assert abs(se - np.sqrt(golden["kr_var"][q])) < 1e-4 and ci[0] < mean < ci[1]
+    daily, norms, se = InterpTair(krig, gwr).interp(pt)
+    assert np.abs(daily - golden["it_daily"][0]).max() < 1e-4 and np.abs(norms - golden["it_norms"][0]).max() < 1e-4
+    assert pt[sdb.get_norm_varname(7)] == norms[6]
+    d7 = gwr.gwr_mth(pt, 7)
+    assert np.abs(d7 - golden["it_daily"][0][tmin.mth_idx[7]]).max() < 1e-4
+    with pytest.raises(IndexError):           # stn_dists[nnghs] past the end (station_select.py:164)
+        slct.set_ngh_stns(golden["sel_lat"][0], golden["sel_lon"][0], int(good.sum()))
+
+
+def test_pt_interp_tair_interp_pt_and_chunk(case, golden):
+    import make_golden
+    from topowx_amd.interp import PtInterpTair, Tiler
+    from oracle import pyoracle as orc
+    grid, tmin, tmax = case
+    p = PtInterpTair(tmin, make_golden.lowered_tmax(tmax))
+    for i, (r, c) in enumerate(golden["lo_cell"]):
+        _fill(p.a_pt, grid, r, c)
+        tmin_d, tmax_d, nmin, nmax, smin, smax, ninv = p.interp_pt()
+        assert ninv == golden["lo_ninv"][i] and ninv > 0
+        assert np.abs(tmin_d - golden["lo_tmin"][i]).max() < 1e-4 and np.abs(tmax_d - golden["lo_tmax"][i]).max() < 1e-4
+        assert np.abs(nmin - golden["lo_nmin"][i]).max() < 1e-4 and np.abs(smax - golden["lo_smax"][i]).max() < 1e-4
+    # the batched work-chunk entry returns what the worker writes (step25:163-172)
+    r, c = golden["lo_cell"][0]
+    t = Tiler(grid, 100, 100, 5, 5)
+    for k, w in t:
+        if w[0, 0, 0] <= r < w[0, 0, 0] + 5 and w[1, 0, 0] <= c < w[1, 0, 0] + 5:
+            break
+    out = p.interp_chunk(w)
+    rr, cc = int(r - w[0, 0, 0]), int(c - w[1, 0, 0])
+    assert out["status"][rr, cc] == 0 and out["ninvalid"][rr, cc] == golden["lo_ninv"][0]
+    dd = np.abs(out["daily_tmin"][:, rr, cc].astype(int) - orc.pack_i16(golden["lo_tmin"][0]).astype(int))
+    assert dd.max() <= 1
+    p.close()
+
+
+def test_xval_callers(case, golden):
+    from topowx_amd import stationdb as sdb
+    from topowx_amd.interp import XvalTairAnom, XvalTairOverall
+    grid, tmin, _ = case
+    good_ids = tmin.stns[sdb.STN_ID][np.isnan(tmin.stns[sdb.BAD])]
+    xo = XvalTairOverall(tmin, "tmin")
+    ids = [good_ids[j] for j in golden["xv_idx"]]
+    d, n, s = xo.run_interp_many(ids)
+    assert np.abs(d - golden["xv_daily"]).max() < 1e-4 and np.abs(n - golden["xv_norms"]).max() < 1e-4
+    d1, n1, s1 = xo.run_interp(ids[0])
+    assert np.array_equal(d1, d[0])
+    xo.close()
+    xa = XvalTairAnom(tmin, "tmin")
+    bias, mae, r2 = xa.run_xval(ids[0], np.array([35, 57, 101]))
+    assert bias.shape == (3, 12) and np.all(mae > 0) and np.all((r2 >= 0) & (r2 <= 1))
+    xa.close()

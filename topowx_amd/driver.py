@@ -1,0 +1,134 @@
+"""Python-3 counterpart of ``scripts/step25_mpi_interp_tair.py`` for one node of GPUs.
+
+The reference farms 50x50 work chunks of 250x250 tiles over MPI workers that each
+loop over cells in Python and write their own netCDF chunk (step25:49-314).  Here
+one process drives one GPU (``torch.distributed``, backend nccl = RCCL on ROCm,
+gloo in the CPU tests): tiles are dealt to ranks balanced by their number of
+unmasked cells, every rank holds the full station table (a few MB; the obs matrix
+~1 GB per variable) and interpolates whole tiles with one library call each.
+Cells are independent, so the data path needs NO collective; the optional
+``gather_mosaic`` assembles the f4 normals / SE mosaics on rank 0 over xGMI
+(SURVEY.md section 8e).  netCDF output is out of scope (8f-2): results are
+returned as arrays / written as ``.npz``.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+FILL_F4 = np.float32(9.969209968386869e36)
+
+
+def tile_list(mask, tile_y, tile_x):
+    """[(tile number, row0, col0, n valid cells)] for tiles holding >= 1 valid cell,
+    numbered like the reference (row-major over tiles, empty tiles skipped: tiling.py:131-165)."""
+    mask = np.asarray(mask) != 0
+    out, k = [], 0
+    for i in range(0, mask.shape[0], tile_y):
+        for j in range(0, mask.shape[1], tile_x):
+            n = int(mask[i:i + tile_y, j:j + tile_x].sum())
+            if n > 0:
+                out.append((k, i, j, n))
+                k += 1
+    return out
+
+
+def assign_tiles(tiles, world):
+    """Deterministic longest-processing-time deal: heaviest tile to the least loaded rank."""
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for t in sorted(tiles, key=lambda t: (-t[3], t[0])):
+        r = min(range(world), key=lambda q: (load[q], q))
+        mine[r].append(t)
+        load[r] += t[3]
+    for m in mine:
+        m.sort(key=lambda t: t[0])
+    return mine
+
+
+def interp_tiles(grid, compute, tiles, tile_y, tile_x):
+    """Run ``compute(grid, rows, cols) -> dict of arrays`` on every tile of this rank."""
+    return {k: compute(grid, slice(i, i + tile_y), slice(j, j + tile_x)) for k, i, j, _ in tiles}
+
+
+def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, device="cpu"):
+    """Assemble [12, Y, X] f4 mosaics of ``keys`` on rank 0.
+
+    One equal-size (padded) tensor per rank through ``dist.gather``; over RCCL every
+    peer has a direct xGMI link to the root, so this is world-1 concurrent
+    point-to-point transfers.
+    """
+    import torch
+    import torch.distributed as dist
+    nmax = max(len(a) for a in assignment)
+    buf = np.full((nmax, len(keys), 12, tile_y, tile_x), FILL_F4, np.float32)
+    for s, (k, _, _, _) in enumerate(assignment[rank]):
+        for q, key in enumerate(keys):
+            buf[s, q] = local[k][key]
+    t = torch.from_numpy(buf).to(device)
+    if world > 1:
+        parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, parts, dst=0)
+    else:
+        parts = [t]
+    if rank != 0:
+        return None
+    mosaic = {key: np.full((12,) + tuple(shape), FILL_F4, np.float32) for key in keys}
+    for r in range(world):
+        arr = parts[r].cpu().numpy()
+        for s, (k, i, j, _) in enumerate(assignment[r]):
+            for q, key in enumerate(keys):
+                mosaic[key][:, i:i + tile_y, j:j + tile_x] = arr[s, q]
+    return mosaic
+
+
+def gpu_compute(ctx, variables=("tmin", "tmax"), daily=False):
+    """compute() backed by libtwxhip (the product path)."""
+    def compute(grid, rows, cols):
+        return ctx.interp_grid(grid, variables=variables, daily=daily, rows=rows, cols=cols)
+    return compute
+
+
+def main():
+    ap = argparse.ArgumentParser(description="interpolate a synthetic grid on the GPUs of one node")
+    ap.add_argument("--config", default="C1")
+    ap.add_argument("--tile", type=int, default=50)
+    ap.add_argument("--daily", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="assemble the normals mosaic on rank 0 (RCCL gather)")
+    ap.add_argument("--out", default=None, help=".npz for rank 0's mosaic")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from . import _lib, synth
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    grid, tmin, tmax = synth.make_case(args.config, with_obs=args.daily)
+    ctx = _lib.Context(device=local)
+    ctx.set_stations(_lib.TMIN, tmin, with_obs=args.daily)
+    ctx.set_stations(_lib.TMAX, tmax, with_obs=args.daily)
+    tiles = tile_list(grid["mask"], args.tile, args.tile)
+    assignment = assign_tiles(tiles, world)
+    t0 = time.perf_counter()
+    mine = interp_tiles(grid, gpu_compute(ctx, daily=args.daily), assignment[rank], args.tile, args.tile)
+    dt = time.perf_counter() - t0
+    ncell = sum(t[3] for t in assignment[rank])
+    print(json.dumps({"rank": rank, "tiles": len(assignment[rank]), "cells": ncell, "seconds": dt}), flush=True)
+    if args.gather:
+        keys = ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")
+        mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, keys, rank, world,
+                               device="cuda:%d" % local)
+        if rank == 0 and args.out:
+            np.savez_compressed(args.out, **mosaic)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

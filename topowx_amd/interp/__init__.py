@@ -1,0 +1,14 @@
+"""Python-3 facade with the class / method names of ``twx.interp``.
+
+Every numerical result comes from libtwxhip (HIP kernels on MI355X) through
+``topowx_amd._lib``; there is no CPU implementation here.
+"""
+from .station_select import StationSelect  # noqa: F401
+from .interp_tair import (GwrTairAnom, InterpTair, KrigTair, PtInterpTair, StationDataWrkChk,  # noqa: F401
+                          build_empty_pt, tmin_tmax_fixer)
+from .optimize import XvalTairAnom, XvalTairOverall, build_nstn_bandwidths  # noqa: F401
+from .tiling import Tiler, TileGridInfo  # noqa: F401
+
+__all__ = ["StationSelect", "KrigTair", "GwrTairAnom", "InterpTair", "PtInterpTair", "StationDataWrkChk",
+           "build_empty_pt", "tmin_tmax_fixer", "XvalTairOverall", "XvalTairAnom", "build_nstn_bandwidths",
+           "Tiler", "TileGridInfo"]

@@ -1,0 +1,172 @@
+"""``twx.interp.interp_tair`` facade: KrigTair, GwrTairAnom, InterpTair, PtInterpTair.
+
+Call signatures, return values and error behaviour follow
+twx/interp/interp_tair.py of the reference; the arithmetic runs in libtwxhip.
+"""
+import numpy as np
+
+from .. import _lib
+from ..dates import MONTH, YEAR, get_mth_metadata
+from ..stationdb import (BAD, CLIMDIV, ELEV, LAT, LON, MASK, TDI, StationDataWrkChk, get_lst_varname,
+                         get_norm_varname, get_optim_anom_varname, get_optim_varname)
+from .station_select import StationSelect, raise_for_status
+
+__all__ = ["GwrTairAnom", "KrigTair", "InterpTair", "StationDataWrkChk", "PtInterpTair", "build_empty_pt",
+           "tmin_tmax_fixer"]
+
+DFLT_INIT_NNGHS = 100  # interp_tair.py:51
+
+
+def build_empty_pt():
+    """interp_tair.py:200-213: the structured scalar a point is described with."""
+    dt = [(LON, np.float64), (LAT, np.float64), (ELEV, np.float64), (TDI, np.float64), (CLIMDIV, np.float64),
+          (MASK, np.float64)]
+    dt.extend([("tmin%02d" % m, np.float64) for m in range(1, 13)])
+    dt.extend([("tmax%02d" % m, np.float64) for m in range(1, 13)])
+    dt.extend([(get_norm_varname(m), np.float64) for m in range(1, 13)])
+    dt.extend([(get_optim_varname(m), np.float64) for m in range(1, 13)])
+    dt.extend([(get_lst_varname(m), np.float64) for m in range(1, 13)])
+    dt.extend([(get_optim_anom_varname(m), np.float64) for m in range(1, 13)])
+    return np.zeros(1, dtype=dt)[0]
+
+
+def _pt_to_twx(ctx, pt):
+    return ctx.make_pts(pt[LON], pt[LAT], pt[ELEV], pt[TDI], [pt[get_lst_varname(m)] for m in range(1, 13)])
+
+
+def tmin_tmax_fixer(tmin, tmax, tail=15, ctx=None):
+    """interp_tair.py:143-197 on the GPU (twx_fix_pair).  Returns (tmin, tmax, ninvalid)."""
+    tmin = np.asarray(tmin, np.float64)
+    tmax = np.asarray(tmax, np.float64)
+    own = ctx is None or ctx.ndays != tmin.size
+    if own:
+        from ..dates import get_days_metadata
+        import datetime as dt
+        ctx = _lib.Context(fixer_tail=tail)
+        d0 = dt.date(2001, 1, 1)
+        ctx.set_days(get_days_metadata(d0, d0 + dt.timedelta(days=int(tmin.size) - 1)))
+    fa, fb, ninv, _, _, st = ctx.fix_pair(tmin, tmax)
+    if own:
+        ctx.close()
+    raise_for_status(st[0])
+    return fa[0], fb[0], int(ninv[0])
+
+
+class KrigTair(object):
+    """Moving-window regression kriging of monthly normals (interp_tair.py:771-926)."""
+
+    def __init__(self, stn_slct):
+        self.stn_slct = stn_slct
+        self.ci_critval = -1.959963984540054  # stats.norm.ppf(0.025), interp_tair.py:792
+
+    def std_err_ci(self, tair_mean, tair_var):
+        std_err = np.sqrt(tair_var) if tair_var >= 0 else 0
+        ci_r = np.abs(std_err * self.ci_critval)
+        return std_err, (tair_mean - ci_r, tair_mean + ci_r)
+
+    def krig(self, pt, mth, nnghs=None, vario_params=None, stns_rm=None):
+        s = self.stn_slct
+        mean, var, _, st, _ = s.ctx.krig_points(
+            s.var, _pt_to_twx(s.ctx, pt), int(mth), nnghs=None if nnghs is None else int(nnghs),
+            vario=None if vario_params is None else vario_params, excl=s.excl_index(stns_rm),
+            rm_zero_dist=s.rm_zero_dist_stns)
+        raise_for_status(st[0])
+        return mean[0], var[0]
+
+
+class GwrTairAnom(object):
+    """GWR of daily anomalies for one month (interp_tair.py:215-314)."""
+
+    def __init__(self, stn_slct):
+        self.stn_slct = stn_slct
+
+    def gwr_mth(self, pt, mth, nnghs=None, stns_rm=None):
+        s = self.stn_slct
+        out, _, st = s.ctx.gwr_points(s.var, _pt_to_twx(s.ctx, pt), pt[get_norm_varname(mth)], int(mth),
+                                      nnghs=None if nnghs is None else int(nnghs), excl=s.excl_index(stns_rm),
+                                      rm_zero_dist=s.rm_zero_dist_stns)
+        raise_for_status(st[0])
+        return out[0, :s.ctx.mth_days[mth - 1]]
+
+
+class InterpTair(object):
+    """Normals + daily values of one variable at a point (interp_tair.py:371-439)."""
+
+    def __init__(self, krig_tair, gwr_tair):
+        self.krig_tair = krig_tair
+        self.gwr_tair = gwr_tair
+        self.mth_masks = gwr_tair.stn_slct.stn_da.mth_idx
+        self.ndays = gwr_tair.stn_slct.stn_da.days.size
+
+    def interp(self, pt, stns_rm=None):
+        s = self.gwr_tair.stn_slct
+        daily, norms, se, st = s.ctx.interp_points(s.var, _pt_to_twx(s.ctx, pt), excl=s.excl_index(stns_rm),
+                                                   rm_zero_dist=s.rm_zero_dist_stns)
+        raise_for_status(st[0])
+        for m in range(1, 13):          # the reference stores the normals on the point (:433)
+            pt[get_norm_varname(m)] = norms[0, m - 1]
+        return daily[0], norms[0], se[0]
+
+
+class PtInterpTair(object):
+    """Tmin and Tmax at a point / over a work chunk (interp_tair.py:441-592).
+
+    ``interp_pt`` keeps the reference's one-point-per-call contract;
+    ``interp_chunk`` is the batched entry the GPU wants: it takes the reference's
+    f8[32, Y, X] work chunk (tiling.py:205-213) and returns the arrays the worker
+    writes (step25:163-172).
+    """
+
+    def __init__(self, stn_da_tmin, stn_da_tmax, aux_fpaths=None, interp_orders=None, norms_only=False,
+                 device=0):
+        if aux_fpaths is not None:
+            raise NotImplementedError("point-mode predictor sampling is out of scope (SURVEY.md 8f-4)")
+        self.days = stn_da_tmin.days
+        self.stn_da_tmin = stn_da_tmin
+        self.stn_da_tmax = stn_da_tmax
+        self.norms_only = norms_only
+        self.ctx = _lib.Context(device=device)
+        self.ctx.set_stations(_lib.TMIN, stn_da_tmin, with_obs=not norms_only)
+        self.ctx.set_stations(_lib.TMAX, stn_da_tmax, with_obs=not norms_only)
+        slct_n = StationSelect(stn_da_tmin, np.isnan(stn_da_tmin.stns[BAD]), ctx=self.ctx, var=_lib.TMIN)
+        slct_x = StationSelect(stn_da_tmax, np.isnan(stn_da_tmax.stns[BAD]), ctx=self.ctx, var=_lib.TMAX)
+        self.interp_tmin = InterpTair(KrigTair(slct_n), GwrTairAnom(slct_n))
+        self.interp_tmax = InterpTair(KrigTair(slct_x), GwrTairAnom(slct_x))
+        self.a_pt = build_empty_pt()
+
+    def interp_pt(self, fix_invalid=True, stns_rm=None):
+        pt = self.a_pt
+        out = []
+        for v, itp in (("tmin", self.interp_tmin), ("tmax", self.interp_tmax)):
+            for m in range(1, 13):          # interp_tair.py:560-563 / :569-572
+                pt[get_lst_varname(m)] = pt["%s%02d" % (v, m)]
+            s = itp.gwr_tair.stn_slct
+            daily, norms, se, st = self.ctx.interp_points(s.var, _pt_to_twx(self.ctx, pt), excl=s.excl_index(stns_rm),
+                                                          rm_zero_dist=s.rm_zero_dist_stns,
+                                                          daily=not self.norms_only)
+            raise_for_status(st[0])
+            out.append((daily[0] if daily is not None else None, norms[0], se[0]))
+        (tmin_dly, tmin_norms, tmin_se), (tmax_dly, tmax_norms, tmax_se) = out
+        ninvalid = 0
+        if fix_invalid and not self.norms_only:
+            fa, fb, ninv, nmin, nmax, st = self.ctx.fix_pair(tmin_dly, tmax_dly)
+            raise_for_status(st[0])
+            tmin_dly, tmax_dly, ninvalid = fa[0], fb[0], int(ninv[0])
+            if ninvalid > 0:                # normals recomputed from the fixed series (:583-590)
+                tmin_norms, tmax_norms = nmin[0], nmax[0]
+        return tmin_dly, tmax_dly, tmin_norms, tmax_norms, tmin_se, tmax_se, ninvalid
+
+    def interp_chunk(self, wrk_chk, daily=None):
+        """All unmasked cells of a reference work chunk in one GPU call.
+
+        ``wrk_chk`` planes: 0 row, 1 col, 2 mask, 3 lat, 4 lon, 5 elev, 6 tdi, 7 climdiv,
+        8-19 LST night (tmin01..12), 20-31 LST day (tmax01..12).
+        """
+        w = np.asarray(wrk_chk)
+        grid = dict(lat=w[3, :, 0], lon=w[4, 0, :], mask=(w[2] != 0) & np.isfinite(w[2]),
+                    elev=w[5], tdi=w[6], climdiv=np.nan_to_num(w[7]), lst_night=w[8:20], lst_day=w[20:32])
+        daily = (not self.norms_only) if daily is None else daily
+        return self.ctx.interp_grid(grid, daily=daily)
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,86 @@
+"""Cross-validation callers of the same kernels (twx/interp/optimize.py:376-604)."""
+import numpy as np
+
+from .. import _lib
+from ..stationdb import BAD, ELEV, LAT, LON, STN_ID, TDI, get_lst_varname, get_norm_varname
+from .station_select import raise_for_status
+
+__all__ = ["build_nstn_bandwidths", "XvalTairOverall", "XvalTairAnom"]
+
+
+def build_nstn_bandwidths(rng_min, rng_max, pct_step):
+    """optimize.py:376-405: ladder of station bandwidths (35..147 for 35, 150, 0.10)."""
+    out, n = [], rng_min
+    while n <= rng_max:
+        out.append(n)
+        n = n + np.round(pct_step * n)
+    return np.array(out, dtype=np.int64)
+
+
+class _XvalBase(object):
+    def __init__(self, stn_da, tair_var, device=0):
+        self.stn_da = stn_da
+        self.var = _lib.TMAX if tair_var == "tmax" else _lib.TMIN
+        self.ctx = _lib.Context(device=device)
+        self.ctx.set_stations(self.var, stn_da)
+        good = np.isnan(stn_da.stns[BAD])
+        self.stns = stn_da.stns[good]
+        self._obs_cols = np.nonzero(good)[0]
+        self.idx = {s: i for i, s in enumerate(self.stns[STN_ID])}
+        self.mth_masks = stn_da.mth_idx
+
+    def _pts(self, ids):
+        j = np.array([self.idx[s] for s in ids])
+        st = self.stns[j]
+        lst = np.column_stack([st[get_lst_varname(m)] for m in range(1, 13)])
+        return j, self.ctx.make_pts(st[LON], st[LAT], st[ELEV], st[TDI], lst)
+
+    def close(self):
+        self.ctx.close()
+
+
+class XvalTairOverall(_XvalBase):
+    """Leave-one-out interpolation of normals + daily values (optimize.py:548-604):
+    StationSelect(rm_zero_dist_stns=True) and stns_rm = the station's own id."""
+
+    def run_interp(self, stn_id):
+        d, n, s = self.run_interp_many([stn_id])
+        return d[0], n[0], s[0]
+
+    def run_interp_many(self, stn_ids, daily=True):
+        j, pts = self._pts(stn_ids)
+        d, norms, se, st = self.ctx.interp_points(self.var, pts, excl=j, rm_zero_dist=True, daily=daily)
+        for s in st:
+            raise_for_status(s)
+        return d, norms, se
+
+
+class XvalTairAnom(_XvalBase):
+    """Leave-one-out GWR anomalies over a ladder of bandwidths (optimize.py:476-545).
+    Returns bias, MAE and r^2, each [n_bandwidths, 12] as the reference does (:510-545)."""
+
+    def run_xval(self, stn_id, a_nnghs):
+        a_nnghs = np.asarray(a_nnghs, np.int32)
+        j, pt = self._pts([stn_id])
+        nb = a_nnghs.size
+        # one (bandwidth, month) pair per GPU point
+        pts = np.repeat(pt, nb * 12)
+        mth = np.tile(np.arange(1, 13, dtype=np.int32), nb)
+        nn = np.repeat(a_nnghs, 12)
+        norm = np.array([self.stns[j[0]][get_norm_varname(m)] for m in range(1, 13)])
+        out, _, st = self.ctx.gwr_points(self.var, pts, np.tile(norm, nb), mth, nnghs=nn, excl=np.full(nb * 12, j[0]),
+                                         rm_zero_dist=True)
+        for s in st:
+            raise_for_status(s)
+        obs = self.stn_da.load_obs(stn_id)
+        bias = np.zeros((nb, 12)); mae = np.zeros((nb, 12)); r2 = np.zeros((nb, 12))
+        for x in range(nb):
+            for m in range(1, 13):
+                rows = self.mth_masks[m]
+                xval_anom = obs[rows] - norm[m - 1]
+                interp_anom = out[x * 12 + m - 1, :rows.size] - norm[m - 1]
+                difs = interp_anom - xval_anom
+                bias[x, m - 1] = difs.mean()
+                mae[x, m - 1] = np.abs(difs).mean()
+                r2[x, m - 1] = np.corrcoef(interp_anom, xval_anom)[0, 1] ** 2
+        return bias, mae, r2
