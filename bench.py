@@ -120,14 +120,21 @@ def main():
     launches = max(1, int(kern[-1]["uk_launches"]))
     solves = int(kern[-1]["uk_solves"])
     ach_gbs = ALG_BYTES_PER_CELL_MONTH * solves / (uk_ms * 1e-3) / 1e9
-    # bandwidths actually used (sample of cells through the point entry) -> fp64 flop model
-    rs = np.random.default_rng(0)
-    rr, cc = rs.integers(0, Y, 400), rs.integers(0, X, 400)
-    pts = ctx.make_pts(grid["lon"][cc], grid["lat"][rr], grid["elev"][rr, cc], grid["tdi"][rr, cc],
-                       grid["lst_night"][:, rr, cc].T)
-    ks = np.concatenate([ctx.krig_points(_lib.TMIN, pts, m)[2] for m in range(1, 13)])
+    # bandwidths actually used by the timed steps (diagnostic accessor, no extra launches)
+    ks = ctx.last_bandwidths(_lib.TMIN).ravel()
     flops_per_solve = float(uk_flops(ks[ks > 0]).mean())
     ach_tflops = flops_per_solve * solves / (uk_ms * 1e-3) / 1e12
+
+    # HBM bytes per k_uk launch from the PMC passes of THIS workload (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs; summary committed under profiles/): PMC counters cannot be read
+    # from inside the process, so the committed measurement is quoted when the workload matches.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r1_bench_hbm_traffic.json")
+    if world == 1 and args.size == 250 and args.nstns == 10000 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj["FETCH_SIZE"]["k_uk_per_launch_bytes"] + tj["WRITE_SIZE"]["k_uk_per_launch_bytes"]
+        traffic_src = "profiles/r1_bench_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE, KB units x 1024, per launch; " \
+                      "8-byte gathers: the guide's x2 wide-read correction does not apply, width uncalibrated)"
 
     res = {
         "metric": "grid-cell-days interpolated/sec",
@@ -142,7 +149,9 @@ def main():
                    "cells_ok": ncell_ok, "mean_nnghs": float(ks[ks > 0].mean()),
                    "parallelism": "tiles partitioned over %d GPU(s), station table replicated" % world},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_MONTH * solves / launches,
                      "kernel": "k_uk<NB> (universal kriging, %d launches per step)" % launches,
                      "kernel_ms_per_step": uk_ms,
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},

@@ -194,6 +194,11 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *grid_dev, const twx_grid_o
 /* kernel times of the last grid call (synchronises on its events) */
 int twx_get_timing(twx_ctx *ctx, twx_timing *t);
 
+/* Diagnostic: the kriging bandwidths nnghs (KrigTair.__get_nnghs, interp_tair.py:821-835) of the
+ * LAST device batch of the last grid / point call of variable var, [cells][12] (0 = month not
+ * solved).  Copies min(capacity, cells*12) values; returns the number of cells in that batch or < 0. */
+int64_t twx_last_bandwidths(twx_ctx *ctx, int var, int32_t *nnghs, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,7 @@ class TwxTiming(C.Structure):
 
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
-           "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing")
+           "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths")
 
 _LIB = None
 
@@ -100,6 +100,7 @@ def load():
         L.twx_last_error.argtypes = [C.c_void_p]
         L.twx_destroy.argtypes = [C.c_void_p]
         L.twx_destroy.restype = None
+        L.twx_last_bandwidths.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -326,6 +327,14 @@ class Context(object):
         """Device-pointer entry (TwxGrid / TwxGridOut hold device addresses)."""
         self._chk(self.lib.twx_interp_grid_dev(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask),
                                                C.c_void_p(stream)), "twx_interp_grid_dev")
+
+    def last_bandwidths(self, var, max_cells=1 << 22):
+        """nnghs[cells, 12] of the last device batch (diagnostic)."""
+        buf = np.zeros((max_cells, 12), np.int32)
+        n = self.lib.twx_last_bandwidths(self.h, C.c_int(var), _p(buf, _ip), C.c_int64(buf.size))
+        if n < 0:
+            self._chk(-1, "twx_last_bandwidths")
+        return buf[:min(n, max_cells)]
 
     def timing(self):
         t = TwxTiming()

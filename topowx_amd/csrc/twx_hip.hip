@@ -824,4 +824,17 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
     return 0;
 }
 
+int64_t twx_last_bandwidths(twx_ctx *ctx, int var, int32_t *nnghs, int64_t capacity)
+{
+    if (!ctx) return -1;
+    if (var < 0 || var > 1 || !nnghs || capacity < 0) return fail(ctx, "twx_last_bandwidths: bad arguments");
+    const SelWs &ws = ctx->work[var].ws;
+    if (!ws.kk || ws.ncell <= 0) return fail(ctx, "twx_last_bandwidths: nothing computed yet");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, "hipSetDevice");
+    const int64_t n = std::min<int64_t>(capacity, ws.ncell * 12);
+    if (hipMemcpy(nnghs, ws.kk, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(ctx, "twx_last_bandwidths: copy failed");
+    return ws.ncell;
+}
+
 }  // extern "C"

@@ -109,7 +109,7 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
 // does not spill the register-resident matrix to chase a higher occupancy)
-#define TWX_UK_WAVES(NB) ((NB) >= 8 ? 2 : ((NB) >= 7 ? 3 : 4))
+#define TWX_UK_WAVES(NB) ((NB) >= 8 ? 2 : ((NB) >= 7 ? 3 : ((NB) >= 5 ? 4 : 5)))
 
 template <int NB>
 __global__ __launch_bounds__(256)
@@ -117,7 +117,8 @@ __attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
 void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems, int ablate)
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
-    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * 4];          // four scaled columns of the current panel, [row][4]
+    constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
+    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * 6];          // four scaled columns of the current panel, [row][4]
     __shared__ double s_B[7][NP];
     __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
     __shared__ double s_cphi[NP];                // cos(lat) per neighbour
@@ -239,15 +240,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                                     double v = A[tri(a, bp)] * rinv;
                                     if (a == bp && tr <= q) v = 0.0;      // rows at / above the diagonal
                                     A[tri(a, bp)] = v;
-                                    pan[(16 * a + tr) * 4 + cc] = v;
+                                    pan[(16 * a + tr) * PS + cc] = v;
                                 });
                             }
                             if constexpr (cc < 3) {          // remaining columns: a(i,p') -= l(i,p) l(p',p)
                                 __builtin_amdgcn_wave_barrier();
-                                const double lpp = pan[(16 * bp + 4 * s + tcl) * 4 + cc];
+                                const double lpp = pan[(16 * bp + 4 * s + tcl) * PS + cc];
                                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                                     constexpr int a = decltype(a_)::value;
-                                    const double li = pan[(16 * a + tr) * 4 + cc];
+                                    const double li = pan[(16 * a + tr) * PS + cc];
                                     if (tcl > cc) A[tri(a, bp)] = fma(-li, lpp, A[tri(a, bp)]);
                                 });
                             }
@@ -255,7 +256,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                             sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                                 constexpr int a = decltype(a_)::value;
                                 A[tri(a, bp)] = 0.0;
-                                pan[(16 * a + tr) * 4 + cc] = 0.0;
+                                pan[(16 * a + tr) * PS + cc] = 0.0;
                             });
                         }
                     });
@@ -264,14 +265,14 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 // rank-4 update of this thread's elements
                 sfor<bp, NB>([&](auto b_) __attribute__((always_inline)) {
                     constexpr int b = decltype(b_)::value;
-                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * 4]);
-                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * 4 + 2]);
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS + 2]);
                     lj0[b] = u0.x; lj1[b] = u0.y; lj2[b] = u1.x; lj3[b] = u1.y;
                 });
                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value;
-                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * 4]);
-                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * 4 + 2]);
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
                     sfor<bp, a + 1>([&](auto b_) __attribute__((always_inline)) {
                         constexpr int b = decltype(b_)::value;
                         double acc = A[tri(a, b)];
