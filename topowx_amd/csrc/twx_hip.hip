@@ -46,14 +46,14 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S;
     int cmax = 512;
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S})
             b->release();
     }
 };
@@ -148,6 +148,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
     HIPCHK(w.ctrig.ensure((size_t)ncell * 32));
+    HIPCHK(w.uk_S.ensure((size_t)ncell * 12 * TWX_UK_SLEN * 8));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
@@ -165,7 +166,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.vario = w.vario.as<double>(); s.cstat = w.cstat.as<int32_t>(); s.kmaxc = w.kmaxc.as<int32_t>();
     s.bucket_cells = w.bucket_cells.as<int32_t>();
     s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
-    s.ctrig = w.ctrig.as<double>();
+    s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     return 0;
 }
@@ -227,6 +228,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
             ctx->t_launches++;
             ctx->t_solves += (int64_t)cnt[b];
         }
+        hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -10,6 +10,8 @@
 #pragma once
 #include "twx_device.h"
 
+#define TWX_UK_SLEN 29
+
 // Workspace of one (batch, variable)
 struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
@@ -36,6 +38,7 @@ struct SelWs {
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
+    double *uk_S;        // [ncell][12][TWX_UK_SLEN] lower triangle of B'C^-1B + error flag
     double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
 };
 

@@ -123,7 +123,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
     __shared__ double s_cphi[NP];                // cos(lat) per neighbour
     __shared__ double s_red[4][4];
-    __shared__ double s_S[49];
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, tc = t >> 4, lane = t & 63, wv = t >> 6, tcl = lane >> 4;
@@ -288,57 +287,78 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
         }
     });
 
-    // ---- Schur complement -> GLS predictor ----------------------------------------------------------
-    if (tr >= 9 && tc >= 9) s_S[(tr - 9) * 7 + (tc - 9)] = -A[tri(NB - 1, NB - 1)];
-    __syncthreads();
-    if (t == 0) {
-        // N = X'C^-1X (5x5), r = X'C^-1y, q = X'C^-1c0, gg = c0'C^-1c0, gb = c0'C^-1y
-        double L[5][5], beta[5], u[5];
-        bool bad = s_err != 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double s = s_S[i * 7 + j];
-#pragma unroll
-                for (int p = 0; p < j; ++p) s -= L[i][p] * L[j][p];
-                if (i == j) { if (!(s > 0.0)) bad = true; L[i][i] = sqrt(s); }
-                else L[i][j] = s / L[j][j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {       // L z = r
-            double s = s_S[i * 7 + 5];
-#pragma unroll
-            for (int p = 0; p < i; ++p) s -= L[i][p] * beta[p];
-            beta[i] = s / L[i][i];
-        }
-#pragma unroll
-        for (int i = 4; i >= 0; --i) {      // L' beta = z
-            double s = beta[i];
-#pragma unroll
-            for (int p = i + 1; p < 5; ++p) s -= L[p][i] * beta[p];
-            beta[i] = s / L[i][i];
-        }
-        // x0 = [1, 0, 0, 0, 0] (trend columns are shifted to the cell)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) u[i] = (i == 0 ? 1.0 : 0.0) - s_S[i * 7 + 6];
-        double mean = s_S[6 * 7 + 5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) mean += u[i] * beta[i];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {       // L w = u
-            double s = u[i];
-#pragma unroll
-            for (int p = 0; p < i; ++p) s -= L[i][p] * u[p];
-            u[i] = s / L[i][i];
-        }
-        double var = c00 - s_S[48];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) var += u[i] * u[i];
-        if (!finite_d(mean) || !finite_d(var)) bad = true;
-        if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
-        ws.uk_mean[lc * 12 + m0] = mean;
-        ws.uk_var[lc * 12 + m0] = var;
+    // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
+    if (tr >= 9 && tc >= 9 && tr >= tc) {
+        const int r = tr - 9, cq = tc - 9;
+        ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = -A[tri(NB - 1, NB - 1)];
     }
+    __syncthreads();
+    if (t == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = s_err ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------
+// k_uk_solve: one thread per (cell, month).  From S = B'C^-1B (lower triangle):
+// N = X'C^-1X (5x5), r = X'C^-1y, q = X'C^-1c0, gg = c0'C^-1c0, gb = c0'C^-1y ->
+//   beta = N^-1 r;  mean = x0'beta + gb - q'beta;  var = c(0) - gg + (x0-q)'N^-1(x0-q)
+// with x0 = [1,0,0,0,0] (trend columns are shifted to the cell).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_uk_solve(SelWs ws)
+{
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= ws.ncell * 12) return;
+    const int64_t lc = item / 12;
+    if (ws.cstat[lc] != 0 || ws.kk[item] <= 0) return;
+    const double *Sp = ws.uk_S + item * TWX_UK_SLEN;
+    double S[7][7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int cq = 0; cq <= r; ++cq) { S[r][cq] = Sp[r * (r + 1) / 2 + cq]; S[cq][r] = S[r][cq]; }
+    const double c00 = ws.vario[item * 3] + ws.vario[item * 3 + 1];
+    double L[5][5], beta[5], u[5];
+    bool bad = Sp[28] != 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = S[i][j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) s -= L[i][p] * L[j][p];
+            if (i == j) { if (!(s > 0.0)) bad = true; L[i][i] = sqrt(s); }
+            else L[i][j] = s / L[j][j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {       // L z = r
+        double s = S[i][5];
+#pragma unroll
+        for (int p = 0; p < i; ++p) s -= L[i][p] * beta[p];
+        beta[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {      // L' beta = z
+        double s = beta[i];
+#pragma unroll
+        for (int p = i + 1; p < 5; ++p) s -= L[p][i] * beta[p];
+        beta[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) u[i] = (i == 0 ? 1.0 : 0.0) - S[i][6];
+    double mean = S[6][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) mean += u[i] * beta[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {       // L w = u
+        double s = u[i];
+#pragma unroll
+        for (int p = 0; p < i; ++p) s -= L[i][p] * u[p];
+        u[i] = s / L[i][i];
+    }
+    double var = c00 - S[6][6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) var += u[i] * u[i];
+    if (!finite_d(mean) || !finite_d(var)) bad = true;
+    if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
+    ws.uk_mean[item] = mean;
+    ws.uk_var[item] = var;
 }
