@@ -109,7 +109,8 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
 // does not spill the register-resident matrix to chase a higher occupancy)
-#define TWX_UK_WAVES(NB) ((NB) >= 8 ? 2 : ((NB) >= 7 ? 3 : ((NB) >= 5 ? 4 : 5)))
+// (measured per bucket on the C2 bench: more resident work-groups beat the few spilled registers)
+#define TWX_UK_WAVES(NB) ((NB) >= 9 ? 3 : ((NB) >= 7 ? 4 : ((NB) == 6 ? 5 : ((NB) == 5 ? 6 : 7))))
 
 template <int NB>
 __global__ __launch_bounds__(256)
