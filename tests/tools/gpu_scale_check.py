@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as orc  # noqa: E402
 from topowx_amd import _lib, synth  # noqa: E402
@@ -72,6 +72,33 @@ def main():
         dd = np.abs(want[k].astype(int) - got[k][:, rs, cs].astype(int))
         print("   %s vs oracle: max LSB diff %d, equal %.6f" % (k, dd.max(), (dd == 0).mean()))
         assert dd.max() <= 1
+    ctx.close()
+
+    # ---- (3) config 5 shape: leave-one-out xval of the normals over all stations (step24 path) -----
+    grid = synth.make_grid("C2")
+    stn = synth.make_stations(grid["bbox"], 10000, 1, "tmin")
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, stn, with_obs=False)
+    good = np.isnan(stn.stns["bad"])
+    s = stn.stns[good]
+    lst = np.column_stack([s["lst%02d" % m] for m in range(1, 13)])
+    pts = ctx.make_pts(s["longitude"], s["latitude"], s["elevation"], s["tdi"], lst)
+    j = np.arange(s.size, dtype=np.int32)
+    t0 = time.time()
+    _, norms, se, st = ctx.interp_points(_lib.TMIN, pts, excl=j, rm_zero_dist=True, daily=False)
+    t1 = time.time()
+    ok = st == 0
+    obs_norm = np.column_stack([s["norm%02d" % m] for m in range(1, 13)])
+    mae = np.abs(norms[ok] - obs_norm[ok]).mean()
+    print("LOO xval normals, %d stations x 12 months: %.3f s host call (%.3g station-months/s), ok %d, MAE %.3f degC, status %s"
+          % (s.size, t1 - t0, s.size * 12 / (t1 - t0), ok.sum(), mae, dict(zip(*np.unique(st, return_counts=True)))))
+    db = orc.Db(stn)
+    for q in (0, 1234, 9000):
+        pt = orc.make_pt(s["longitude"][q], s["latitude"][q], s["elevation"][q], s["tdi"][q], lst[q])
+        rc, _, n_o, se_o = orc.interp(db, orc.params(), pt, excl=int(q), rm_zero_dist=True, daily=False)
+        assert rc == st[q]
+        if rc == 0:
+            assert np.abs(n_o - norms[q]).max() < 1e-4 and np.abs(se_o - se[q]).max() < 1e-4
     ctx.close()
 
 
