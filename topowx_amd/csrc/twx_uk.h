@@ -42,6 +42,15 @@ __device__ __forceinline__ void sfor(F &&f)
     }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor2(F &&f)       // step 2
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor2<I + 2, N>(f);
+    }
+}
+
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
     // v_rsq_f64 seed (~2^-23) + Newton steps; the second step only polishes the
@@ -213,7 +222,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
 
     // ---- elimination: panels of four columns ------------------------------------------------------
     int pbuf = 0;
-    double lj0[NB], lj1[NB], lj2[NB], lj3[NB];
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
         const int ncb = (ablate & 1) ? 0 : k - 16 * bp;      // C columns left (ablate: timing experiments only)
@@ -262,25 +270,39 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                     });
                 }
                 __syncthreads();
-                // rank-4 update of this thread's elements
-                sfor<bp, NB>([&](auto b_) __attribute__((always_inline)) {
+                // rank-4 update of this thread's elements, two block columns at a time: the slab rows of
+                // two columns (8 doubles) stay in registers while the rows a >= b stream through; keeping
+                // all NB column rows live instead costs (NB-2)*8 VGPRs, i.e. occupancy or spills
+                sfor2<bp, NB>([&](auto b_) __attribute__((always_inline)) {
                     constexpr int b = decltype(b_)::value;
-                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS]);
-                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS + 2]);
-                    lj0[b] = u0.x; lj1[b] = u0.y; lj2[b] = u1.x; lj3[b] = u1.y;
-                });
-                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                    constexpr int a = decltype(a_)::value;
-                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
-                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
-                    sfor<bp, a + 1>([&](auto b_) __attribute__((always_inline)) {
-                        constexpr int b = decltype(b_)::value;
-                        double acc = A[tri(a, b)];
-                        acc = fma(-u0.x, lj0[b], acc);
-                        acc = fma(-u0.y, lj1[b], acc);
-                        acc = fma(-u1.x, lj2[b], acc);
-                        acc = fma(-u1.y, lj3[b], acc);
-                        A[tri(a, b)] = acc;
+                    constexpr bool two = (b + 1 < NB);
+                    const double2 p0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS]);
+                    const double2 p1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS + 2]);
+                    double2 q0 = p0, q1 = p1;
+                    if constexpr (two) {
+                        q0 = *reinterpret_cast<const double2 *>(&pan[(16 * (b + 1) + tc) * PS]);
+                        q1 = *reinterpret_cast<const double2 *>(&pan[(16 * (b + 1) + tc) * PS + 2]);
+                    }
+                    sfor<b, NB>([&](auto a_) __attribute__((always_inline)) {
+                        constexpr int a = decltype(a_)::value;
+                        const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
+                        const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
+                        {
+                            double acc = A[tri(a, b)];
+                            acc = fma(-u0.x, p0.x, acc);
+                            acc = fma(-u0.y, p0.y, acc);
+                            acc = fma(-u1.x, p1.x, acc);
+                            acc = fma(-u1.y, p1.y, acc);
+                            A[tri(a, b)] = acc;
+                        }
+                        if constexpr (two && a >= b + 1) {
+                            double acc = A[tri(a, b + 1)];
+                            acc = fma(-u0.x, q0.x, acc);
+                            acc = fma(-u0.y, q0.y, acc);
+                            acc = fma(-u1.x, q1.x, acc);
+                            acc = fma(-u1.y, q1.y, acc);
+                            A[tri(a, b + 1)] = acc;
+                        }
                     });
                 });
                 pbuf ^= 1;
