@@ -17,6 +17,7 @@
 #include "twx_daily.h"
 #include "twx_out.h"
 #include "twx_uk.h"
+#include "twx_uk1.h"
 
 namespace {
 
@@ -143,7 +144,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
     HIPCHK(w.cstat.ensure((size_t)ncell * 4));
     HIPCHK(w.kmaxc.ensure((size_t)ncell * 4));
-    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 7 * 4));
+    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 13 * 4));
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
@@ -159,7 +160,11 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.cell0 = cell0; s.ncell = ncell; s.tile0 = tile0; s.ntile = ntile;
     s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
     s.ncand_max = w.small.as<int32_t>();          // [0]
-    s.bucket_cnt = w.small.as<int32_t>() + 8;     // [8..15]
+    s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16..31]
+    {
+        static const int small_kmax = getenv("TWX_UK1_MAXK") ? atoi(getenv("TWX_UK1_MAXK")) : 72;
+        s.small_kmax = std::min(std::max(small_kmax, 0), 72);
+    }
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
     s.nnear = w.nnear.as<int32_t>(); s.kk = w.kk.as<int32_t>(); s.ka = w.ka.as<int32_t>();
@@ -176,6 +181,12 @@ void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int3
 {
     static const int ablate = getenv("TWX_UK_ABLATE") ? atoi(getenv("TWX_UK_ABLATE")) : 0;  // timing experiments only
     hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt, ablate);
+}
+
+template <int NB8>
+void launch_uk1(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_uk1<NB8>), dim3(cnt), dim3(64), 0, s, st, src, ws, cells, cnt);
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
@@ -208,21 +219,27 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     }
     if (!src.do_krig) return 0;
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
-    int32_t cnt[8];
+    int32_t cnt[16];
     HIPCHK(hipMemcpyAsync(cnt, w.ws.bucket_cnt, sizeof cnt, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     {
         EvScope ev(ctx, stream, EV_UK);
-        for (int b = 0; b < 7; ++b) {
+        for (int b = 0; b < 13; ++b) {
             if (cnt[b] <= 0) continue;
             const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell * 12;
-            switch (b + 4) {
-            case 4: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 5: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 6: launch_uk<6>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 7: launch_uk<7>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 8: launch_uk<8>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 9: launch_uk<9>(st, src, w.ws, cells, cnt[b], stream); break;
+            switch (b) {
+            case 0: launch_uk1<5>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 1: launch_uk1<6>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 2: launch_uk1<7>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 3: launch_uk1<8>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 4: launch_uk1<9>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 5: launch_uk1<10>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 6: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 7: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 8: launch_uk<6>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 9: launch_uk<7>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 10: launch_uk<8>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 11: launch_uk<9>(st, src, w.ws, cells, cnt[b], stream); break;
             default: launch_uk<10>(st, src, w.ws, cells, cnt[b], stream); break;
             }
             ctx->t_launches++;

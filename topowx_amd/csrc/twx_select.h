@@ -17,6 +17,7 @@ struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
     int cmax;            // candidate slots per tile
     int init_nnghs;
+    int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_uk1)
     int64_t cell0;       // first global cell id of the batch
     int64_t ncell;       // cells in the batch
     int64_t tile0;       // first tile id of the batch
@@ -33,8 +34,8 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *kmaxc;      // [ncell] largest kk / ka of the cell
-    int32_t *bucket_cnt; // [8]
-    int32_t *bucket_cells; // [7][ncell * 12] (cell, month) items per matrix-size bucket
+    int32_t *bucket_cnt; // [16]: 0..5 one-wave kernel NB8 = 5..10, 6..12 four-wave kernel NB = 4..10
+    int32_t *bucket_cells; // [13][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
@@ -339,23 +340,28 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 {
-    __shared__ int s_cnt[8], s_base[8];
+    __shared__ int s_cnt[16], s_base[16];
     const int t = threadIdx.x;
-    if (t < 8) s_cnt[t] = 0;
+    if (t < 16) s_cnt[t] = 0;
     __syncthreads();
     const int64_t item = (int64_t)blockIdx.x * 256 + t;
-    int nb = -1, rank = 0;
+    int id = -1, rank = 0;
     if (item < ws.ncell * 12) {
         const int64_t lc = item / 12;
         const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
         if (k > 0) {
-            nb = (k + 8 + 15) / 16;
-            if (nb < 4) nb = 4;
-            rank = atomicAdd(&s_cnt[nb - 4], 1);
+            if (k <= ws.small_kmax) {
+                int nb8 = (k + 8 + 7) / 8;
+                id = (nb8 < 5 ? 5 : nb8) - 5;
+            } else {
+                int nb = (k + 8 + 15) / 16;
+                id = 6 + (nb < 4 ? 4 : nb) - 4;
+            }
+            rank = atomicAdd(&s_cnt[id], 1);
         }
     }
     __syncthreads();
-    if (t < 7 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
+    if (t < 13 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
     __syncthreads();
-    if (nb >= 4) ws.bucket_cells[(int64_t)(nb - 4) * ws.ncell * 12 + s_base[nb - 4] + rank] = (int32_t)item;
+    if (id >= 0) ws.bucket_cells[(int64_t)id * ws.ncell * 12 + s_base[id] + rank] = (int32_t)item;
 }
