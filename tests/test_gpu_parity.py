@@ -233,3 +233,31 @@ def test_cell_on_station_is_exact_interpolator(env):
     mean, var, _, st, _ = ctx.krig_points(lib.TMIN, pts, 6)
     # pair distances are kept in fp32 registers on the GPU: exactness holds to ~1e-7 degC
     assert st[0] == 0 and abs(mean[0] - c["norm"][5, j]) < 1e-6 and abs(var[0]) < 1e-6
+
+
+def test_device_pointer_entry_matches_host_entry(env):
+    """twx_interp_grid_dev (inputs resident in HBM, caller's stream) == twx_interp_grid."""
+    import torch
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    rs, cs = slice(8, 40), slice(16, 64)
+    host = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
+    a = ctx.grid_arrays(grid, rs, cs)
+    Y, X = a["mask"].shape
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in a.items()}
+    norm = torch.full((12, Y, X), float(lib.FILL_F4), dtype=torch.float32, device=dev)
+    se = torch.full((12, Y, X), float(lib.FILL_F4), dtype=torch.float32, device=dev)
+    stat = torch.full((Y, X), -1, dtype=torch.int32, device=dev)
+    g = lib.TwxGrid(Y, X, d["mask"].data_ptr(), d["lat"].data_ptr(), d["lon"].data_ptr(), d["elev"].data_ptr(),
+                    d["tdi"].data_ptr(), d["climdiv"].data_ptr(), d["lst_night"].data_ptr(), None)
+    o = lib.TwxGridOut(norm.data_ptr(), se.data_ptr(), None, None, None, None, None, stat.data_ptr())
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.interp_grid_dev(g, o, lib.VAR_TMIN_BIT, s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(norm.cpu().numpy(), host["norm_tmin"]) and np.array_equal(se.cpu().numpy(), host["se_tmin"])
+    assert np.array_equal(stat.cpu().numpy(), host["status"])
+    t = ctx.timing()
+    assert t["cells"] == Y * X and t["uk_solves"] == Y * X * 12 and t["uk_ms"] > 0 and t["total_ms"] >= t["uk_ms"]
+    k = ctx.last_bandwidths(lib.TMIN)
+    assert k.shape == (Y * X, 12) and k.min() >= 35 and k.max() <= 147

@@ -446,6 +446,8 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
                   const int32_t *mth, const int32_t *nnghs, const double *vario, const int32_t *excl,
                   const double *pt_norm, PtDev &pd)
 {
+    ctx->ev_used = 0;   // point entries do not report kernel timing: recycle the event pool
+    ctx->have_total = false;
     size_t bytes = (size_t)npts * (sizeof(twx_pt) + 3 * 4 + 4 * 8) + 4096;
     HIPCHK(ctx->pt_in.ensure(bytes));
     char *cur = ctx->pt_in.as<char>();
