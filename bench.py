@@ -54,20 +54,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TWX_BENCH_BACKEND=gloo + TWX_BENCH_SHARE_GPU=1: control-flow check of the N > 1 path on a 1-GPU box
+    backend = os.environ.get("TWX_BENCH_BACKEND", "nccl")
+    if os.environ.get("TWX_BENCH_SHARE_GPU") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    # ---- synthetic workload: rank r gets the tile r columns to the east -------------------
+    # ---- synthetic workload -----------------------------------------------------------------
+    # Every rank holds the SAME replicated station table (the N = 1 table) and interpolates its own
+    # 250x250 tile: rank r's tile is the C2 tile shifted by multiples of 1/8 degree, so all tiles lie
+    # inside the station region and carry statistically the same work (weak scaling, fixed per-GPU work).
     Y = X = args.size
-    grid = synth.make_grid("C2", nrows=Y, ncols=X, lon_west=-111.0 + rank * X * synth.CELL)
-    # station table replicated on every rank: built over the union bbox of all ranks' tiles
-    g0 = synth.make_grid("C2", nrows=Y, ncols=X) if rank else grid
-    bbox = (g0["bbox"][0], g0["bbox"][1], g0["bbox"][2], g0["bbox"][3] + (world - 1) * X * synth.CELL)
-    nst = args.nstns if world == 1 else int(args.nstns * (4.0 + 2.083 * world) / 6.083)
-    stn = synth.make_stations(bbox, nst, synth.CONFIGS["C2"][5], "tmin")
+    base = synth.make_grid("C2", nrows=Y, ncols=X)
+    stn = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmin")
+    if rank == 0:
+        grid = base
+    else:
+        grid = synth.make_grid("C2", nrows=Y, ncols=X, lon_west=-111.0 + 0.125 * (rank % 4),
+                               lat_north=46.0 - 0.125 * (rank // 4))
 
     ctx = _lib.Context(device=local)
     ctx.set_stations(_lib.TMIN, stn, with_obs=False)
@@ -106,7 +117,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
