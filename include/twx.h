@@ -171,6 +171,15 @@ int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,
                       const int32_t *excl, int rm_zero_dist, double *daily, double *norms,
                       double *se, int32_t *status);
 
+/* BuildKrigParams.get_krig_params(pt, mth) (interp_tair.py:635-698) and the first half of R
+ * krig_all (interp.R:148-159): R get_vario_params (interp.R:54-113) -- OLS-residual variogram,
+ * range fit, GLS-residual variogram, range fit -- on the nnghs nearest stations of each (point,
+ * month).  nnghs NULL / <= 0 -> smoothed bandwidth (:665-678).  vario[npts][3] = (nug, psill, range),
+ * (nug, 0, 0) for a pure-nugget result.  SURVEY.md 8f-1; parity with gstat unpinned. */
+int twx_fit_vario_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                         const int32_t *nnghs, const int32_t *excl, int rm_zero_dist, double *vario,
+                         int32_t *nnghs_used, int32_t *status);
+
 /* tmin_tmax_fixer + normals recompute (interp_tair.py:143-197,579-590) on
  * nseries independent [ndays] degC series, in place.  norm_* [nseries][12] are
  * overwritten only for series with ninvalid > 0 (may be NULL). */

@@ -264,3 +264,28 @@ def interp_grid(db_tmin, db_tmax, prm, grid, daily=False, nthreads=1, rows=None,
         g("daily_tmin", i16p), g("daily_tmax", i16p), _ptr(out["ninvalid"], _ip), _ptr(out["status"], _ip),
         C.c_int(nthreads))
     return out
+
+
+# ---- second tier (8f-1): variogram estimation + range fit --------------------------------------
+def get_vario_params(lon, lat, elev, lst, y, max_ngh_dist):
+    lon, lat, elev, lst, y = (np.ascontiguousarray(a, np.float64) for a in (lon, lat, elev, lst, y))
+    v = np.zeros(3)
+    rc = lib().orc_get_vario_params(C.c_int(lon.size), _ptr(lon, _dp), _ptr(lat, _dp), _ptr(elev, _dp),
+                                    _ptr(lst, _dp), _ptr(y, _dp), C.c_double(max_ngh_dist), _ptr(v, _dp))
+    return rc, v
+
+
+def build_krig_params(db, prm, pt, mth):
+    v = np.zeros(3)
+    used = C.c_int()
+    rc = lib().orc_build_krig_params(C.byref(db.c), C.byref(prm), C.byref(pt), C.c_int(mth), _ptr(v, _dp),
+                                     C.byref(used))
+    return rc, v, used.value
+
+
+def krigall(db, prm, pt, nnghs, excl=-1, rm_zero_dist=False):
+    norms = np.zeros(12)
+    vario = np.zeros((12, 3))
+    rc = lib().orc_krigall(C.byref(db.c), C.byref(prm), C.byref(pt), C.c_int(nnghs), C.c_int32(excl),
+                           C.c_int(int(rm_zero_dist)), _ptr(norms, _dp), _ptr(vario, _dp))
+    return rc, norms, vario

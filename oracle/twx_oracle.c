@@ -592,6 +592,280 @@ void orc_pack_i16(const double *x, int64_t n, int16_t *out)
     }
 }
 
+/* ------------------------------------------------ second tier: 8f-1 ---- */
+/* OLS residuals of y ~ 1 + lon + lat + elev + lst (lm(FORMULA), interp.R:66,64): columns
+ * centred / scaled first (same fitted values), normal equations by Cholesky. */
+static int ols_residuals(int k, const double *const cols[4], const double *y, double *e)
+{
+    enum { P = 5 };
+    double mu[4], sc[4], N[P * P], r[P], b[P];
+    for (int c = 0; c < 4; ++c) {
+        double m = 0, s = 0;
+        for (int i = 0; i < k; ++i) m += cols[c][i];
+        m /= k;
+        for (int i = 0; i < k; ++i) { double t = fabs(cols[c][i] - m); if (t > s) s = t; }
+        mu[c] = m; sc[c] = s > 0.0 ? s : 1.0;
+    }
+    memset(N, 0, sizeof N); memset(r, 0, sizeof r);
+    for (int i = 0; i < k; ++i) {
+        double x[P] = { 1.0, (cols[0][i] - mu[0]) / sc[0], (cols[1][i] - mu[1]) / sc[1],
+                        (cols[2][i] - mu[2]) / sc[2], (cols[3][i] - mu[3]) / sc[3] };
+        for (int c = 0; c < P; ++c) {
+            for (int d = 0; d <= c; ++d) N[c * P + d] += x[c] * x[d];
+            r[c] += x[c] * y[i];
+        }
+    }
+    for (int c = 0; c < P; ++c) for (int d = c + 1; d < P; ++d) N[c * P + d] = N[d * P + c];
+    if (chol_lower(N, P)) return 1;
+    memcpy(b, r, sizeof r);
+    fwd_solve(N, P, b); bwd_solve_t(N, P, b);
+    for (int i = 0; i < k; ++i) {
+        double f = b[0];
+        for (int c = 0; c < 4; ++c) f += b[1 + c] * ((cols[c][i] - mu[c]) / sc[c]);
+        e[i] = y[i] - f;
+    }
+    return 0;
+}
+
+static double sample_var(const double *x, int n)
+{
+    double m = 0, s = 0;
+    for (int i = 0; i < n; ++i) m += x[i];
+    m /= n;
+    for (int i = 0; i < n; ++i) s += (x[i] - m) * (x[i] - m);
+    return s / (n - 1);
+}
+
+/* gstat::variogram(..., cutoff, width) on residuals [upstream-recall]: every pair i<j with
+ * 0 < h <= cutoff goes to bin floor(h / width) (a pair exactly on a boundary to the lower bin),
+ * gamma = sum (e_i - e_j)^2 / (2 np), dist = mean h; empty bins are dropped. */
+int orc_variogram(int k, const double *lon, const double *lat, const double *e, double cutoff,
+                  double width, double *dist, double *gamma, double *np)
+{
+    int nb = (int)ceil(cutoff / width) + 1;
+    if (nb > 4096) nb = 4096;
+    double *sh = calloc((size_t)nb, sizeof(double)), *sg = calloc((size_t)nb, sizeof(double));
+    double *sn = calloc((size_t)nb, sizeof(double));
+    for (int i = 1; i < k; ++i)
+        for (int j = 0; j < i; ++j) {
+            double h = orc_ellip_dist(lon[i], lat[i], lon[j], lat[j]);
+            if (!(h <= cutoff)) continue;
+            int b = (int)floor(h / width);
+            if (b > 0 && h == b * width) --b;
+            if (b >= nb) b = nb - 1;
+            double d = e[i] - e[j];
+            sh[b] += h; sg[b] += d * d; sn[b] += 1.0;
+        }
+    int n = 0;
+    for (int b = 0; b < nb; ++b)
+        if (sn[b] > 0) { dist[n] = sh[b] / sn[b]; gamma[n] = sg[b] / (2.0 * sn[b]); np[n] = sn[b]; ++n; }
+    free(sh); free(sg); free(sn);
+    return n;
+}
+
+static double fit_sse(int nbin, const double *dist, const double *gamma, const double *np,
+                      double nug, double psill, double range)
+{
+    double s = 0;
+    for (int b = 0; b < nbin; ++b) {
+        double m = nug + psill * (1.0 - exp(-dist[b] / range));
+        double w = np[b] / (dist[b] * dist[b]);
+        s += w * (gamma[b] - m) * (gamma[b] - m);
+    }
+    return s;
+}
+
+/* fit.variogram(..., fit.sills = FALSE, fit.ranges = TRUE, fit.method = 7) restated: Gauss-Newton
+ * on the range alone, weights np/h^2; a step is halved (up to 30 times) while it leaves range <= 0
+ * or increases the weighted SSE; stop when the SSE improves by less than 1e-10 relative or after 200
+ * iterations.  Unusable (-> pure-nugget fallback in the caller): psill <= 0, no bins, non-finite or
+ * non-positive range, or a flat objective (no range information). */
+int orc_fit_range(int nbin, const double *dist, const double *gamma, const double *np, double nug,
+                  double psill, double range0, double *range)
+{
+    if (nbin < 1 || !(psill > 0.0) || !(range0 > 0.0)) return 1;
+    double r = range0, sse = fit_sse(nbin, dist, gamma, np, nug, psill, r);
+    for (int it = 0; it < 200; ++it) {
+        double num = 0, den = 0;
+        for (int b = 0; b < nbin; ++b) {
+            double ex = exp(-dist[b] / r);
+            double m = nug + psill * (1.0 - ex);
+            double J = -psill * ex * dist[b] / (r * r);
+            double w = np[b] / (dist[b] * dist[b]);
+            num += w * J * (gamma[b] - m); den += w * J * J;
+        }
+        if (!(den > 0.0) || !isfinite(num)) return 1;
+        double step = num / den, rn = r, ssen = sse;
+        int ok = 0;
+        for (int h = 0; h < 30; ++h) {
+            rn = r + step;
+            if (rn > 0.0 && isfinite(rn)) {
+                ssen = fit_sse(nbin, dist, gamma, np, nug, psill, rn);
+                if (ssen <= sse) { ok = 1; break; }
+            }
+            step *= 0.5;
+        }
+        if (!ok) break; /* no descent possible: converged at r */
+        double impr = sse - ssen;
+        r = rn; sse = ssen;
+        if (impr <= 1e-10 * sse) break;
+    }
+    if (!(r > 0.0) || !isfinite(r)) return 1;
+    *range = r;
+    return 0;
+}
+
+/* GLS trend residuals y - X beta_gls for covariance model (nug, psill, range): what
+ * predict(g, stns_ngh, BLUE = TRUE) returns is the trend X beta_gls (interp.R:82-84). */
+static int gls_residuals(int k, const double *lon, const double *lat, const double *const cols[4],
+                         const double *y, double nug, double psill, double rng, double *e)
+{
+    enum { P = 5 };
+    double *C = malloc(sizeof(double) * (size_t)k * k), *A = malloc(sizeof(double) * (size_t)k * (P + 1));
+    double mu[4], sc[4];
+    int rc = 0;
+    for (int i = 0; i < k; ++i) {
+        C[i * k + i] = nug + psill;
+        for (int j = 0; j < i; ++j)
+            C[i * k + j] = C[j * k + i] = cov_model(orc_ellip_dist(lon[i], lat[i], lon[j], lat[j]), nug, psill, rng);
+    }
+    for (int c = 0; c < 4; ++c) {
+        double m = 0, s = 0;
+        for (int i = 0; i < k; ++i) m += cols[c][i];
+        m /= k;
+        for (int i = 0; i < k; ++i) { double t = fabs(cols[c][i] - m); if (t > s) s = t; }
+        mu[c] = m; sc[c] = s > 0.0 ? s : 1.0;
+    }
+    for (int i = 0; i < k; ++i) {
+        A[i * (P + 1)] = 1.0;
+        for (int c = 0; c < 4; ++c) A[i * (P + 1) + 1 + c] = (cols[c][i] - mu[c]) / sc[c];
+        A[i * (P + 1) + P] = y[i];
+    }
+    if (chol_lower(C, k)) { rc = 1; goto done; }
+    {
+        double *W = malloc(sizeof(double) * (size_t)k * (P + 1));
+        memcpy(W, A, sizeof(double) * (size_t)k * (P + 1));
+        for (int i = 0; i < k; ++i)
+            for (int c = 0; c <= P; ++c) {
+                double t = W[i * (P + 1) + c];
+                for (int p = 0; p < i; ++p) t -= C[i * k + p] * W[p * (P + 1) + c];
+                W[i * (P + 1) + c] = t / C[i * k + i];
+            }
+        double N[P * P], r[P];
+        memset(N, 0, sizeof N); memset(r, 0, sizeof r);
+        for (int i = 0; i < k; ++i)
+            for (int c = 0; c < P; ++c) {
+                for (int d = 0; d <= c; ++d) N[c * P + d] += W[i * (P + 1) + c] * W[i * (P + 1) + d];
+                r[c] += W[i * (P + 1) + c] * W[i * (P + 1) + P];
+            }
+        for (int c = 0; c < P; ++c) for (int d = c + 1; d < P; ++d) N[c * P + d] = N[d * P + c];
+        free(W);
+        if (chol_lower(N, P)) { rc = 1; goto done; }
+        fwd_solve(N, P, r); bwd_solve_t(N, P, r);
+        for (int i = 0; i < k; ++i) {
+            double f = 0;
+            for (int c = 0; c < P; ++c) f += r[c] * A[i * (P + 1) + c];
+            e[i] = y[i] - f;
+        }
+    }
+done:
+    free(C); free(A);
+    return rc;
+}
+
+/* one variogram + constrained fit (interp.R:63-80 and :86-96): nugget fixed at min(gamma), total
+ * sill fixed at `sill`, range fitted from 0.1 * max bin distance; fallback: pure nugget of `sill`. */
+static void fit_or_nugget(int k, const double *lon, const double *lat, const double *e, double cutoff,
+                          double sill, double m[3])
+{
+    int cap = (int)ceil(cutoff / 5.0) + 3;
+    double *dist = malloc(sizeof(double) * 3 * (size_t)cap), *gam = dist + cap, *np = gam + cap;
+    int nb = orc_variogram(k, lon, lat, e, cutoff, 5.0, dist, gam, np);
+    m[0] = sill; m[1] = 0.0; m[2] = 0.0;
+    if (nb > 0) {
+        double gmin = gam[0], dmax = dist[0], rng;
+        for (int b = 1; b < nb; ++b) { if (gam[b] < gmin) gmin = gam[b]; if (dist[b] > dmax) dmax = dist[b]; }
+        if (orc_fit_range(nb, dist, gam, np, gmin, sill - gmin, 0.1 * dmax, &rng) == 0) {
+            m[0] = gmin; m[1] = sill - gmin; m[2] = rng;
+        }
+    }
+    free(dist);
+}
+
+/* interp.R:54-113 */
+int orc_get_vario_params(int k, const double *lon, const double *lat, const double *elev,
+                         const double *lst, const double *y, double max_ngh_dist, double vario[3])
+{
+    const double *cols[4] = { lon, lat, elev, lst };
+    if (k < 7 || k > ORC_MAXK) return ORC_ERR_RANGE;
+    double *e = malloc(sizeof(double) * (size_t)k);
+    double m1[3];
+    int rc = ORC_OK;
+    const double cutoff = max_ngh_dist * 1.4;                         /* :63 */
+    if (ols_residuals(k, cols, y, e)) { rc = ORC_ERR_NUMERIC; goto done; }
+    fit_or_nugget(k, lon, lat, e, cutoff, sample_var(e, k), m1);      /* :64-80 */
+    if (gls_residuals(k, lon, lat, cols, y, m1[0], m1[1], m1[2], e)) { rc = ORC_ERR_NUMERIC; goto done; } /* :82-84 */
+    fit_or_nugget(k, lon, lat, e, cutoff, sample_var(e, k), vario);   /* :85-96, returned as (nug, psill, range) :102-112 */
+    if (!isfinite(vario[0]) || !isfinite(vario[1]) || !isfinite(vario[2])) rc = ORC_ERR_NUMERIC;
+done:
+    free(e);
+    return rc;
+}
+
+static int vario_with_near(const orc_db *db, const near_t *nr, int mth, int nnghs, double vario[3])
+{
+    int32_t idx[ORC_MAXK]; double dist[ORC_MAXK], wgt[ORC_MAXK];
+    double lo[ORC_MAXK], la[ORC_MAXK], el[ORC_MAXK], ls[ORC_MAXK], y[ORC_MAXK];
+    const int m0 = mth - 1;
+    const int64_t n = db->n;
+    int rc = orc_select(nr->idx, nr->dist, nr->n, nnghs, idx, dist, wgt);
+    if (rc) return rc;
+    double dmax = 0;
+    for (int i = 0; i < nnghs; ++i) {
+        int32_t j = idx[i];
+        lo[i] = db->lon[j]; la[i] = db->lat[j]; el[i] = db->elev[j];
+        ls[i] = db->lst[m0 * n + j]; y[i] = db->norm[m0 * n + j];
+        if (dist[i] > dmax) dmax = dist[i];
+    }
+    return orc_get_vario_params(nnghs, lo, la, el, ls, y, dmax, vario);
+}
+
+/* interp_tair.py:635-698 */
+int orc_build_krig_params(const orc_db *db, const orc_params *p, const orc_pt *pt, int mth,
+                          double vario[3], int *nnghs_used)
+{
+    near_t nr;
+    int32_t idx[ORC_MAXK]; double dist[ORC_MAXK], wgt[ORC_MAXK];
+    int nnghs = 0;
+    nr.n = orc_nearest(db, pt->lat, pt->lon, -1, 0, pick_ksel(db, p, 0), nr.idx, nr.dist);
+    int rc = orc_select(nr.idx, nr.dist, nr.n, p->init_nnghs, idx, dist, wgt);         /* :667 */
+    if (rc) return rc;
+    rc = orc_smooth_nnghs(db->optim_nnghs + (mth - 1) * db->n, idx, wgt, p->init_nnghs, &nnghs); /* :669-678 */
+    if (rc) return rc;
+    if (nnghs < 1 || nnghs > ORC_MAXK) return ORC_ERR_RANGE;
+    if (nnghs_used) *nnghs_used = nnghs;
+    return vario_with_near(db, &nr, mth, nnghs, vario);                                 /* :681-698 */
+}
+
+/* interp_tair.py:722-769 + interp.R:148-159 */
+int orc_krigall(const orc_db *db, const orc_params *p, const orc_pt *pt, int nnghs, int32_t excl,
+                int rm_zero_dist, double norms[12], double vario_out[36])
+{
+    near_t nr;
+    if (nnghs < 1 || nnghs > ORC_MAXK) return ORC_ERR_RANGE;
+    nr.n = orc_nearest(db, pt->lat, pt->lon, excl, rm_zero_dist, pick_ksel(db, p, nnghs), nr.idx, nr.dist);
+    for (int mth = 1; mth <= 12; ++mth) {
+        double v[3], mean, var;
+        int rc = vario_with_near(db, &nr, mth, nnghs, v);
+        if (rc) return rc;
+        if (vario_out) memcpy(vario_out + (mth - 1) * 3, v, sizeof v);
+        rc = krig_with_near(db, p, pt, &nr, mth, nnghs, v, &mean, &var, NULL, NULL);
+        if (rc) return rc;
+        norms[mth - 1] = mean;
+    }
+    return ORC_OK;
+}
+
 /* ----------------------------------------------------- step25:126-172 ---- */
 int orc_interp_grid(const orc_db *tmin, const orc_db *tmax, const orc_params *p,
                     int Y, int X, const uint8_t *mask, const double *lat,

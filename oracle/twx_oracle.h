@@ -134,6 +134,35 @@ int orc_interp_grid(const orc_db *tmin, const orc_db *tmax, const orc_params *p,
                     int16_t *daily_tmin, int16_t *daily_tmax, int32_t *ninvalid,
                     int32_t *status, int nthreads);
 
+/* ---- second tier: variogram estimation + range fit ---------------------
+ * R get_vario_params (interp.R:54-113) with my.autofit.gwvario (:290-428) -> gstat
+ * variogram / fit.variogram / predict(BLUE=TRUE).  PARITY UNPINNED (gstat not runnable, its
+ * optimiser's stopping rules are restated, not copied): see twx_oracle.c for the exact scheme. */
+
+/* binned semivariogram of residuals e (interp.R:64,86): pairs within cutoff, 5 km bins of the
+ * B.1 distance; returns the number of non-empty bins; arrays sized >= cutoff/width + 2 */
+int orc_variogram(int k, const double *lon, const double *lat, const double *e, double cutoff,
+                  double width, double *dist, double *gamma, double *np);
+
+/* one-parameter weighted fit of the range of nug + psill (1 - exp(-h/range)), weights np/h^2
+ * (fit.method = 7), Gauss-Newton from range0 with step halving; returns 0 and *range, or 1 if the
+ * fit is unusable (the R code then falls back to a pure nugget, interp.R:73-80) */
+int orc_fit_range(int nbin, const double *dist, const double *gamma, const double *np, double nug,
+                  double psill, double range0, double *range);
+
+/* get_vario_params (interp.R:54-113): vario = (nug, psill, range) or (nug, 0, 0) */
+int orc_get_vario_params(int k, const double *lon, const double *lat, const double *elev,
+                         const double *lst, const double *y, double max_ngh_dist, double vario[3]);
+
+/* BuildKrigParams.get_krig_params (interp_tair.py:635-698): smoothed nnghs, no exclusion */
+int orc_build_krig_params(const orc_db *db, const orc_params *p, const orc_pt *pt, int mth,
+                          double vario[3], int *nnghs_used);
+
+/* KrigTairAll.krigall (interp_tair.py:722-769) -> R krig_all (interp.R:148-159): per month fit
+ * the variogram on the nnghs nearest (stns_rm / zero-distance removed) and krige with it */
+int orc_krigall(const orc_db *db, const orc_params *p, const orc_pt *pt, int nnghs, int32_t excl,
+                int rm_zero_dist, double norms[12], double vario_out[36] /*optional*/);
+
 #ifdef __cplusplus
 }
 #endif

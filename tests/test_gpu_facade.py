@@ -97,3 +97,49 @@ def test_xval_callers(case, golden):
     bias, mae, r2 = xa.run_xval(ids[0], np.array([35, 57, 101]))
     assert bias.shape == (3, 12) and np.all(mae > 0) and np.all((r2 >= 0) & (r2 <= 1))
     xa.close()
+
+
+def test_variogram_fit_and_krigall(case, orc):
+    """BuildKrigParams.get_krig_params / KrigTairAll.krigall / XvalTairNorm /
+    StationKrigParams against the oracle's restatement of R get_vario_params (parity with gstat unpinned)."""
+    from topowx_amd import stationdb as sdb
+    from topowx_amd.interp import (BuildKrigParams, KrigTairAll, StationKrigParams, StationSelect, XvalTairNorm,
+                                   build_nstn_bandwidths)
+    grid, tmin, _ = case
+    good = np.isnan(tmin.stns[sdb.BAD])
+    stns = tmin.stns[good]
+    db, prm = orc.Db(tmin), orc.params()
+    c = db.cols
+    # step22 shape: the station record is the point, it stays in its own neighbourhood
+    slct = StationSelect(tmin, good)
+    bkp = BuildKrigParams(slct)
+    for j, m in ((3, 1), (77, 6), (150, 9), (301, 12)):
+        nug, psill, rng = bkp.get_krig_params(stns[j], m)
+        pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+        rc, v, _ = orc.build_krig_params(db, prm, pt, m)
+        assert rc == 0
+        np.testing.assert_allclose([nug, psill, rng], v, rtol=1e-6, atol=1e-9)
+    skp = StationKrigParams(tmin, "tmin")
+    ids = [stns[sdb.STN_ID][j] for j in (3, 77)]
+    nug, psill, rng = skp.get_krig_params_many(ids)
+    assert nug.shape == (2, 12) and np.all(nug > 0) and np.all(psill >= 0) and np.all(rng >= 0)
+    rc, v, _ = orc.build_krig_params(db, prm, orc.make_pt(c["lon"][77], c["lat"][77], c["elev"][77], c["tdi"][77],
+                                                          c["lst"][:, 77]), 6)
+    np.testing.assert_allclose([nug[1, 5], psill[1, 5], rng[1, 5]], v, rtol=1e-6, atol=1e-9)
+    skp.close()
+    # step21 shape: leave-one-out, explicit bandwidth, fit + krige per month
+    xs = StationSelect(tmin, good, rm_zero_dist_stns=True)
+    ka = KrigTairAll(xs)
+    for j, k in ((10, 35), (200, 57), (333, 101)):
+        got = ka.krigall(stns[j], k, stns_rm=stns[sdb.STN_ID][j])
+        pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+        rc, want, _ = orc.krigall(db, prm, pt, k, excl=j, rm_zero_dist=True)
+        assert rc == 0 and np.abs(got - want).max() < 1e-4
+    xv = XvalTairNorm(tmin, "tmin")
+    ladder = build_nstn_bandwidths(35, 150, 0.10)
+    err = xv.run_xval(stns[sdb.STN_ID][200], ladder)
+    assert err.shape == (12, 16)
+    pt = orc.make_pt(c["lon"][200], c["lat"][200], c["elev"][200], c["tdi"][200], c["lst"][:, 200])
+    rc, want, _ = orc.krigall(db, prm, pt, int(ladder[5]), excl=200, rm_zero_dist=True)
+    assert np.abs(err[:, 5] - (want - c["norm"][:, 200])).max() < 1e-4
+    xv.close()

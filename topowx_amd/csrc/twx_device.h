@@ -39,6 +39,7 @@ struct CellSrc {
     const double *vario_in;    // per point [3] explicit variogram (NaN nugget = smooth) or null
     int rm_zero;
     int do_krig;         // derive kriging bandwidth + variogram (a3, a4)
+    int do_vario;        // smooth the variogram from the neighbours' (0: it is fitted afterwards, 8f-1)
     int do_anom;         // derive the GWR bandwidth (needs optim_nnghs_anom)
 };
 

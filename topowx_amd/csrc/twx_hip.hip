@@ -18,6 +18,7 @@
 #include "twx_out.h"
 #include "twx_uk.h"
 #include "twx_uk1.h"
+#include "twx_vario.h"
 
 namespace {
 
@@ -47,14 +48,14 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit;
     int cmax = 512;
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit})
             b->release();
     }
 };
@@ -128,7 +129,7 @@ template <class T> T *carve(char *&cur, size_t count)
 
 // ---- workspace of one (batch, variable) ---------------------------------------------
 int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile0, int64_t ntile, int ksel,
-                 int nblocks_tile, bool need_gwr)
+                 int nblocks_tile, bool need_gwr, bool fit_vario = false)
 {
     Work &w = ctx->work[v];
     const int n = ctx->var[v].n;
@@ -155,7 +156,13 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
     }
+    if (fit_vario) {
+        HIPCHK(w.uk_beta.ensure((size_t)ncell * 12 * 5 * 8));
+        HIPCHK(w.vfit.ensure((size_t)ncell * 12 * 3 * 8));
+    }
     SelWs &s = w.ws;
+    s.uk_beta = fit_vario ? w.uk_beta.as<double>() : nullptr;
+    s.vfit = fit_vario ? w.vfit.as<double>() : nullptr;
     s.ksel = ksel; s.cmax = w.cmax; s.init_nnghs = ctx->p.init_nnghs;
     s.cell0 = cell0; s.ncell = ncell; s.tile0 = tile0; s.ntile = ntile;
     s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
@@ -191,13 +198,13 @@ void launch_uk1(const StnDev &st, const CellSrc &src, const SelWs &ws, const int
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
 int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_t ncell, int64_t tile0,
-                  int64_t ntile, int ksel, bool need_gwr, hipStream_t stream)
+                  int64_t ntile, int ksel, bool need_gwr, hipStream_t stream, bool fit_vario = false)
 {
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
     const int nblk = (int)std::min<int64_t>(ntile, 2048);
     for (;;) {
-        if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr)) return -1;
+        if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario)) return -1;
         HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
         {
             EvScope ev(ctx, stream, EV_TILE);
@@ -218,6 +225,8 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         hipLaunchKernelGGL(k_select, dim3((unsigned)((ncell + 3) / 4)), dim3(256), lds, stream, st, src, w.ws);
     }
     if (!src.do_krig) return 0;
+    if (fit_vario)   // model 1: OLS-residual variogram -> ws.vario, then the kriging kernels give the GLS trend
+        hipLaunchKernelGGL(k_vario<0>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     int32_t cnt[16];
     HIPCHK(hipMemcpyAsync(cnt, w.ws.bucket_cnt, sizeof cnt, hipMemcpyDeviceToHost, stream));
@@ -247,6 +256,8 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         }
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
+    if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit
+        hipLaunchKernelGGL(k_vario<1>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -472,7 +483,7 @@ CellSrc point_src(const PtDev &pd, int rm_zero, int do_krig, int do_anom)
 {
     CellSrc s{};
     s.mode = 1; s.pts = pd.pts; s.excl = pd.excl; s.mth = pd.mth; s.nnghs_in = pd.nnghs; s.vario_in = pd.vario;
-    s.rm_zero = rm_zero; s.do_krig = do_krig; s.do_anom = do_anom;
+    s.rm_zero = rm_zero; s.do_krig = do_krig; s.do_anom = do_anom; s.do_vario = 1;
     return s;
 }
 
@@ -545,6 +556,39 @@ int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, cons
         hipLaunchKernelGGL(k_sorted_neighbours, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, nullptr, src,
                            ctx->work[var].ws, 0, ld, d_ngh, (double *)nullptr, (double *)nullptr, (int32_t *)nullptr);
         HIPCHK(hipMemcpy(ngh_idx, d_ngh, npts * ld * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int twx_fit_vario_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                         const int32_t *nnghs, const int32_t *excl, int rm_zero_dist, double *vario,
+                         int32_t *nnghs_used, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (check_var(ctx, var, false)) return -1;
+    if (npts <= 0 || !pts || !mth || !vario || !status) return fail(ctx, "twx_fit_vario_points: bad arguments");
+    for (int64_t i = 0; i < npts; ++i)
+        if (mth[i] < 1 || mth[i] > 12) return fail(ctx, "twx_fit_vario_points: month outside 1..12");
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, nullptr, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 1, 0);
+    src.do_vario = 0;
+    const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, false, nullptr, true)) return -1;
+    HIPCHK(hipDeviceSynchronize());
+    Work &w = ctx->work[var];
+    std::vector<int32_t> cs(npts), us(npts), kk((size_t)npts * 12);
+    std::vector<double> vf((size_t)npts * 36);
+    HIPCHK(hipMemcpy(cs.data(), w.ws.cstat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(us.data(), w.ws.uk_stat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(kk.data(), w.ws.kk, npts * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vf.data(), w.ws.vfit, vf.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i) {
+        status[i] = cs[i] ? cs[i] : us[i];
+        const int m0 = mth[i] - 1;
+        if (nnghs_used) nnghs_used[i] = status[i] ? 0 : kk[i * 12 + m0];
+        if (status[i] == 0) std::memcpy(vario + i * 3, vf.data() + (i * 12 + m0) * 3, 24);
     }
     return 0;
 }
@@ -721,7 +765,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             s.mode = 0; s.Y = Y; s.X = X; s.ts = ts; s.ntx = ntx;
             s.mask = g->mask; s.lat = g->lat; s.lon = g->lon; s.elev = g->elev; s.tdi = g->tdi;
             s.lst = v == 0 ? g->lst_night : g->lst_day;
-            s.do_krig = 1; s.do_anom = daily ? 1 : 0;
+            s.do_krig = 1; s.do_anom = daily ? 1 : 0; s.do_vario = 1;
             if (run_select_uk(ctx, v, s, cell0, ncell, tile0, ntile, pick_ksel(ctx, v, 0), daily, stream)) return -1;
             if (daily && run_gwr(ctx, v, s, nullptr, stream)) return -1;
         }

@@ -40,6 +40,8 @@ struct SelWs {
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
     double *uk_S;        // [ncell][12][TWX_UK_SLEN] lower triangle of B'C^-1B + error flag
+    double *uk_beta;     // [ncell][12][5] GLS trend coefficients (shifted / scaled basis of k_uk)
+    double *vfit;        // [ncell][12][3] fitted variogram (8f-1)
     double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
 };
 
@@ -288,10 +290,13 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
                     if (given) {
                         vp[0] = src.vario_in[c * 3]; vp[1] = src.vario_in[c * 3 + 1]; vp[2] = src.vario_in[c * 3 + 2];
                         if (k >= nnear) status = TWX_CELL_FEW_STATIONS;
-                    } else {
+                    } else if (src.do_vario) {
                         int rc = smooth3(snd, sni, nnear, k, st.nug + m0 * n, st.psill + m0 * n, st.rng + m0 * n, lane, vp);
                         if (rc == -1) rc = TWX_CELL_VARIO;
                         if (rc) status = rc;
+                    } else {                       // variogram fitted afterwards: only Select(k) must exist
+                        if (k >= nnear) status = TWX_CELL_FEW_STATIONS;
+                        else if (!(snd[k] > 0.0)) status = TWX_CELL_NUMERIC;
                     }
                 }
             }

@@ -384,4 +384,8 @@ __global__ __launch_bounds__(256) void k_uk_solve(SelWs ws)
     if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
     ws.uk_mean[item] = mean;
     ws.uk_var[item] = var;
+    if (ws.uk_beta) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ws.uk_beta[item * 5 + i] = beta[i];
+    }
 }

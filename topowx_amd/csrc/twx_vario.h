@@ -1,0 +1,219 @@
+// twx_vario.h -- variogram estimation + one-parameter range fit.
+//
+// R get_vario_params (twx/interp/rpy/interp.R:54-113) behind BuildKrigParams.get_krig_params
+// (interp_tair.py:635-698, step22) and KrigTairAll.krigall (interp_tair.py:722-769, step21):
+//   pass 0: OLS residuals of tair ~ lon + lat + elev + lst over the k neighbours, binned
+//           semivariogram (5 km bins of the sp/gstat distance, cutoff 1.4 x the largest neighbour
+//           distance), nugget fixed at min(gamma), total sill at var(residuals), range fitted by
+//           weighted Gauss-Newton (weights np/h^2); pure-nugget fallback (interp.R:63-80)
+//   GLS trend with that model: the kriging kernels (k_uk / k_uk1 + k_uk_solve) deliver
+//           beta = (X'C^-1X)^-1 X'C^-1 y for the same neighbourhood (interp.R:82-84)
+//   pass 1: the same on the GLS residuals -> (nug, psill, range) (interp.R:85-112)
+// gstat cannot run here: the estimator and the optimiser's stopping rule are restated (scheme in
+// DESIGN.md section 8); parity with gstat itself is unpinned.
+//
+// One 256-thread workgroup per (point, month) item.
+#pragma once
+#include "twx_uk.h"
+
+#define TWX_VBINS 512        // 5 km bins: cutoff up to 2 555 km
+
+__device__ __forceinline__ double block_sum(double v, double *s_tmp /*[4]*/)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+__device__ __forceinline__ double block_max(double v, double *s_tmp)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(s_tmp[0], s_tmp[1]), fmax(s_tmp[2], s_tmp[3]));
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
+{
+    __shared__ double s_lon[TWX_KSEL_MAX], s_lat[TWX_KSEL_MAX], s_e[TWX_KSEL_MAX];
+    __shared__ double s_sh[TWX_VBINS], s_sg[TWX_VBINS], s_sn[TWX_VBINS];
+    __shared__ double s_red[4], s_beta[5], s_nrm[20];
+    __shared__ int s_bad;
+    const int t = threadIdx.x, lane = t & 63;
+    const int64_t item = blockIdx.x;
+    if (item >= ws.ncell * 12) return;
+    const int64_t lc = item / 12;
+    const int m0 = (int)(item % 12);
+    const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
+    if (k <= 0) return;                                  // uniform
+    const int64_t c = ws.cell0 + lc;
+    const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    if (t == 0) s_bad = 0;
+
+    // ---- neighbours (rank order), trend columns shifted to the point and scaled exactly as in k_uk
+    double x[5] = {0, 0, 0, 0, 0}, y = 0, dh = 0;
+    if (t < k) {
+        const int j = ws.near_idx[lc * ws.ksel + t];
+        const double lo = st.lon[j], la = st.lat[j];
+        s_lon[t] = lo; s_lat[t] = la;
+        x[0] = 1.0; x[1] = lo - cv.lon; x[2] = la - cv.lat; x[3] = st.elev[j] - cv.elev; x[4] = st.lst[m0 * n + j] - plst;
+        y = st.norm[m0 * n + j];
+        dh = ws.near_dist[lc * ws.ksel + t];
+    }
+#pragma unroll
+    for (int q = 1; q < 5; ++q) {
+        const double mx = block_max(fabs(x[q]), s_red);
+        x[q] = x[q] * (mx > 0.0 ? 1.0 / mx : 1.0);
+    }
+    const double cutoff = 1.4 * block_max(dh, s_red);    // interp.R:63 (ngh_dist = haversine km)
+
+    // ---- residuals ---------------------------------------------------------------------------------
+    if (PASS == 0) {
+        // lm(FORMULA): normal equations (15 + 5 sums), 5x5 Cholesky by thread 0
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                const double v = block_sum(x[a] * x[b], s_red);
+                if (t == 0) s_nrm[q] = v;
+                ++q;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const double v = block_sum(x[a] * y, s_red);
+            if (t == 0) s_nrm[15 + a] = v;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double L[5][5], b[5];
+            bool bad = false;
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double s = s_nrm[i * (i + 1) / 2 + j];
+                    for (int p = 0; p < j; ++p) s -= L[i][p] * L[j][p];
+                    if (i == j) { if (!(s > 0.0)) bad = true; L[i][i] = sqrt(s); }
+                    else L[i][j] = s / L[j][j];
+                }
+            for (int i = 0; i < 5; ++i) {
+                double s = s_nrm[15 + i];
+                for (int p = 0; p < i; ++p) s -= L[i][p] * b[p];
+                b[i] = s / L[i][i];
+            }
+            for (int i = 4; i >= 0; --i) {
+                double s = b[i];
+                for (int p = i + 1; p < 5; ++p) s -= L[p][i] * b[p];
+                b[i] = s / L[i][i];
+            }
+            for (int i = 0; i < 5; ++i) { s_beta[i] = b[i]; if (!finite_d(b[i])) bad = true; }
+            if (bad) s_bad = 1;
+        }
+    } else {
+        if (t < 5) s_beta[t] = ws.uk_beta[item * 5 + t];       // GLS beta from k_uk_solve
+        if (t == 0 && ws.uk_S[item * TWX_UK_SLEN + 28] != 0.0) s_bad = 1;
+    }
+    __syncthreads();
+    double e = 0.0;
+    if (t < k) {
+        e = y - (s_beta[0] + s_beta[1] * x[1] + s_beta[2] * x[2] + s_beta[3] * x[3] + s_beta[4] * x[4]);
+        s_e[t] = e;
+    }
+    const double emean = block_sum(e, s_red) / k;
+    const double dev = t < k ? e - emean : 0.0;
+    const double sill = block_sum(dev * dev, s_red) / (k - 1);  // var(residuals), interp.R:66,85
+
+    // ---- binned semivariogram (gstat::variogram, width 5 km) -------------------------------------------
+    const double width = 5.0;
+    int nb = (int)ceil(cutoff / width) + 1;
+    if (nb > TWX_VBINS) nb = TWX_VBINS;
+    for (int b = t; b < TWX_VBINS; b += 256) { s_sh[b] = 0.0; s_sg[b] = 0.0; s_sn[b] = 0.0; }
+    __syncthreads();
+    const int npair = k * (k - 1) / 2;
+    for (int p = t; p < npair; p += 256) {
+        int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        const int j = p - i * (i - 1) / 2;
+        const double h = ellip_km(s_lon[i], s_lat[i], s_lon[j], s_lat[j]);
+        if (h <= cutoff) {
+            int b = (int)floor(h / width);
+            if (b > 0 && h == b * width) --b;
+            if (b >= nb) b = nb - 1;
+            const double d = s_e[i] - s_e[j];
+            atomicAdd(&s_sh[b], h); atomicAdd(&s_sg[b], d * d); atomicAdd(&s_sn[b], 1.0);
+        }
+    }
+    __syncthreads();
+
+    // ---- constrained fit by wave 0 (bins over lanes); Gauss-Newton with step halving ----------------------
+    if (t < 64) {
+        double gmin = INFINITY, dmax = 0.0;
+        for (int b = lane; b < nb; b += 64)
+            if (s_sn[b] > 0.0) {
+                const double hb = s_sh[b] / s_sn[b], gb = s_sg[b] / (2.0 * s_sn[b]);
+                s_sh[b] = hb; s_sg[b] = gb;                     // now: mean distance, gamma
+                gmin = fmin(gmin, gb); dmax = fmax(dmax, hb);
+            }
+        gmin = -wave_max(-gmin); dmax = wave_max(dmax);
+        double m0v = sill, m1v = 0.0, m2v = 0.0;               // pure nugget unless the fit is usable
+        const double nug = gmin, psill = sill - gmin;
+        double r = 0.1 * dmax;
+        bool usable = (dmax > 0.0) && (psill > 0.0) && (r > 0.0) && finite_d(psill);
+        if (usable) {
+            auto sse_of = [&](double rr) {
+                double s = 0.0;
+                for (int b = lane; b < nb; b += 64)
+                    if (s_sn[b] > 0.0) {
+                        const double hb = s_sh[b];
+                        const double mm = nug + psill * (1.0 - exp(-hb / rr));
+                        const double w = s_sn[b] / (hb * hb);
+                        s += w * (s_sg[b] - mm) * (s_sg[b] - mm);
+                    }
+                return wave_sum(s);
+            };
+            double sse = sse_of(r);
+            for (int it = 0; it < 200; ++it) {
+                double num = 0.0, den = 0.0;
+                for (int b = lane; b < nb; b += 64)
+                    if (s_sn[b] > 0.0) {
+                        const double hb = s_sh[b];
+                        const double ex = exp(-hb / r);
+                        const double mm = nug + psill * (1.0 - ex);
+                        const double J = -psill * ex * hb / (r * r);
+                        const double w = s_sn[b] / (hb * hb);
+                        num += w * J * (s_sg[b] - mm); den += w * J * J;
+                    }
+                num = wave_sum(num); den = wave_sum(den);
+                if (!(den > 0.0) || !finite_d(num)) { usable = false; break; }
+                double step = num / den, rn = r, ssen = sse;
+                bool ok = false;
+                for (int hh = 0; hh < 30; ++hh) {
+                    rn = r + step;
+                    if (rn > 0.0 && finite_d(rn)) {
+                        ssen = sse_of(rn);
+                        if (ssen <= sse) { ok = true; break; }
+                    }
+                    step *= 0.5;
+                }
+                if (!ok) break;
+                const double impr = sse - ssen;
+                r = rn; sse = ssen;
+                if (impr <= 1e-10 * sse) break;
+            }
+            if (usable && r > 0.0 && finite_d(r)) { m0v = nug; m1v = psill; m2v = r; }
+        }
+        if (lane == 0) {
+            const bool bad = s_bad != 0 || !finite_d(m0v) || !finite_d(m1v) || !finite_d(m2v) || !(k >= 7);
+            if (bad) ws.uk_stat[lc] = TWX_CELL_NUMERIC;
+            double *out = (PASS == 0) ? (ws.vario + item * 3) : (ws.vfit + item * 3);
+            out[0] = m0v; out[1] = m1v; out[2] = m2v;
+        }
+    }
+}

@@ -4,11 +4,12 @@ Every numerical result comes from libtwxhip (HIP kernels on MI355X) through
 ``topowx_amd._lib``; there is no CPU implementation here.
 """
 from .station_select import StationSelect  # noqa: F401
-from .interp_tair import (GwrTairAnom, InterpTair, KrigTair, PtInterpTair, StationDataWrkChk,  # noqa: F401
-                          build_empty_pt, tmin_tmax_fixer)
-from .optimize import XvalTairAnom, XvalTairOverall, build_nstn_bandwidths  # noqa: F401
+from .interp_tair import (BuildKrigParams, GwrTairAnom, InterpTair, KrigTair, KrigTairAll,  # noqa: F401
+                          PtInterpTair, StationDataWrkChk, build_empty_pt, tmin_tmax_fixer)
+from .optimize import (StationKrigParams, XvalTairAnom, XvalTairNorm, XvalTairOverall,  # noqa: F401
+                       build_nstn_bandwidths)
 from .tiling import Tiler, TileGridInfo  # noqa: F401
 
-__all__ = ["StationSelect", "KrigTair", "GwrTairAnom", "InterpTair", "PtInterpTair", "StationDataWrkChk",
-           "build_empty_pt", "tmin_tmax_fixer", "XvalTairOverall", "XvalTairAnom", "build_nstn_bandwidths",
-           "Tiler", "TileGridInfo"]
+__all__ = ["StationSelect", "KrigTair", "KrigTairAll", "BuildKrigParams", "GwrTairAnom", "InterpTair",
+           "PtInterpTair", "StationDataWrkChk", "build_empty_pt", "tmin_tmax_fixer", "XvalTairOverall",
+           "XvalTairAnom", "XvalTairNorm", "StationKrigParams", "build_nstn_bandwidths", "Tiler", "TileGridInfo"]

@@ -11,8 +11,8 @@ from ..stationdb import (BAD, CLIMDIV, ELEV, LAT, LON, MASK, TDI, StationDataWrk
                          get_norm_varname, get_optim_anom_varname, get_optim_varname)
 from .station_select import StationSelect, raise_for_status
 
-__all__ = ["GwrTairAnom", "KrigTair", "InterpTair", "StationDataWrkChk", "PtInterpTair", "build_empty_pt",
-           "tmin_tmax_fixer"]
+__all__ = ["GwrTairAnom", "KrigTair", "KrigTairAll", "BuildKrigParams", "InterpTair", "StationDataWrkChk",
+           "PtInterpTair", "build_empty_pt", "tmin_tmax_fixer"]
 
 DFLT_INIT_NNGHS = 100  # interp_tair.py:51
 
@@ -170,3 +170,43 @@ class PtInterpTair(object):
 
     def close(self):
         self.ctx.close()
+
+
+class BuildKrigParams(object):
+    """Variogram parameters of a point's neighbourhood (interp_tair.py:612-698, step22):
+    bandwidth smoothed from the neighbours' optimum, then R ``get_vario_params`` -- here
+    ``twx_fit_vario_points`` (parity with gstat unpinned)."""
+
+    def __init__(self, stn_slct):
+        self.stn_slct = stn_slct
+
+    def get_krig_params(self, pt, mth, rm_stnid=None):
+        s = self.stn_slct
+        # the reference never passes rm_stnid on (:667,681): the station sits in its own neighbourhood
+        vario, _, st = s.ctx.fit_vario_points(s.var, _pt_to_twx(s.ctx, pt), int(mth),
+                                              rm_zero_dist=s.rm_zero_dist_stns)
+        raise_for_status(st[0])
+        return vario[0, 0], vario[0, 1], vario[0, 2]
+
+
+class KrigTairAll(object):
+    """Variogram fitting + kriging in one step for a given bandwidth (interp_tair.py:700-769,
+    R ``krig_all`` interp.R:148-159); used by the bandwidth optimisation of step21."""
+
+    def __init__(self, stn_slct):
+        self.stn_slct = stn_slct
+
+    def krigall(self, pt, nnghs, stns_rm=None):
+        s = self.stn_slct
+        pts = np.repeat(_pt_to_twx(s.ctx, pt), 12)
+        mth = np.arange(1, 13, dtype=np.int32)
+        excl = s.excl_index(stns_rm)
+        vario, _, st = s.ctx.fit_vario_points(s.var, pts, mth, nnghs=int(nnghs), excl=excl,
+                                              rm_zero_dist=s.rm_zero_dist_stns)
+        for q in st:
+            raise_for_status(q)
+        mean, _, _, st, _ = s.ctx.krig_points(s.var, pts, mth, nnghs=int(nnghs), vario=vario, excl=excl,
+                                              rm_zero_dist=s.rm_zero_dist_stns)
+        for q in st:
+            raise_for_status(q)
+        return mean

@@ -5,7 +5,7 @@ from .. import _lib
 from ..stationdb import BAD, ELEV, LAT, LON, STN_ID, TDI, get_lst_varname, get_norm_varname
 from .station_select import raise_for_status
 
-__all__ = ["build_nstn_bandwidths", "XvalTairOverall", "XvalTairAnom"]
+__all__ = ["build_nstn_bandwidths", "XvalTairOverall", "XvalTairAnom", "XvalTairNorm", "StationKrigParams"]
 
 
 def build_nstn_bandwidths(rng_min, rng_max, pct_step):
@@ -84,3 +84,50 @@ class XvalTairAnom(_XvalBase):
                 mae[x, m - 1] = np.abs(difs).mean()
                 r2[x, m - 1] = np.corrcoef(interp_anom, xval_anom)[0, 1] ** 2
         return bias, mae, r2
+
+
+class XvalTairNorm(_XvalBase):
+    """Leave-one-out xval of the normals over a ladder of bandwidths with variogram fitting
+    (optimize.py:209-266, step21).  Returns err[12, n_bandwidths] = interpolated - observed."""
+
+    def run_xval(self, stn_id, abw_nngh):
+        return self.run_xval_many([stn_id], abw_nngh)[0]
+
+    def run_xval_many(self, stn_ids, abw_nngh):
+        abw = np.asarray(abw_nngh, np.int32)
+        j, pt = self._pts(stn_ids)
+        ns, nb = len(stn_ids), abw.size
+        # one GPU point per (station, bandwidth, month)
+        pts = np.repeat(pt, nb * 12)
+        mth = np.tile(np.arange(1, 13, dtype=np.int32), ns * nb)
+        nn = np.tile(np.repeat(abw, 12), ns)
+        excl = np.repeat(j.astype(np.int32), nb * 12)
+        vario, _, st = self.ctx.fit_vario_points(self.var, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
+        for q in st:
+            raise_for_status(q)
+        mean, _, _, st, _ = self.ctx.krig_points(self.var, pts, mth, nnghs=nn, vario=vario, excl=excl,
+                                                 rm_zero_dist=True)
+        for q in st:
+            raise_for_status(q)
+        obs = np.column_stack([self.stns[j][get_norm_varname(m)] for m in range(1, 13)])      # [ns, 12]
+        interp = mean.reshape(ns, nb, 12)
+        return np.transpose(interp - obs[:, None, :], (0, 2, 1))                                # [ns, 12, nb]
+
+
+class StationKrigParams(_XvalBase):
+    """Per-station variogram parameters for every month (optimize.py:408-474, step22).  As in the
+    reference the station stays inside its own neighbourhood (rm_zero_dist_stns=False, no stns_rm)."""
+
+    def get_krig_params(self, stn_id):
+        nug, psill, rng = self.get_krig_params_many([stn_id])
+        return nug[0], psill[0], rng[0]
+
+    def get_krig_params_many(self, stn_ids):
+        j, pt = self._pts(stn_ids)
+        pts = np.repeat(pt, 12)
+        mth = np.tile(np.arange(1, 13, dtype=np.int32), len(stn_ids))
+        vario, _, st = self.ctx.fit_vario_points(self.var, pts, mth)
+        for q in st:
+            raise_for_status(q)
+        v = vario.reshape(len(stn_ids), 12, 3)
+        return v[:, :, 0], v[:, :, 1], v[:, :, 2]
