@@ -261,3 +261,40 @@ def test_device_pointer_entry_matches_host_entry(env):
     assert t["cells"] == Y * X and t["uk_solves"] == Y * X * 12 and t["uk_ms"] > 0 and t["total_ms"] >= t["uk_ms"]
     k = ctx.last_bandwidths(lib.TMIN)
     assert k.shape == (Y * X, 12) and k.min() >= 35 and k.max() <= 147
+
+
+def test_all_masked_and_nan_predictors(env):
+    """A chunk without any valid cell is a no-op; a NaN predictor fails only its own cell
+    (np.seterr(all='raise') -> FloatingPointError -> fill values, step25:154-160,319)."""
+    ctx, lib = env["ctx"], env["lib"]
+    grid = dict(env["grid"])
+    grid["mask"] = np.zeros_like(grid["mask"])
+    got = ctx.interp_grid(grid, rows=slice(0, 20), cols=slice(0, 30))
+    assert np.all(got["status"] == -1) and np.all(got["norm_tmin"] == lib.FILL_F4)
+    grid = dict(env["grid"])
+    grid["elev"] = grid["elev"].copy()
+    grid["lst_day"] = grid["lst_day"].copy()
+    grid["elev"][3, 4] = np.nan
+    grid["lst_day"][6, 5, 9] = np.nan
+    got = ctx.interp_grid(grid, rows=slice(0, 12), cols=slice(0, 12))
+    bad = np.zeros((12, 12), bool)
+    bad[3, 4] = bad[5, 9] = True
+    assert np.all(got["status"][bad] == 4) and np.all(got["status"][~bad] == 0)
+    assert np.all(got["norm_tmin"][:, bad] == lib.FILL_F4) and np.all(got["norm_tmax"][:, bad] == lib.FILL_F4)
+    assert np.all(np.isfinite(got["norm_tmin"][:, ~bad])) and np.all(got["ninvalid"][bad] == lib.FILL_I4)
+
+
+def test_api_misuse_is_reported_not_crashed(env):
+    lib = env["lib"]
+    ctx = lib.Context()
+    with pytest.raises(lib.TwxError, match="no station table"):
+        ctx.knn(lib.TMIN, [-110.0], [45.0], 10)
+    ctx.set_stations(lib.TMIN, env["tmin"], with_obs=False)
+    with pytest.raises(lib.TwxError, match="needs observations"):
+        ctx.interp_grid(env["grid"], variables=("tmin",), daily=True, rows=slice(0, 2), cols=slice(0, 2))
+    with pytest.raises(lib.TwxError, match="bad arguments"):
+        ctx.knn(lib.TMIN, [-110.0], [45.0], 400)
+    pts = ctx.make_pts(-110.0, 45.0, 1500.0, 30.0, np.zeros(12))
+    with pytest.raises(lib.TwxError, match="month"):
+        ctx.krig_points(lib.TMIN, pts, 13)
+    ctx.close()
