@@ -143,3 +143,25 @@ def test_variogram_fit_and_krigall(case, orc):
     rc, want, _ = orc.krigall(db, prm, pt, int(ladder[5]), excl=200, rm_zero_dist=True)
     assert np.abs(err[:, 5] - (want - c["norm"][:, 200])).max() < 1e-4
     xv.close()
+
+
+def test_step25_chunk_loop_equals_whole_grid(case):
+    """Tiler -> wrk_chk -> PtInterpTair.interp_chunk -> tile store (the step25 worker structure)."""
+    from topowx_amd import _lib, step25
+    grid, tmin, tmax = case
+    sub = {k: (v[:40, :60] if k in ("mask", "elev", "tdi", "climdiv") else v) for k, v in grid.items()}
+    sub["lat"], sub["lon"] = grid["lat"][:40], grid["lon"][:60]
+    sub["lst_night"], sub["lst_day"] = grid["lst_night"][:, :40, :60], grid["lst_day"][:, :40, :60]
+    sub["mask"] = sub["mask"].copy()
+    sub["mask"][:20, :20] = 0                                     # tile h00v00 has no valid cell
+    stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True)
+    assert sorted(stores) == ["h00v01", "h01v00", "h01v01", "h02v00", "h02v01"]
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    whole = ctx.interp_grid(sub, daily=True)
+    ctx.close()
+    for tile_id, (i, j) in (("h01v00", (0, 20)), ("h02v01", (20, 40))):
+        a = stores[tile_id].a
+        for k in ("norm_tmin", "se_tmax", "daily_tmin", "daily_tmax", "ninvalid", "status"):
+            assert np.array_equal(a[k], whole[k][..., i:i + 20, j:j + 20]), (tile_id, k)
