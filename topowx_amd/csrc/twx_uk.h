@@ -81,6 +81,17 @@ __device__ __forceinline__ float exp2_neg_split(float h, float chi, float clo)
     return ldexpf(e, (int)fmaxf(n, -160.f));
 }
 
+// far pairs (> ~1300 km): full fp64 formula; kept out of line so that the (never taken in practice)
+// branch does not bloat every unrolled element of the covariance build
+__device__ __attribute__((noinline)) float ellip_pair_far(double Sd, double cc, double sG2)
+{
+    const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
+    double w = atan(sqrt(Sd / Cd));
+    double R = sqrt(Sd * Cd) / w;
+    double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
+    return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
+}
+
 // WGS84 great-circle distance (sp / gstat) of two points from the
 // sines / cosines of their half latitudes and half longitudes plus cos(lat).
 // With F = (p1+p2)/2, G = (p1-p2)/2, L = (l1-l2)/2:
@@ -96,13 +107,7 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
     const double cc = cph1 * cph2;
     const double sG2 = sG * sG, sL2 = sL * sL;
     const double Sd = fma(cc, sL2, sG2);
-    if (Sd > 0.01) { // > ~1300 km: accurate slow path
-        const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
-        double w = atan(sqrt(Sd / Cd));
-        double R = sqrt(Sd * Cd) / w;
-        double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
-        return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
-    }
+    if (Sd > 0.01) return ellip_pair_far(Sd, cc, sG2);   // > ~1300 km: accurate fp64 path, out of line
     const float S = (float)Sd, g2 = (float)sG2, ccf = (float)cc;
     if (!(S > 0.f)) return 0.f;
     const float cF2 = ccf + g2, sF2 = 1.f - cF2, cG2 = 1.f - g2, C = 1.f - S;
