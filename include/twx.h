@@ -208,6 +208,29 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t);
  * solved).  Copies min(capacity, cells*12) values; returns the number of cells in that batch or < 0. */
 int64_t twx_last_bandwidths(twx_ctx *ctx, int var, int32_t *nnghs, int64_t capacity);
 
+/* ---- monthly / annual aggregation of the daily product --------------------
+ * Replaces _TairAggregate (twx/interp/tiling.py:1080-1166: daily_to_mthly, daily_to_ann,
+ * mthly_to_ann) and the rounding + int16 packing of write_ds_mthly (tiling.py:1169-1219, driven by
+ * scripts/step27_create_monthly.py).  The day axis is the one given to twx_set_days; groups are
+ * (unique years) x (unique months) in year-major order, a (year, month) without days is an empty
+ * group (tiling.py:1101-1107). */
+#define TWX_DT_I16 0 /* raw 'i2' product: value = int16 * float32(0.01), -32767 = masked (tiling.py:36,448) */
+#define TWX_DT_F32 1 /* degC, NaN = masked */
+#define TWX_DT_F64 2
+
+/* number of years / of distinct months on the day axis: mthly has nyr*nmth planes, ann has nyr */
+int twx_aggregate_dims(twx_ctx *ctx, int32_t *nyr, int32_t *nmth);
+
+/* daily [ndays][ncell] of dtype -> any of
+ *   mthly     f8 [nyr*nmth][ncell]  group means, NaN = masked        (daily_to_mthly)
+ *   mthly_i16 i2 [nyr*nmth][ncell]  np.ma.round(mean, 2) packed with scale_factor float32(0.01),
+ *                                    -32767 = masked                   (write_ds_mthly)
+ *   ann       f8 [nyr][ncell]       mean of the year's monthly means  (daily_to_ann / mthly_to_ann)
+ * on_device != 0: all pointers are device pointers and the kernel is enqueued on hip_stream.
+ * kernel_ms (optional): device time of the aggregation kernel (HIP events; synchronises). */
+int twx_aggregate(twx_ctx *ctx, const void *daily, int dtype, int64_t ncell, int on_device,
+                  double *mthly, int16_t *mthly_i16, double *ann, void *hip_stream, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

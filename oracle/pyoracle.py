@@ -289,3 +289,44 @@ def krigall(db, prm, pt, nnghs, excl=-1, rm_zero_dist=False):
     rc = lib().orc_krigall(C.byref(db.c), C.byref(prm), C.byref(pt), C.c_int(nnghs), C.c_int32(excl),
                            C.c_int(int(rm_zero_dist)), _ptr(norms, _dp), _ptr(vario, _dp))
     return rc, norms, vario
+
+
+# ---- second tier (8f-3): monthly / annual aggregation --------------------------------------------
+_AGG_DT = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+
+def agg_groups(day_year, day_month):
+    day_year = np.ascontiguousarray(day_year, np.int32)
+    day_month = np.ascontiguousarray(day_month, np.int32)
+    grp = np.zeros(day_year.size, np.int32)
+    nyr, nmth = C.c_int32(), C.c_int32()
+    rc = lib().orc_agg_groups(C.c_int64(day_year.size), _ptr(day_year, _ip), _ptr(day_month, _ip),
+                              C.byref(nyr), C.byref(nmth), _ptr(grp, _ip))
+    return rc, nyr.value, nmth.value, grp
+
+
+def daily_to_mthly(daily, day_group, ng):
+    """daily: [ndays, ...] int16 raw / f4 / f8 (NaN = masked) -> f8 [ng, ...] (NaN = masked)."""
+    daily = np.ascontiguousarray(daily)
+    nd = daily.shape[0]
+    ncell = int(np.prod(daily.shape[1:], dtype=np.int64))
+    out = np.empty((ng,) + daily.shape[1:], np.float64)
+    lib().orc_daily_to_mthly(C.c_void_p(daily.ctypes.data), C.c_int(_AGG_DT[daily.dtype]), C.c_int64(nd),
+                             C.c_int64(ncell), _ptr(np.ascontiguousarray(day_group, np.int32), _ip),
+                             C.c_int(ng), _ptr(out, _dp))
+    return out
+
+
+def mthly_to_ann(mthly, nyr, nmth):
+    mthly = np.ascontiguousarray(mthly, np.float64)
+    ncell = int(np.prod(mthly.shape[1:], dtype=np.int64))
+    out = np.empty((nyr,) + mthly.shape[1:], np.float64)
+    lib().orc_mthly_to_ann(_ptr(mthly, _dp), C.c_int(nyr), C.c_int(nmth), C.c_int64(ncell), _ptr(out, _dp))
+    return out
+
+
+def pack_mthly_i16(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(x.shape, np.int16)
+    lib().orc_pack_mthly_i16(_ptr(x, _dp), C.c_int64(x.size), out.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out

@@ -937,3 +937,99 @@ int orc_interp_grid(const orc_db *tmin, const orc_db *tmax, const orc_params *p,
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------ second tier: 8f-3 ---- */
+/* _TairAggregate.__init__ (tiling.py:1085-1118): groups = u_yrs x u_mths in year-major order
+ * (a (year, month) with no day is an EMPTY group -> masked mean); group id per day. */
+int orc_agg_groups(int64_t ndays, const int32_t *day_year, const int32_t *day_month, int32_t *nyr,
+                   int32_t *nmth, int32_t *day_group)
+{
+    if (ndays <= 0) return ORC_ERR_RANGE;
+    int32_t y0 = day_year[0], y1 = day_year[0];
+    int has[13] = {0};
+    for (int64_t d = 0; d < ndays; ++d) {
+        if (day_month[d] < 1 || day_month[d] > 12) return ORC_ERR_RANGE;
+        if (day_year[d] < y0) y0 = day_year[d];
+        if (day_year[d] > y1) y1 = day_year[d];
+        has[day_month[d]] = 1;
+    }
+    /* np.unique(days[YEAR]): only years that occur */
+    int32_t ny = 0;
+    int32_t *ymap = (int32_t *)malloc(sizeof(int32_t) * (size_t)(y1 - y0 + 1));
+    char *yhas = (char *)calloc((size_t)(y1 - y0 + 1), 1);
+    for (int64_t d = 0; d < ndays; ++d) yhas[day_year[d] - y0] = 1;
+    for (int32_t y = y0; y <= y1; ++y) ymap[y - y0] = yhas[y - y0] ? ny++ : -1;
+    int mmap[13], nm = 0;
+    for (int m = 1; m <= 12; ++m) mmap[m] = has[m] ? nm++ : -1;
+    for (int64_t d = 0; d < ndays; ++d) day_group[d] = ymap[day_year[d] - y0] * nm + mmap[day_month[d]];
+    *nyr = ny; *nmth = nm;
+    free(ymap); free(yhas);
+    return ORC_OK;
+}
+
+/* one daily value as netCDF4 / numpy hand it to daily_to_mthly: raw int16 is unpacked as
+ * int16 * np.float32(0.01) (float32 product; tiling.py:36,448) with _FillValue masked */
+static inline int agg_value(const void *daily, int dtype, int64_t i, double *v)
+{
+    if (dtype == 0) {
+        int16_t r = ((const int16_t *)daily)[i];
+        if (r == (int16_t)-32767) return 0;
+        float f = (float)r * 0.01f;
+        *v = (double)f;
+        return 1;
+    } else if (dtype == 1) {
+        float f = ((const float *)daily)[i];
+        if (isnan(f)) return 0;
+        *v = (double)f;
+        return 1;
+    }
+    double x = ((const double *)daily)[i];
+    if (isnan(x)) return 0;
+    *v = x;
+    return 1;
+}
+
+/* daily_to_mthly (tiling.py:1120-1134): np.ma.mean(np.ma.take(tair, mask, axis=0), axis=0,
+ * dtype=float) = (sum of the unmasked values, in day order, in f8) * 1. / count; NaN = masked */
+void orc_daily_to_mthly(const void *daily, int dtype, int64_t ndays, int64_t ncell,
+                        const int32_t *day_group, int ng, double *mthly)
+{
+    double *sum = (double *)calloc((size_t)ng, sizeof(double));
+    int64_t *cnt = (int64_t *)calloc((size_t)ng, sizeof(int64_t));
+    for (int64_t c = 0; c < ncell; ++c) {
+        for (int g = 0; g < ng; ++g) { sum[g] = 0.0; cnt[g] = 0; }
+        for (int64_t d = 0; d < ndays; ++d) {
+            double v;
+            if (agg_value(daily, dtype, d * ncell + c, &v)) { sum[day_group[d]] += v; cnt[day_group[d]]++; }
+        }
+        for (int g = 0; g < ng; ++g) mthly[(int64_t)g * ncell + c] = cnt[g] ? sum[g] * 1.0 / (double)cnt[g] : NAN;
+    }
+    free(sum); free(cnt);
+}
+
+/* mthly_to_ann (tiling.py:1151-1166): per year the mean of its nmth monthly means */
+void orc_mthly_to_ann(const double *mthly, int nyr, int nmth, int64_t ncell, double *ann)
+{
+    for (int y = 0; y < nyr; ++y)
+        for (int64_t c = 0; c < ncell; ++c) {
+            double s = 0.0; int n = 0;
+            for (int m = 0; m < nmth; ++m) {
+                double v = mthly[((int64_t)y * nmth + m) * ncell + c];
+                if (!isnan(v)) { s += v; n++; }
+            }
+            ann[(int64_t)y * ncell + c] = n ? s * 1.0 / (double)n : NAN;
+        }
+}
+
+/* write_ds_mthly (tiling.py:1215-1216): np.ma.round(x, 2) assigned to an 'i2' netCDF variable with
+ * scale_factor float32(0.01): netCDF4-python packs as np.around(x / scale_factor) (restated from its
+ * published behaviour; netCDF4 is not installed here); masked -> _FillValue */
+void orc_pack_mthly_i16(const double *x, int64_t n, int16_t *out)
+{
+    const double scale = (double)0.01f;
+    for (int64_t i = 0; i < n; ++i) {
+        if (isnan(x[i])) { out[i] = (int16_t)-32767; continue; }
+        double r = nearbyint(x[i] * 100.0) / 100.0;
+        out[i] = (int16_t)nearbyint(r / scale);
+    }
+}

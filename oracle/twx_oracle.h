@@ -163,6 +163,18 @@ int orc_build_krig_params(const orc_db *db, const orc_params *p, const orc_pt *p
 int orc_krigall(const orc_db *db, const orc_params *p, const orc_pt *pt, int nnghs, int32_t excl,
                 int rm_zero_dist, double norms[12], double vario_out[36] /*optional*/);
 
+/* ---- second tier: monthly / annual aggregation ----------------------------
+ * _TairAggregate (tiling.py:1080-1166) and the rounding + packing of write_ds_mthly
+ * (tiling.py:1169-1219).  PINNED against the executed _TairAggregate slice
+ * (tests/golden/make_golden_agg.py); the netCDF4 unpack / pack arithmetic around it is restated.
+ * dtype: 0 = raw int16 (scale float32(0.01), fill -32767), 1 = f4, 2 = f8 (NaN = masked). */
+int orc_agg_groups(int64_t ndays, const int32_t *day_year, const int32_t *day_month, int32_t *nyr,
+                   int32_t *nmth, int32_t *day_group);
+void orc_daily_to_mthly(const void *daily, int dtype, int64_t ndays, int64_t ncell,
+                        const int32_t *day_group, int ng, double *mthly);
+void orc_mthly_to_ann(const double *mthly, int nyr, int nmth, int64_t ncell, double *ann);
+void orc_pack_mthly_i16(const double *x, int64_t n, int16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

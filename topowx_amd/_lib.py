@@ -79,7 +79,7 @@ class TwxTiming(C.Structure):
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
-           "twx_fit_vario_points")
+           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate")
 
 _LIB = None
 
@@ -138,6 +138,7 @@ class Context(object):
             raise TwxError("twx_create failed (%d): no usable MI355X / HIP device %d; there is no CPU fallback"
                            % (rc, device))
         self.h = h
+        self.device = device
         self.ndays = 0
         self.good = {}
         self.ids = {}
@@ -298,6 +299,47 @@ class Context(object):
         out = np.empty(x.shape, np.int16)
         self._chk(self.lib.twx_pack_i16(self.h, C.c_int64(x.size), _p(x, _dp), _p(out, _sp)), "twx_pack_i16")
         return out
+
+    # ---- monthly / annual aggregation ------------------------------------
+    AGG_DTYPES = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+    def aggregate_dims(self):
+        nyr, nmth = C.c_int32(), C.c_int32()
+        self._chk(self.lib.twx_aggregate_dims(self.h, C.byref(nyr), C.byref(nmth)), "twx_aggregate_dims")
+        return nyr.value, nmth.value
+
+    def aggregate(self, daily, mthly=True, mthly_i16=False, ann=False):
+        """daily [ndays, ...] (raw int16 / f4 / f8 with NaN = masked) on the day axis of ``set_days`` ->
+        dict of the requested f8 ``mthly`` [nyr*nmth, ...], int16 ``mthly_i16`` and f8 ``ann`` [nyr, ...]."""
+        daily = np.ascontiguousarray(daily)
+        if daily.dtype not in self.AGG_DTYPES:
+            raise TypeError("aggregate: daily must be int16, float32 or float64")
+        nyr, nmth = self.aggregate_dims()
+        shp = daily.shape[1:]
+        ncell = int(np.prod(shp, dtype=np.int64))
+        out = {}
+        if mthly:
+            out["mthly"] = np.empty((nyr * nmth,) + shp, np.float64)
+        if mthly_i16:
+            out["mthly_i16"] = np.empty((nyr * nmth,) + shp, np.int16)
+        if ann:
+            out["ann"] = np.empty((nyr,) + shp, np.float64)
+        ms = C.c_float()
+        self._chk(self.lib.twx_aggregate(
+            self.h, C.c_void_p(daily.ctypes.data), C.c_int(self.AGG_DTYPES[daily.dtype]), C.c_int64(ncell),
+            C.c_int(0), _p(out["mthly"], _dp) if mthly else None, _p(out["mthly_i16"], _sp) if mthly_i16 else None,
+            _p(out["ann"], _dp) if ann else None, C.c_void_p(0), C.byref(ms)), "twx_aggregate")
+        out["kernel_ms"] = ms.value
+        return out
+
+    def aggregate_dev(self, daily_ptr, dtype, ncell, mthly_ptr=0, mthly_i16_ptr=0, ann_ptr=0, stream=0, timed=True):
+        """Device-pointer form; returns the kernel time in ms when ``timed`` (synchronises)."""
+        ms = C.c_float()
+        self._chk(self.lib.twx_aggregate(
+            self.h, C.c_void_p(daily_ptr), C.c_int(dtype), C.c_int64(ncell), C.c_int(1),
+            C.cast(C.c_void_p(mthly_ptr), _dp), C.cast(C.c_void_p(mthly_i16_ptr), _sp),
+            C.cast(C.c_void_p(ann_ptr), _dp), C.c_void_p(stream), C.byref(ms) if timed else None), "twx_aggregate")
+        return ms.value if timed else None
 
     # ---- grid entries ------------------------------------------------------------------
     @staticmethod

@@ -19,6 +19,7 @@
 #include "twx_uk.h"
 #include "twx_uk1.h"
 #include "twx_vario.h"
+#include "twx_agg.h"
 
 namespace {
 
@@ -76,6 +77,10 @@ struct twx_ctx {
     std::vector<int32_t> day_month, day_year, mm2chron, chron2mm;
     DevBuf day_dev;
     DayAxis da{};
+    // (year, month) groups of the aggregation entry (tiling.py:1085-1118)
+    DevBuf agg_dev, agg_in, agg_out;
+    AggAxis agg{};
+    hipEvent_t ev_agg_a = nullptr, ev_agg_b = nullptr;
     // scratch for the point entries / fixer
     DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list;
     std::string err;
@@ -331,6 +336,8 @@ void twx_destroy(twx_ctx *ctx)
     for (auto &e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->ev_total_a) (void)hipEventDestroy(ctx->ev_total_a);
     if (ctx->ev_total_b) (void)hipEventDestroy(ctx->ev_total_b);
+    if (ctx->ev_agg_a) (void)hipEventDestroy(ctx->ev_agg_a);
+    if (ctx->ev_agg_b) (void)hipEventDestroy(ctx->ev_agg_b);
     delete ctx;
 }
 
@@ -383,6 +390,30 @@ int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const in
     }
     da.ndays = (int)ndays; da.mm2chron = d_mm2c; da.chron2mm = d_c2mm; da.day_month = d_dm; da.day_year = d_dy;
     da.tail = ctx->p.fixer_tail; da.norm_ny = ny; da.ym_start = d_ys; da.ym_cnt = d_yc;
+
+    // _TairAggregate.__init__: groups = unique years x unique months, year-major; days ascending
+    {
+        int ya = day_year[0], yb = day_year[0];
+        bool mhas[13] = {false};
+        for (int64_t d = 0; d < ndays; ++d) { ya = std::min(ya, day_year[d]); yb = std::max(yb, day_year[d]); mhas[day_month[d]] = true; }
+        std::vector<int> ymap((size_t)(yb - ya + 1), -1);
+        for (int64_t d = 0; d < ndays; ++d) ymap[day_year[d] - ya] = 0;
+        int nyr = 0, nmth = 0, mmap[13];
+        for (auto &v : ymap) if (v == 0) v = nyr++;
+        for (int m = 1; m <= 12; ++m) mmap[m] = mhas[m] ? nmth++ : -1;
+        const int ng = nyr * nmth;
+        std::vector<int32_t> gs((size_t)ng + 1, 0), gd((size_t)ndays);
+        for (int64_t d = 0; d < ndays; ++d) gs[(size_t)ymap[day_year[d] - ya] * nmth + mmap[day_month[d]] + 1]++;
+        for (int g = 0; g < ng; ++g) gs[g + 1] += gs[g];
+        std::vector<int32_t> fillp(gs.begin(), gs.end() - 1);
+        for (int64_t d = 0; d < ndays; ++d) gd[fillp[(size_t)ymap[day_year[d] - ya] * nmth + mmap[day_month[d]]]++] = (int32_t)d;
+        HIPCHK(ctx->agg_dev.ensure(((size_t)ng + 1 + ndays) * 4 + 1024));
+        char *ac = ctx->agg_dev.as<char>();
+        int32_t *d_gs = carve<int32_t>(ac, (size_t)ng + 1), *d_gd = carve<int32_t>(ac, ndays);
+        HIPCHK(hipMemcpy(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_gd, gd.data(), gd.size() * 4, hipMemcpyHostToDevice));
+        ctx->agg.ng = ng; ctx->agg.nyr = nyr; ctx->agg.nmth = nmth; ctx->agg.gstart = d_gs; ctx->agg.gday = d_gd;
+    }
     return 0;
 }
 
@@ -727,6 +758,70 @@ int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out)
     HIPCHK(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dx, n, dout);
     HIPCHK(hipMemcpy(out, dout, n * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- monthly / annual aggregation ------------------------------------------
+int twx_aggregate_dims(twx_ctx *ctx, int32_t *nyr, int32_t *nmth)
+{
+    if (!ctx) return -1;
+    if (ctx->ndays <= 0) return fail(ctx, "twx_aggregate_dims: call twx_set_days first");
+    if (nyr) *nyr = ctx->agg.nyr;
+    if (nmth) *nmth = ctx->agg.nmth;
+    return 0;
+}
+
+int twx_aggregate(twx_ctx *ctx, const void *daily, int dtype, int64_t ncell, int on_device, double *mthly,
+                  int16_t *mthly_i16, double *ann, void *hip_stream, float *kernel_ms)
+{
+    if (!ctx) return -1;
+    if (!daily || ncell <= 0 || dtype < TWX_DT_I16 || dtype > TWX_DT_F64 || (!mthly && !mthly_i16 && !ann))
+        return fail(ctx, "twx_aggregate: bad arguments");
+    if (ctx->ndays <= 0) return fail(ctx, "twx_aggregate: call twx_set_days first");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const size_t esz = dtype == TWX_DT_I16 ? 2 : dtype == TWX_DT_F32 ? 4 : 8;
+    const size_t nd = (size_t)ctx->ndays, nc = (size_t)ncell, ng = (size_t)ctx->agg.ng, ny = (size_t)ctx->agg.nyr;
+    const void *d_in = daily;
+    double *d_m = mthly, *d_a = ann;
+    int16_t *d_i = mthly_i16;
+    if (!on_device) {
+        HIPCHK(ctx->agg_in.ensure(nd * nc * esz));
+        HIPCHK(ctx->agg_out.ensure(ng * nc * 10 + ny * nc * 8 + 1024));
+        HIPCHK(hipMemcpyAsync(ctx->agg_in.p, daily, nd * nc * esz, hipMemcpyHostToDevice, stream));
+        d_in = ctx->agg_in.p;
+        char *cur = ctx->agg_out.as<char>();
+        d_m = mthly ? carve<double>(cur, ng * nc) : nullptr;
+        d_a = ann ? carve<double>(cur, ny * nc) : nullptr;
+        d_i = mthly_i16 ? carve<int16_t>(cur, ng * nc) : nullptr;
+    }
+    if (!ctx->ev_agg_a) { HIPCHK(hipEventCreate(&ctx->ev_agg_a)); HIPCHK(hipEventCreate(&ctx->ev_agg_b)); }
+    // widest vector whose loads stay aligned for every day row
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_in);
+    HIPCHK(hipEventRecord(ctx->ev_agg_a, stream));
+    if (dtype == TWX_DT_I16) {
+        if (ncell % 8 == 0 && addr % 16 == 0) launch_agg<int16_t, 8>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+        else if (ncell % 4 == 0 && addr % 8 == 0) launch_agg<int16_t, 4>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+        else launch_agg<int16_t, 1>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+    } else if (dtype == TWX_DT_F32) {
+        if (ncell % 4 == 0 && addr % 16 == 0) launch_agg<float, 4>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+        else launch_agg<float, 1>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+    } else {
+        if (ncell % 2 == 0 && addr % 16 == 0) launch_agg<double, 2>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+        else launch_agg<double, 1>(d_in, ncell, ctx->agg, d_m, d_i, d_a, stream);
+    }
+    HIPCHK(hipEventRecord(ctx->ev_agg_b, stream));
+    HIPCHK(hipGetLastError());
+    if (!on_device) {
+        if (mthly) HIPCHK(hipMemcpyAsync(mthly, d_m, ng * nc * 8, hipMemcpyDeviceToHost, stream));
+        if (ann) HIPCHK(hipMemcpyAsync(ann, d_a, ny * nc * 8, hipMemcpyDeviceToHost, stream));
+        if (mthly_i16) HIPCHK(hipMemcpyAsync(mthly_i16, d_i, ng * nc * 2, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    if (kernel_ms) {
+        HIPCHK(hipEventSynchronize(ctx->ev_agg_b));
+        HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev_agg_a, ctx->ev_agg_b));
+    }
     return 0;
 }
 

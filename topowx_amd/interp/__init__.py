@@ -9,7 +9,9 @@ from .interp_tair import (BuildKrigParams, GwrTairAnom, InterpTair, KrigTair, Kr
 from .optimize import (StationKrigParams, XvalTairAnom, XvalTairNorm, XvalTairOverall,  # noqa: F401
                        build_nstn_bandwidths)
 from .tiling import Tiler, TileGridInfo  # noqa: F401
+from .aggregate import TairAggregate, TileMosaic, mthly_from_daily  # noqa: F401
 
 __all__ = ["StationSelect", "KrigTair", "KrigTairAll", "BuildKrigParams", "GwrTairAnom", "InterpTair",
            "PtInterpTair", "StationDataWrkChk", "build_empty_pt", "tmin_tmax_fixer", "XvalTairOverall",
-           "XvalTairAnom", "XvalTairNorm", "StationKrigParams", "build_nstn_bandwidths", "Tiler", "TileGridInfo"]
+           "XvalTairAnom", "XvalTairNorm", "StationKrigParams", "build_nstn_bandwidths", "Tiler", "TileGridInfo",
+           "TairAggregate", "TileMosaic", "mthly_from_daily"]

@@ -2,7 +2,7 @@
 
 In-memory counterpart of the reference's ``Tiler``: cuts the grid into tiles and
 work chunks and yields the f8[5+N, Y, X] work chunk in the reference's plane order.
-netCDF tile writing / mosaicking is out of scope.
+netCDF tile writing is SURVEY.md 8f-2; mosaicking / aggregation live in ``aggregate.py`` (8f-3).
 """
 import numpy as np
 
