@@ -231,6 +231,23 @@ int twx_aggregate_dims(twx_ctx *ctx, int32_t *nyr, int32_t *nmth);
 int twx_aggregate(twx_ctx *ctx, const void *daily, int dtype, int64_t ncell, int on_device,
                   double *mthly, int16_t *mthly_i16, double *ann, void *hip_stream, float *kernel_ms);
 
+/* ---- point-mode predictor sampling -----------------------------------------
+ * Replaces PredictorGrids.setPtValues (twx/interp/interp_tair.py:115-141) behind
+ * PtInterpTair.interp_to_lonlat (:513-524).  order 0: the raster cell of GeoNc.get_row_col
+ * (twx/utils/util_ncdf.py:292-301); status 1 where the reference raises IndexError (cell outside
+ * the raster).  order 1: bilinear (mpl_toolkits.basemap.interp order=1, masked), else nearest, else
+ * `missing`; row / col are -1. */
+typedef struct {
+    int32_t nrows, ncols;
+    const double *lon; /* [ncols] cell-centre longitudes, ascending */
+    const double *lat; /* [nrows] cell-centre latitudes, descending (north-up) */
+    const float *data; /* [nrows][ncols], NaN = missing */
+} twx_raster;
+
+int twx_sample_points(twx_ctx *ctx, const twx_raster *raster, int64_t npts, const double *lon,
+                      const double *lat, int order, double missing, double *val, int32_t *row,
+                      int32_t *col, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -330,3 +330,22 @@ def pack_mthly_i16(x):
     out = np.empty(x.shape, np.int16)
     lib().orc_pack_mthly_i16(_ptr(x, _dp), C.c_int64(x.size), out.ctypes.data_as(C.POINTER(C.c_int16)))
     return out
+
+
+# ---- second tier (8f-4): point-mode predictor sampling --------------------------------------------
+def sample_points(lons, lats, data, lon, lat, order=0, missing=-9999.0):
+    """Raster [nrows, ncols] north-up f4 (NaN = missing) sampled at the points; returns
+    (val, row, col, status)."""
+    lons, lats = np.ascontiguousarray(lons, np.float64), np.ascontiguousarray(lats, np.float64)
+    data = np.ascontiguousarray(data, np.float32)
+    lon, lat = np.atleast_1d(np.asarray(lon, np.float64)), np.atleast_1d(np.asarray(lat, np.float64))
+    n = lon.size
+    val, row, col, st = np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    L = lib()
+    v, r, c = C.c_double(), C.c_int32(), C.c_int32()
+    for i in range(n):
+        st[i] = L.orc_sample_point(C.c_int(lats.size), C.c_int(lons.size), _ptr(lons, _dp), _ptr(lats, _dp),
+                                   _ptr(data, _fp), C.c_double(lon[i]), C.c_double(lat[i]), C.c_int(order),
+                                   C.c_double(missing), C.byref(v), C.byref(r), C.byref(c))
+        val[i], row[i], col[i] = v.value, r.value, c.value
+    return val, row, col, st

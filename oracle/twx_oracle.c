@@ -1033,3 +1033,71 @@ void orc_pack_mthly_i16(const double *x, int64_t n, int16_t *out)
         out[i] = (int16_t)nearbyint(r / scale);
     }
 }
+
+/* ------------------------------------------------ second tier: 8f-4 ---- */
+/* GeoNc.get_row_col (util_ncdf.py:262-301): GDAL-style geotransform from the first two cell
+ * centres, int() truncation, abs().  Returns 1 when the cell is outside the raster (the reference
+ * then raises IndexError at var[row, col], interp_tair.py:122). */
+int orc_get_row_col(int nrows, int ncols, const double *lons, const double *lats, double lon, double lat,
+                    int32_t *row, int32_t *col)
+{
+    const double ph = -fabs(lats[0] - lats[1]), pw = fabs(lons[0] - lons[1]);
+    const double ox = lons[0] - pw / 2.0, oy = lats[0] + fabs(ph / 2.0);
+    const double fc = (lon - ox) / pw, fr = (lat - oy) / ph;
+    if (!(fabs(fc) < 2147483648.0) || !(fabs(fr) < 2147483648.0)) return 1;
+    int64_t c = (int64_t)fc, r = (int64_t)fr;
+    if (c < 0) c = -c;
+    if (r < 0) r = -r;
+    *row = (int32_t)r; *col = (int32_t)c;
+    return (r >= nrows || c >= ncols) ? 1 : 0;
+}
+
+/* PredictorGrids.setPtValues (interp_tair.py:115-141).  order 0: the cell of get_row_col.  order 1:
+ * mpl_toolkits.basemap.interp(order=1, masked=True) on the south-up copy of the raster, falling back to
+ * its order=0 (nearest) and then to the missing value.  basemap is a third-party dependency that is not
+ * vendored: its published algorithm is restated (PARITY UNPINNED for order 1).  data: [nrows][ncols]
+ * north-up f4, NaN = missing; lats descending.  Returns 0 ok, 1 outside (order 0 only). */
+static double bm_coord(double g0, double g1, int n, double v)
+{
+    /* regular axis: (len-1) * (out - in[0]) / (in[-1] - in[0]) */
+    return (double)(n - 1) * (v - g0) / (g1 - g0);
+}
+
+int orc_sample_point(int nrows, int ncols, const double *lons, const double *lats, const float *data,
+                     double lon, double lat, int order, double missing, double *val, int32_t *row, int32_t *col)
+{
+    if (order == 0) {
+        int rc = orc_get_row_col(nrows, ncols, lons, lats, lon, lat, row, col);
+        if (rc) return rc;
+        *val = (double)data[(int64_t)(*row) * ncols + *col];
+        return 0;
+    }
+    /* yGrid = np.sort(lat) (ascending), ncData = flipud(a): row i of the flipped copy = nrows-1-i */
+    const double ylo = lats[nrows - 1], yhi = lats[0];
+    const int outside = (lon < lons[0]) || (lon > lons[ncols - 1]) || (lat < ylo) || (lat > yhi);
+    double xc = bm_coord(lons[0], lons[ncols - 1], ncols, lon);
+    double yc = bm_coord(ylo, yhi, nrows, lat);
+    if (xc < 0) xc = 0;
+    if (xc > ncols - 1) xc = ncols - 1;
+    if (yc < 0) yc = 0;
+    if (yc > nrows - 1) yc = nrows - 1;
+    *row = -1; *col = -1;
+    if (!outside) {
+        int xi = (int)xc, yi = (int)yc;
+        int xip = xi + 1 > ncols - 1 ? ncols - 1 : xi + 1, yip = yi + 1 > nrows - 1 ? nrows - 1 : yi + 1;
+        const double dx = xc - (double)(float)xi, dy = yc - (double)(float)yi;
+#define FL(yy, xx) ((double)data[(int64_t)(nrows - 1 - (yy)) * ncols + (xx)])
+        const double a = FL(yi, xi), b = FL(yip, xip), c = FL(yip, xi), d = FL(yi, xip);
+        if (!isnan(a) && !isnan(b) && !isnan(c) && !isnan(d)) {
+            *val = (1. - dx) * (1. - dy) * a + dx * dy * b + (1. - dx) * dy * c + dx * (1. - dy) * d;
+            return 0;
+        }
+        /* order 0: np.around (half to even) */
+        const int xn = (int)nearbyint(xc), yn = (int)nearbyint(yc);
+        const double v = FL(yn, xn);
+#undef FL
+        if (!isnan(v)) { *val = v; return 0; }
+    }
+    *val = missing;
+    return 0;
+}

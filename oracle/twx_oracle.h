@@ -175,6 +175,16 @@ void orc_daily_to_mthly(const void *daily, int dtype, int64_t ndays, int64_t nce
 void orc_mthly_to_ann(const double *mthly, int nyr, int nmth, int64_t ncell, double *ann);
 void orc_pack_mthly_i16(const double *x, int64_t n, int16_t *out);
 
+/* ---- second tier: point-mode predictor sampling -----------------------------
+ * GeoNc.get_row_col (util_ncdf.py:262-301; PINNED against the executed slice) and
+ * PredictorGrids.setPtValues (interp_tair.py:115-141; order 1 goes through mpl_toolkits.basemap.interp,
+ * not vendored: restated, PARITY UNPINNED). */
+int orc_get_row_col(int nrows, int ncols, const double *lons, const double *lats, double lon, double lat,
+                    int32_t *row, int32_t *col);
+int orc_sample_point(int nrows, int ncols, const double *lons, const double *lats, const float *data,
+                     double lon, double lat, int order, double missing, double *val, int32_t *row,
+                     int32_t *col);
+
 #ifdef __cplusplus
 }
 #endif

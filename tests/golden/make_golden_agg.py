@@ -7,6 +7,7 @@ reference's own source slices.  Build container only (needs /root/reference):
 Slices executed (reference file:lines), read from /root/reference at run time, nothing stored:
   twx/utils/util_dates.py:19-203     date / month metadata helpers
   twx/interp/tiling.py:1080-1166     _TairAggregate (daily_to_mthly, daily_to_ann, mthly_to_ann)
+  twx/utils/util_ncdf.py:260-301     GeoNc (geotransform, get_row_col) -> golden_sample_v1.npz (8f-4)
 
 What the slices cannot cover is netCDF4-python (not installed): write_ds_mthly (tiling.py:1169-1219)
 reads the daily variable through its auto mask-and-scale (int16 * float32(0.01), _FillValue masked)
@@ -80,6 +81,44 @@ def case_inputs(name):
     return d0, d1, raw
 
 
+class _FakeDs(object):
+    """Stands in for a netCDF4 Dataset holding 1-D lon / lat variables."""
+
+    def __init__(self, lon, lat):
+        self.variables = {"lon": lon.copy(), "lat": lat.copy()}
+
+
+def sample_inputs():
+    """Raster axes (north-up) and query points, some exactly on cell edges / centres."""
+    rng = np.random.default_rng(21)
+    lon = -110.0 + (np.arange(40) + 0.5) * (1.0 / 120.0)
+    lat = 45.0 - (np.arange(30) + 0.5) * (1.0 / 120.0)
+    qlon = rng.uniform(lon[0] - 0.02, lon[-1] + 0.02, 300)
+    qlat = rng.uniform(lat[-1] - 0.02, lat[0] + 0.02, 300)
+    qlon[:40], qlat[:40] = lon, lat[:30].repeat(2)[:40]                 # cell centres
+    qlon[40:60] = lon[:20] + 0.5 / 120.0                                 # cell edges
+    qlat[60:80] = lat[:20] - 0.5 / 120.0
+    return lon, lat, qlon, qlat
+
+
+def make_sample_golden():
+    src = {"np": np}
+    exec(compile(_slice("twx/utils/util_ncdf.py", 260, 301), "util_ncdf", "exec"), src)
+    lon, lat, qlon, qlat = sample_inputs()
+    geo = src["GeoNc"](_FakeDs(lon, lat))
+    rows, cols, glon, glat = [], [], [], []
+    for x, y in zip(qlon, qlat):
+        try:
+            row, col, gx, gy = geo.get_row_col(x, y)
+        except IndexError:                       # lons[col] / lats[row] outside the raster
+            row, col, gx, gy = -1, -1, np.nan, np.nan
+        rows.append(row); cols.append(col); glon.append(gx); glat.append(gy)
+    np.savez_compressed(os.path.join(HERE, "golden_sample_v1.npz"), lon=lon, lat=lat, qlon=qlon, qlat=qlat,
+                        row=np.array(rows, np.int32), col=np.array(cols, np.int32), glon=np.array(glon),
+                        glat=np.array(glat))
+    print("sample", len(rows), "points;", int(np.isnan(glon).sum()), "outside")
+
+
 def input_hash(raw):
     return hashlib.sha256(np.ascontiguousarray(raw).tobytes()).hexdigest()
 
@@ -108,6 +147,7 @@ def main():
         out[name + "_mthly_f8"] = np.ma.filled(m8.astype(np.float64), np.nan)
         print(name, raw.shape, "groups", mthly.shape[0], "years", ann.shape[0])
     np.savez_compressed(os.path.join(HERE, "golden_agg_v1.npz"), **out)
+    make_sample_golden()
 
 
 if __name__ == "__main__":

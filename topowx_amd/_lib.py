@@ -69,6 +69,11 @@ class TwxGridOut(C.Structure):
                 ("ninvalid", C.c_void_p), ("status", C.c_void_p)]
 
 
+class TwxRaster(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("ncols", C.c_int32), ("lon", C.POINTER(C.c_double)),
+                ("lat", C.POINTER(C.c_double)), ("data", C.POINTER(C.c_float))]
+
+
 class TwxTiming(C.Structure):
     _fields_ = [("tile_cand_ms", C.c_float), ("select_ms", C.c_float), ("uk_ms", C.c_float),
                 ("gwr_ms", C.c_float), ("daily_ms", C.c_float), ("fix_ms", C.c_float),
@@ -79,7 +84,7 @@ class TwxTiming(C.Structure):
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
-           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate")
+           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points")
 
 _LIB = None
 
@@ -340,6 +345,23 @@ class Context(object):
             C.cast(C.c_void_p(mthly_ptr), _dp), C.cast(C.c_void_p(mthly_i16_ptr), _sp),
             C.cast(C.c_void_p(ann_ptr), _dp), C.c_void_p(stream), C.byref(ms) if timed else None), "twx_aggregate")
         return ms.value if timed else None
+
+    # ---- point-mode predictor sampling --------------------------------------
+    def sample_points(self, lons, lats, data, lon, lat, order=0, missing=-9999.0):
+        """Raster [nrows, ncols] (north-up, NaN = missing) at the points -> (val, row, col, status)."""
+        lons, lats = np.ascontiguousarray(lons, np.float64), np.ascontiguousarray(lats, np.float64)
+        data = np.ascontiguousarray(data, np.float32)
+        if data.shape != (lats.size, lons.size):
+            raise ValueError("sample_points: data must be [lat, lon]")
+        lon = np.ascontiguousarray(np.atleast_1d(lon), np.float64)
+        lat = np.ascontiguousarray(np.atleast_1d(lat), np.float64)
+        n = lon.size
+        r = TwxRaster(lats.size, lons.size, _p(lons, _dp), _p(lats, _dp), _p(data, _fp))
+        val, row, col, st = np.empty(n), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+        self._chk(self.lib.twx_sample_points(self.h, C.byref(r), C.c_int64(n), _p(lon, _dp), _p(lat, _dp),
+                                             C.c_int(order), C.c_double(missing), _p(val, _dp), _p(row, _ip),
+                                             _p(col, _ip), _p(st, _ip)), "twx_sample_points")
+        return val, row, col, st
 
     # ---- grid entries ------------------------------------------------------------------
     @staticmethod

@@ -20,6 +20,7 @@
 #include "twx_uk1.h"
 #include "twx_vario.h"
 #include "twx_agg.h"
+#include "twx_sample.h"
 
 namespace {
 
@@ -822,6 +823,41 @@ int twx_aggregate(twx_ctx *ctx, const void *daily, int dtype, int64_t ncell, int
         HIPCHK(hipEventSynchronize(ctx->ev_agg_b));
         HIPCHK(hipEventElapsedTime(kernel_ms, ctx->ev_agg_a, ctx->ev_agg_b));
     }
+    return 0;
+}
+
+// ---- point-mode predictor sampling ------------------------------------------
+int twx_sample_points(twx_ctx *ctx, const twx_raster *r, int64_t npts, const double *lon, const double *lat,
+                      int order, double missing, double *val, int32_t *row, int32_t *col, int32_t *status)
+{
+    if (!ctx) return -1;
+    if (!r || r->nrows < 2 || r->ncols < 2 || !r->lon || !r->lat || !r->data || npts <= 0 || !lon || !lat || !val ||
+        order < 0 || order > 1)
+        return fail(ctx, "twx_sample_points: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nr = (size_t)r->nrows, nc = (size_t)r->ncols, n = (size_t)npts;
+    HIPCHK(ctx->agg_in.ensure((nr + nc) * 8 + nr * nc * 4 + n * 16 + 2048));
+    HIPCHK(ctx->agg_out.ensure(n * 20 + 2048));
+    char *cur = ctx->agg_in.as<char>();
+    double *d_lon = carve<double>(cur, nc), *d_lat = carve<double>(cur, nr);
+    float *d_data = carve<float>(cur, nr * nc);
+    double *d_qx = carve<double>(cur, n), *d_qy = carve<double>(cur, n);
+    char *oc = ctx->agg_out.as<char>();
+    double *d_val = carve<double>(oc, n);
+    int32_t *d_row = carve<int32_t>(oc, n), *d_col = carve<int32_t>(oc, n), *d_st = carve<int32_t>(oc, n);
+    HIPCHK(hipMemcpy(d_lon, r->lon, nc * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_lat, r->lat, nr * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_data, r->data, nr * nc * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_qx, lon, n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_qy, lat, n * 8, hipMemcpyHostToDevice));
+    RasterDev rd{r->nrows, r->ncols, d_lon, d_lat, d_data};
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, rd, npts, d_qx, d_qy,
+                       order, missing, d_val, d_row, d_col, d_st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(val, d_val, n * 8, hipMemcpyDeviceToHost));
+    if (row) HIPCHK(hipMemcpy(row, d_row, n * 4, hipMemcpyDeviceToHost));
+    if (col) HIPCHK(hipMemcpy(col, d_col, n * 4, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, d_st, n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -108,6 +108,69 @@ class InterpTair(object):
         return daily[0], norms[0], se[0]
 
 
+class PredictorGrids(object):
+    """Predictor rasters sampled at a point (interp_tair.py:87-141).
+
+    ``rasters``: ordered mapping ``a_pt field -> dict(lon=[ncols], lat=[nrows] north-up, data=[nrows, ncols],
+    missing_value=...)`` -- the array-level stand-in for the reference's one-variable netCDF files (the
+    file reader is SURVEY.md 8f-2).  ``interp_orders[i] == 1`` marks rasters that are interpolated
+    bilinearly when the point is not snapped to the grid."""
+
+    def __init__(self, rasters, interp_orders=None, ctx=None, device=0):
+        self.rasters = dict(rasters)
+        orders = np.zeros(len(self.rasters)) if interp_orders is None else interp_orders
+        self.orders = {k: int(o) for k, o in zip(self.rasters, orders)}
+        self._own = ctx is None
+        self.ctx = _lib.Context(device) if ctx is None else ctx
+        self._f4 = {}
+        for k, r in self.rasters.items():
+            d = np.ma.filled(np.ma.masked_invalid(np.ma.asarray(r["data"], dtype=np.float64)), np.nan)
+            if r.get("missing_value") is not None:
+                d = np.where(d == r["missing_value"], np.nan, d)
+            self._f4[k] = d.astype(np.float32)
+
+    def close(self):
+        if self._own:
+            self.ctx.close()
+
+    def _sample(self, name, lon, lat, order):
+        r = self.rasters[name]
+        lons = np.asarray(r["lon"], np.float64)
+        lons = np.where(lons > 180, lons - 360.0, lons)                  # util_ncdf.py:266-268
+        miss = r.get("missing_value")
+        return self.ctx.sample_points(lons, r["lat"], self._f4[name], lon, lat, order=order,
+                                      missing=np.nan if miss is None else float(miss)), lons
+
+    def setPtValues(self, aPt, chgLatLon=True):
+        chged = False
+        for name in self.rasters:
+            if chgLatLon or self.orders[name] != 1:
+                (val, row, col, st), lons = self._sample(name, aPt[LON], aPt[LAT], 0)
+                if st[0] != 0:
+                    raise IndexError("point (%r, %r) is outside raster %r" % (aPt[LON], aPt[LAT], name))
+                v = val[0]
+                if np.isnan(v) and self.rasters[name].get("missing_value") is not None:
+                    v = self.rasters[name]["missing_value"]
+                aPt[name] = v
+                if chgLatLon and not chged:
+                    aPt[LON] = lons[col[0]]
+                    aPt[LAT] = np.asarray(self.rasters[name]["lat"], np.float64)[row[0]]
+                    chged = True
+            else:
+                (val, _, _, _), _ = self._sample(name, aPt[LON], aPt[LAT], 1)
+                aPt[name] = val[0]
+
+    def sample(self, lon, lat, order_override=None):
+        """Batched form: every raster at all points -> dict of arrays (status 1 = outside, order 0)."""
+        out = {}
+        for name in self.rasters:
+            order = self.orders[name] if order_override is None else order_override
+            (val, row, col, st), _ = self._sample(name, lon, lat, order)
+            out[name] = val
+            out[name + "_status"] = st
+        return out
+
+
 class PtInterpTair(object):
     """Tmin and Tmax at a point / over a work chunk (interp_tair.py:441-592).
 
@@ -119,8 +182,6 @@ class PtInterpTair(object):
 
     def __init__(self, stn_da_tmin, stn_da_tmax, aux_fpaths=None, interp_orders=None, norms_only=False,
                  device=0):
-        if aux_fpaths is not None:
-            raise NotImplementedError("point-mode predictor sampling is out of scope (SURVEY.md 8f-4)")
         self.days = stn_da_tmin.days
         self.stn_da_tmin = stn_da_tmin
         self.stn_da_tmax = stn_da_tmax
@@ -132,7 +193,20 @@ class PtInterpTair(object):
         slct_x = StationSelect(stn_da_tmax, np.isnan(stn_da_tmax.stns[BAD]), ctx=self.ctx, var=_lib.TMAX)
         self.interp_tmin = InterpTair(KrigTair(slct_n), GwrTairAnom(slct_n))
         self.interp_tmax = InterpTair(KrigTair(slct_x), GwrTairAnom(slct_x))
+        if aux_fpaths is not None:          # here: the raster mapping PredictorGrids takes (interp_tair.py:507-508)
+            self.pGrids = PredictorGrids(aux_fpaths, interp_orders, ctx=self.ctx)
         self.a_pt = build_empty_pt()
+
+    def interp_to_lonlat(self, lon, lat, fixInvalid=True, chgLatLon=True, stns_rm=None, elev=None):
+        """interp_tair.py:513-524: sample the predictor rasters at (lon, lat), then ``interp_pt``."""
+        self.a_pt[LON] = lon
+        self.a_pt[LAT] = lat
+        self.pGrids.setPtValues(self.a_pt, chgLatLon)
+        if elev is not None:
+            self.a_pt[ELEV] = elev
+        if self.a_pt[MASK] == 0:
+            raise Exception('Point is outside interpolation region')
+        return self.interp_pt(fixInvalid, stns_rm)
 
     def interp_pt(self, fix_invalid=True, stns_rm=None):
         pt = self.a_pt
