@@ -165,3 +165,36 @@ def test_step25_chunk_loop_equals_whole_grid(case):
         a = stores[tile_id].a
         for k in ("norm_tmin", "se_tmax", "daily_tmin", "daily_tmax", "ninvalid", "status"):
             assert np.array_equal(a[k], whole[k][..., i:i + 20, j:j + 20]), (tile_id, k)
+
+
+def test_step25_to_netcdf_tiles_to_monthly(case, tmp_path):
+    """step25 -> netCDF tiles (8f-2) -> daily mosaic -> monthly product (8f-3), end to end."""
+    from topowx_amd import _lib, ncio, step25
+    from topowx_amd.interp import TairAggregate, TileMosaic, Tiler
+    grid, tmin, tmax = case
+    sub = {k: (v[:20, :40] if k in ("mask", "elev", "tdi", "climdiv") else v) for k, v in grid.items()}
+    sub["lat"], sub["lon"] = grid["lat"][:20], grid["lon"][:40]
+    sub["lst_night"], sub["lst_day"] = grid["lst_night"][:, :20, :40], grid["lst_day"][:, :20, :40]
+    stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=str(tmp_path),
+                              out_format="nc")
+    tiles = sorted(stores)
+    assert tiles == ["h00v00", "h01v00"]
+    back = ncio.read_tile_stores(str(tmp_path), tiles)
+    for t in tiles:
+        for k in ("daily_tmin", "daily_tmax", "norm_tmin", "se_tmax", "ninvalid"):
+            np.testing.assert_array_equal(back[t].a[k], stores[t].a[k])
+    info = Tiler(sub, 20, 20, 10, 10).build_tile_grid_info()
+    mos = TileMosaic(info)
+    dly = mos.create_dly_mosaic(tiles, "tmin", back)
+    assert dly.shape == (tmin.days.size, 20, 40)
+    agg = TairAggregate(tmin.days)
+    m16 = agg.daily_i16_to_mthly_i16(dly)
+    # numpy restatement of write_ds_mthly on the same cube
+    tair = np.ma.masked_array(dly * np.float32(0.01), mask=dly == _lib.FILL_I2)
+    yrs, mths = np.unique(tmin.days.YEAR), np.unique(tmin.days.MONTH)
+    want = np.ma.array([np.ma.mean(tair[(tmin.days.YEAR == y) & (tmin.days.MONTH == m)], axis=0, dtype=float)
+                        for y in yrs for m in mths])
+    want = np.around(np.ma.getdata(np.ma.round(want, 2)) / np.float32(0.01))
+    want = np.where(np.ma.getmaskarray(tair).all(axis=0)[None], _lib.FILL_I2, want).astype(np.int16)
+    np.testing.assert_array_equal(m16, want)
+    agg.close()

@@ -1,0 +1,100 @@
+"""netCDF containers on scipy's NetCDF-3 writer: tile files in the layout of
+``TileWriter`` (tiling.py:304-537) and the station DB layout ``StationSerialDataDb`` reads
+(station_data.py:547-616).  CPU only."""
+import datetime as dt
+
+import numpy as np
+from scipy.io import netcdf_file
+
+from topowx_amd import ncio, synth
+from topowx_amd import stationdb as sdb
+from topowx_amd.dates import get_days_metadata
+from topowx_amd.interp import TileGridInfo, TileMosaic
+
+
+def _info():
+    lons = -110.0 + (np.arange(12) + 0.5) / 120.0
+    lats = 45.0 - (np.arange(8) + 0.5) / 120.0
+    return TileGridInfo({0: "h00v00", 1: "h01v00"}, {"h00v00": (0, 0), "h01v00": (0, 6)}, 2, lons, lats, 8, 6, 4, 3, 32)
+
+
+def test_tile_writer_roundtrip(tmp_path):
+    info = _info()
+    days = get_days_metadata(dt.date(1999, 12, 30), dt.date(2000, 1, 8))
+    w = ncio.TileWriter(info, str(tmp_path))
+    rng = np.random.default_rng(0)
+    blocks = {}
+    for (r, c) in ((0, 0), (4, 3)):                               # two of the four chunks of the tile
+        b = dict(d=rng.integers(-3000, 3000, (days.size, 4, 3)).astype(np.int16),
+                 n=rng.normal(5, 8, (12, 4, 3)).astype(np.float32), s=rng.random((12, 4, 3)).astype(np.float32),
+                 i=rng.integers(0, 5, (4, 3)).astype(np.int32))
+        w.write_tile_chunk("h01v00", "tmin", days, r, c, b["d"], b["n"], b["s"], b["i"])
+        blocks[(r, c)] = b
+    t = ncio.read_tile(w.fpath("h01v00", "tmin"), "tmin")
+    assert t["daily"].shape == (days.size, 8, 6) and t["daily"].dtype == np.int16
+    for (r, c), b in blocks.items():
+        np.testing.assert_array_equal(t["daily"][:, r:r + 4, c:c + 3], b["d"])
+        np.testing.assert_array_equal(t["norm"][:, r:r + 4, c:c + 3], b["n"])
+        np.testing.assert_array_equal(t["se"][:, r:r + 4, c:c + 3], b["s"])
+        np.testing.assert_array_equal(t["ninvalid"][r:r + 4, c:c + 3], b["i"])
+    assert (t["daily"][:, 0:4, 3:6] == ncio.FILL_I2).all() and (t["ninvalid"][4:8, 0:3] == ncio.FILL_I4).all()
+    assert (t["norm"][:, 4:8, 0:3] == ncio.FILL_F4).all()
+    np.testing.assert_array_equal(t["lon"], info.lons[6:12])
+    np.testing.assert_array_equal(t["lat"], info.lats[0:8])
+    assert t["time_units"] == "days since 1999-12-30 0:0:0"
+    np.testing.assert_array_equal(t["time"], np.arange(days.size) + 0.5)
+    ds = netcdf_file(w.fpath("h01v00", "tmin"), "r", mmap=False)
+    v = ds.variables["tmin"]
+    assert v.dimensions == ("time", "lat", "lon") and v.scale_factor.dtype == np.float32
+    assert np.float32(v.scale_factor) == np.float32(0.01) and np.int16(v._FillValue) == -32767
+    assert v.grid_mapping == b"crs" and ds.variables["crs"].grid_mapping_name == b"latitude_longitude"
+    assert ds.variables["tmin_normal"].dimensions == ("time_normals", "lat", "lon")
+    assert ds.variables["climatology_bounds"].shape == (12, 2) and ds.Conventions == b"CF-1.6"
+    # 1981-01-01 .. 2010-02-01 relative to the first day (tiling.py:412-420)
+    cb = ds.variables["climatology_bounds"][:]
+    assert cb[0, 0] == (dt.date(1981, 1, 1) - dt.date(1999, 12, 30)).days
+    assert cb[11, 1] == (dt.date(2011, 1, 1) - dt.date(1999, 12, 30)).days
+    ds.close()
+
+
+def test_tiles_to_daily_mosaic(tmp_path):
+    info = _info()
+    days = get_days_metadata(dt.date(2001, 1, 1), dt.date(2001, 1, 5))
+    w = ncio.TileWriter(info, str(tmp_path))
+    rng = np.random.default_rng(1)
+    full = {}
+    for t in ("h00v00", "h01v00"):
+        for v in ("tmin", "tmax"):
+            d = rng.integers(-3000, 3000, (days.size, 8, 6)).astype(np.int16)
+            for r in (0, 4):
+                for c in (0, 3):
+                    w.write_tile_chunk(t, v, days, r, c, d[:, r:r + 4, c:c + 3], np.zeros((12, 4, 3)), np.zeros((12, 4, 3)),
+                                       np.zeros((4, 3)))
+            full[(t, v)] = d
+    stores = ncio.read_tile_stores(str(tmp_path), ["h00v00", "h01v00", "h02v00"])
+    assert sorted(stores) == ["h00v00", "h01v00"]
+    mos = TileMosaic(info).create_dly_mosaic(["h00v00", "h01v00"], "tmax", stores)
+    np.testing.assert_array_equal(mos, np.concatenate([full[("h00v00", "tmax")], full[("h01v00", "tmax")]], axis=2))
+
+
+def test_station_db_roundtrip(tmp_path):
+    days = get_days_metadata(dt.date(1980, 1, 1), dt.date(1980, 3, 31))
+    grid = synth.make_grid("C1")
+    db = synth.make_stations(grid["bbox"], 60, 3, "tmin", days, with_obs=True)
+    p = str(tmp_path / "serial_tmin.nc")
+    ncio.write_station_db(p, db)
+    back = ncio.read_station_db(p, "tmin", cls=sdb.StationDataWrkChk)
+    assert isinstance(back, sdb.StationDataWrkChk) and back.var_name == "tmin"
+    np.testing.assert_array_equal(back.stn_ids, db.stn_ids)
+    np.testing.assert_array_equal(back.days.YMD, db.days.YMD)
+    for name in db.stns.dtype.names:
+        if name != sdb.STN_ID:
+            np.testing.assert_array_equal(back.stns[name], db.stns[name])       # NaN-aware, bit-exact f8
+    np.testing.assert_array_equal(back.var, db.var)
+    np.testing.assert_array_equal(back.load_obs(db.stn_ids[[3, 7]], mth=2), db.load_obs(db.stn_ids[[3, 7]], mth=2))
+    # the layout _build_stn_struct reads: (station_id,) columns and a (station_id, string*) char array
+    ds = netcdf_file(p, "r", mmap=False)
+    assert ds.variables[sdb.STN_ID].dimensions[0] == sdb.STN_ID
+    assert ds.variables[sdb.STN_ID].dimensions[1].startswith("string")
+    assert ds.variables["tmin"].dimensions == ("time", sdb.STN_ID)
+    ds.close()

@@ -1,0 +1,276 @@
+"""netCDF containers either side of the path.
+
+The reference reads its serially-complete station DB and writes its tiles through netCDF4-python
+(``twx/db/station_data.py:547-666``, ``twx/interp/tiling.py:304-537``).  netCDF4 / HDF5 are not available
+here; this module keeps the same dimensions, variables and CF attributes on **NetCDF-3 (64-bit offset)**
+through ``scipy.io.netcdf_file`` -- files netCDF4-python, GDAL and ncdump open as they are.  What the
+classic format cannot carry is dropped: zlib, chunking, variable-length strings (station ids are
+``char[station_id][string]`` arrays, the layout ``_build_stn_struct`` already accepts,
+station_data.py:134-157).  ``scipy.io.netcdf_file`` holds a file's variables in memory until it is
+closed, so a tile costs its size in RAM while it is written.
+"""
+import datetime as _dt
+import os
+
+import numpy as np
+from scipy.io import netcdf_file
+
+from . import stationdb as sdb
+from .dates import DAY, MONTH, YEAR, get_days_metadata
+
+__all__ = ["TileWriter", "read_tile", "write_station_db", "read_station_db", "read_tile_stores"]
+
+FILL_I2 = np.int16(-32767)
+FILL_F4 = np.float32(9.969209968386869e36)
+FILL_I4 = np.int32(-2147483647)
+SCALE_FACTOR = np.float32(0.01)                      # tiling.py:36
+# long name, units, standard name, cell method (tiling.py:39-42)
+VAR_ATTRS = {"tmin": ("minimum air temperature", "C", "air_temperature", "minimum"),
+             "tmax": ("maximum air temperature", "C", "air_temperature", "maximum")}
+
+
+def _date(days, i):
+    return _dt.date(int(days[YEAR][i]), int(days[MONTH][i]), int(days[DAY][i]))
+
+
+def _num(d, d0):
+    return float((d - d0).days)
+
+
+def _mid(a, b):
+    return a + _dt.timedelta(days=((b - a).days // 2))
+
+
+class TileWriter(object):
+    """``TileWriter`` (tiling.py:304-537): one file ``<path_out>/<tile_id>/<tile_id>_<varname>.nc`` per tile
+    and variable, created on the first chunk, reopened for every further chunk."""
+
+    def __init__(self, tile_grid_info, path_out):
+        t = tile_grid_info
+        self.tile_ids, self.tile_rc, self.ntiles = t.tile_ids, t.tile_rc, t.ntiles
+        self.lons, self.lats = np.asarray(t.lons, np.float64), np.asarray(t.lats, np.float64)
+        self.path_out = path_out
+        self.tile_size_y, self.tile_size_x = t.tile_size_y, t.tile_size_x
+        self.chk_size_y, self.chk_size_x = t.chk_size_y, t.chk_size_x
+
+    def fpath(self, tile_id, varname):
+        return os.path.join(self.path_out, tile_id, "%s_%s.nc" % (tile_id, varname))
+
+    def _create(self, fpath, tile_id, varname, days):
+        os.makedirs(os.path.dirname(fpath), exist_ok=True)
+        ds = netcdf_file(fpath, "w", version=2, mmap=False)
+        d0, d1 = _date(days, 0), _date(days, days.size - 1)
+        ds.title = "Daily Interpolated Meteorological Data %d-%d" % (
+            d0.year * 10000 + d0.month * 100 + d0.day, d1.year * 10000 + d1.month * 100 + d1.day)
+        ds.institution = "University of Montana"
+        ds.source = "topowx_amd (MI355X implementation of the TopoWx interpolation path)"
+        ds.history = "Created on: " + _dt.date.today().strftime("%Y-%m-%d")
+        ds.references = "http://www.ntsg.umt.edu/project/TopoWx"
+        ds.comment = "30-arcsec spatial resolution, daily timestep"
+        ds.Conventions = "CF-1.6"
+
+        str_row, str_col = self.tile_rc[tile_id]
+        lons = self.lons[str_col:str_col + self.tile_size_x]
+        lats = self.lats[str_row:str_row + self.tile_size_y]
+        ds.createDimension("time", int(days.size))
+        ds.createDimension("lat", int(lats.size))
+        ds.createDimension("lon", int(lons.size))
+        ds.createDimension("nv", 2)
+        ds.createDimension("time_normals", 12)
+
+        units = "days since %d-%d-%d 0:0:0" % (d0.year, d0.month, d0.day)
+        times = ds.createVariable("time", "d", ("time",))
+        times.long_name, times.units, times.standard_name = "time", units, "time"
+        times.calendar, times.bounds = "standard", "time_bnds"
+        nums = np.array([_num(_date(days, i), d0) for i in range(days.size)]) + 0.5
+        times[:] = nums
+        tb = ds.createVariable("time_bnds", "d", ("time", "nv"))
+        tb[:, 0], tb[:, 1] = nums - 0.5, nums + 0.5
+
+        tn = ds.createVariable("time_normals", "d", ("time_normals",))
+        tn.long_name, tn.units, tn.standard_name, tn.calendar = "time", units, "time", "standard"
+        tn.climatology = "climatology_bounds"
+        tn.comment = "Time dimension for the 1981-2010 monthly normals"
+        cb = ds.createVariable("climatology_bounds", "d", ("time_normals", "nv"))
+        for m in range(1, 13):                                            # tiling.py:412-420
+            mn, y1 = (m + 1, 1981) if m != 12 else (1, 1982)
+            tn[m - 1] = _num(_mid(_dt.date(1981, m, 1), _dt.date(y1, mn, 1)), d0)
+            cb[m - 1, 0] = _num(_dt.date(1981, m, 1), d0)
+            cb[m - 1, 1] = _num(_dt.date(2010 if m != 12 else 2011, mn, 1), d0)
+
+        la = ds.createVariable("lat", "d", ("lat",))
+        la.long_name, la.units, la.standard_name = "latitude", "degrees_north", "latitude"
+        la[:] = lats
+        lo = ds.createVariable("lon", "d", ("lon",))
+        lo.long_name, lo.units, lo.standard_name = "longitude", "degrees_east", "longitude"
+        lo[:] = lons
+
+        crs = ds.createVariable("crs", "h", ())                           # tiling.py:539-546
+        crs.grid_mapping_name = "latitude_longitude"
+        crs.longitude_of_prime_meridian = 0.0
+        crs.semi_major_axis = 6378137.0
+        crs.inverse_flattening = 298.257223563
+
+        long_name, vunits, std_name, cell_method = VAR_ATTRS[varname]
+
+        def gridded(v):
+            v.coordinates, v.grid_mapping = "lat lon", "crs"
+
+        mv = ds.createVariable(varname, "h", ("time", "lat", "lon"))
+        mv._FillValue = FILL_I2
+        mv.long_name, mv.units, mv.standard_name = long_name, vunits, std_name
+        mv.scale_factor = SCALE_FACTOR
+        mv.cell_methods = "area: mean time: " + cell_method
+        gridded(mv)
+        mv[:] = FILL_I2
+        nv = ds.createVariable(varname + "_normal", "f", ("time_normals", "lat", "lon"))
+        nv._FillValue = FILL_F4
+        nv.long_name, nv.units, nv.standard_name = "normal " + long_name, vunits, std_name
+        nv.ancillary_variables = varname + "_se"
+        nv.comment = "The 1981-2010 monthly normals"
+        nv.cell_methods = "time: %s within years time: mean over years" % cell_method
+        gridded(nv)
+        nv[:] = FILL_F4
+        sv = ds.createVariable(varname + "_se", "f", ("time_normals", "lat", "lon"))
+        sv._FillValue = FILL_F4
+        sv.long_name = long_name + " kriging standard error"
+        sv.standard_name, sv.units = "air_temperature standard_error", vunits
+        sv.comment = "The uncertainty in the 1981-2010 monthly normals"
+        gridded(sv)
+        sv[:] = FILL_F4
+        iv = ds.createVariable("inconsist_tair", "i", ("lat", "lon"))
+        iv._FillValue = FILL_I4
+        iv.long_name, iv.units = "number of days interpolated tmin >= tmax", "days"
+        iv.comment = ("The number of days daily tmin/tmax had to be adjusted due to interpolated tmin "
+                      "being >= interpolated tmax")
+        gridded(iv)
+        iv[:] = FILL_I4
+        return ds
+
+    def write_tile_chunk(self, tile_id, varname, days, str_row, str_col, daily_vals, mthly_normals,
+                         mthly_normals_se, ninvalid):
+        """tiling.py:488-537; ``daily_vals`` is the packed int16 block (or None for a normals-only run)."""
+        fpath = self.fpath(tile_id, varname)
+        ds = netcdf_file(fpath, "a", mmap=False) if os.path.exists(fpath) else self._create(fpath, tile_id, varname, days)
+        try:
+            ny, nx = np.asarray(mthly_normals).shape[-2:]
+            rs, cs = slice(str_row, str_row + ny), slice(str_col, str_col + nx)
+            if daily_vals is not None:
+                ds.variables[varname][:, rs, cs] = np.asarray(daily_vals, np.int16)
+            ds.variables[varname + "_normal"][:, rs, cs] = np.asarray(mthly_normals, np.float32)
+            ds.variables[varname + "_se"][:, rs, cs] = np.asarray(mthly_normals_se, np.float32)
+            ds.variables["inconsist_tair"][rs, cs] = np.asarray(ninvalid, np.int32)
+        finally:
+            ds.close()
+
+
+def _native(a):
+    """netCDF classic data is big-endian: copy into the native byte order."""
+    a = np.asarray(a)
+    return a.astype(a.dtype.newbyteorder("="))
+
+
+def read_tile(fpath, varname):
+    """Arrays of one tile file: daily int16 (raw), normals / SE f4, ninvalid, lon, lat, time."""
+    ds = netcdf_file(fpath, "r", mmap=False)
+    try:
+        g = ds.variables
+        out = {"daily": _native(g[varname][:]), "norm": _native(g[varname + "_normal"][:]),
+               "se": _native(g[varname + "_se"][:]), "ninvalid": _native(g["inconsist_tair"][:]),
+               "lon": _native(g["lon"][:]), "lat": _native(g["lat"][:]),
+               "time": _native(g["time"][:]), "time_units": g["time"].units.decode(),
+               "scale_factor": g[varname].scale_factor}
+    finally:
+        ds.close()
+    return out
+
+
+def read_tile_stores(path_in, tiles, variables=("tmin", "tmax")):
+    """Tile files -> ``{tile_id: TileStore}`` for ``TileMosaic`` (missing tiles are skipped, as the
+    mosaicker treats them: tiling.py:772-776)."""
+    from .step25 import TileStore
+    stores = {}
+    for t in tiles:
+        st = None
+        for v in variables:
+            fp = os.path.join(path_in, t, "%s_%s.nc" % (t, v))
+            if not os.path.exists(fp):
+                continue
+            a = read_tile(fp, v)
+            if st is None:
+                st = TileStore(a["daily"].shape[0], a["norm"].shape[1], a["norm"].shape[2], True)
+            st.a["daily_" + v], st.a["norm_" + v], st.a["se_" + v] = a["daily"], a["norm"], a["se"]
+            st.a["ninvalid"] = a["ninvalid"]
+        if st is not None:
+            stores[t] = st
+    return stores
+
+
+# ---- serially-complete station database (station_data.py:547-616) -------------------------------------
+def write_station_db(path, stn_da):
+    """A ``StationSerialDataDb`` as a classic netCDF file in the reference's layout: dimension
+    ``station_id`` (+ ``string<N>`` for the ids), ``time``; one variable per station-table column on
+    (station_id,); the observation variable on (time, station_id)."""
+    stns, days = stn_da.stns, stn_da.days
+    ds = netcdf_file(path, "w", version=2, mmap=False)
+    try:
+        n = stns.size
+        idlen = max(len(s) for s in stns[sdb.STN_ID])
+        ds.createDimension(sdb.STN_ID, n)
+        ds.createDimension("string%d" % idlen, idlen)
+        ds.createDimension("time", int(days.size))
+        ids = ds.createVariable(sdb.STN_ID, "c", (sdb.STN_ID, "string%d" % idlen))
+        ids[:] = np.array([list(s.ljust(idlen, "\0")) for s in stns[sdb.STN_ID]], "S1")
+        d0 = _date(days, 0)
+        tv = ds.createVariable("time", "d", ("time",))
+        tv.units = "days since %d-%d-%d 0:0:0" % (d0.year, d0.month, d0.day)
+        tv.calendar, tv.standard_name = "standard", "time"
+        tv[:] = [_num(_date(days, i), d0) for i in range(days.size)]
+        for name in stns.dtype.names:
+            if name == sdb.STN_ID:
+                continue
+            v = ds.createVariable(name, "d", (sdb.STN_ID,))
+            v.missing_value = float(FILL_F4)
+            v[:] = np.where(np.isnan(stns[name]), float(FILL_F4), stns[name])
+        if stn_da.var is not None:
+            ov = ds.createVariable(stn_da.var_name, "f", ("time", sdb.STN_ID))
+            ov.units = "C"
+            ov[:] = stn_da.var
+    finally:
+        ds.close()
+
+
+def read_station_db(path, var_name, cls=None):
+    """``StationSerialDataDb(nc_path, var_name)`` (station_data.py:554-616) on a classic netCDF file."""
+    cls = sdb.StationSerialDataDb if cls is None else cls
+    ds = netcdf_file(path, "r", mmap=False)
+    try:
+        tv = ds.variables["time"]
+        units = tv.units.decode()
+        if not units.startswith("days since "):
+            raise ValueError("time units must be 'days since ...'")
+        y, m, d = (int(x) for x in units.split()[2].split("-"))
+        t = np.floor(np.asarray(tv[:], np.float64)).astype(np.int64)
+        d0 = _dt.date(y, m, d)
+        if not np.array_equal(t - t[0], np.arange(t.size)):
+            raise ValueError("time axis must be daily and gap-free")
+        days = get_days_metadata(d0 + _dt.timedelta(days=int(t[0])), d0 + _dt.timedelta(days=int(t[-1])))
+        raw = ds.variables[sdb.STN_ID][:]
+        ids = np.array([b"".join(r).rstrip(b"\0 ").decode() for r in raw])      # chartostring
+        cols = {}
+        for name, v in ds.variables.items():
+            if v.dimensions == (sdb.STN_ID,):
+                a = np.asarray(v[:], np.float64).copy()
+                for att in ("missing_value", "_FillValue"):
+                    if hasattr(v, att):
+                        a[a == float(getattr(v, att))] = np.nan                # auto-mask -> NaN (:159-164)
+                cols[name] = a
+        dt = [(sdb.STN_ID, "U%d" % max(1, max(len(s) for s in ids)))] + [(k, np.float64) for k in cols]
+        stns = np.empty(ids.size, dtype=dt)
+        stns[sdb.STN_ID] = ids
+        for k, a in cols.items():
+            stns[k] = a
+        obs = np.asarray(ds.variables[var_name][:], np.float32).copy() if var_name in ds.variables else None
+    finally:
+        ds.close()
+    return cls(stns, var_name, days, obs)

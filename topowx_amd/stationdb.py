@@ -116,7 +116,7 @@ class StationSerialDataDb(object):
             obs = obs.reshape(obs.shape[0])
         return obs
 
-    # -- persistence (npz; netCDF is SURVEY.md 8f-2) -------------------------
+    # -- persistence (npz; the netCDF layout lives in topowx_amd/ncio.py) -----
     def save(self, path):
         np.savez_compressed(path, stns=self.stns, var_name=self.var_name,
                             ymd0=int(self.days.YMD[0]), ymd1=int(self.days.YMD[-1]),

@@ -3,8 +3,8 @@
 Keeps the reference's structure -- ``Tiler`` yields f8[32, Y, X] work chunks, a ``PtInterpTair``
 interpolates them, a writer stores ``days x Y x X`` int16 / ``12 x Y x X`` f4 blocks per tile -- but
 one ``interp_chunk`` call replaces the 2 500-iteration Python cell loop, and ranks own whole tiles
-(no per-tile write token, step25:177-196).  Tiles are written as ``<tile_id>.npz`` (netCDF output is
-SURVEY.md 8f-2).
+(no per-tile write token, step25:177-196).  Tiles are written as ``<tile_id>.npz`` or, with
+``out_format="nc"``, through ``ncio.TileWriter`` as ``<tile_id>/<tile_id>_<var>.nc``.
 """
 import os
 
@@ -42,7 +42,7 @@ class TileStore(object):
 
 
 def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, daily=True, out_dir=None,
-              rank=0, world=1, device=0):
+              rank=0, world=1, device=0, out_format="npz"):
     """Interpolate the tiles of this rank chunk by chunk; returns {tile_id: TileStore}."""
     tiles = tile_list(grid["mask"], tile_size, tile_size)
     mine = {t[0] for t in assign_tiles(tiles, world)[rank]}
@@ -56,9 +56,18 @@ def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, dail
         str_row, str_col = int(wrk_chk[0, 0, 0]), int(wrk_chk[1, 0, 0])            # step25:110-111
         out = pt_interp.interp_chunk(wrk_chk, daily=daily)                         # step25:126-172 in one call
         store.write_tile_chunk(str_row, str_col, out)                              # step25:181-185
+    days = pt_interp.days
     pt_interp.close()
     if out_dir is not None:
         os.makedirs(out_dir, exist_ok=True)
-        for tile_id, store in stores.items():
-            store.save(os.path.join(out_dir, tile_id + ".npz"))
+        if out_format == "nc":                                                     # step25:181-185
+            from .ncio import TileWriter
+            writer = TileWriter(info, out_dir)
+            for tile_id, store in stores.items():
+                for v in ("tmin", "tmax"):
+                    writer.write_tile_chunk(tile_id, v, days, 0, 0, store.a.get("daily_" + v), store.a["norm_" + v],
+                                            store.a["se_" + v], store.a["ninvalid"])
+        else:
+            for tile_id, store in stores.items():
+                store.save(os.path.join(out_dir, tile_id + ".npz"))
     return stores
