@@ -68,6 +68,15 @@ __device__ __forceinline__ double readlane_d(double v, int lane /*wave-uniform*/
     return __hiloint2double(hi, lo);
 }
 
+// acc += bcast(p, lane N of this lane's 16-lane row) * u in ONE instruction: v_fmac_f64 with a DPP
+// row_newbcast source (gfx90a+; full fp64 rate on gfx950: tests/tools/micro/fmac_dpp.hip).  The column
+// operand of the rank-4 update is common to the 16 lanes of a row, so it never has to be re-read from LDS.
+template <int N>
+__device__ __forceinline__ void fmac_rowbcast(double &acc, double p, double u)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(u), "n"(N));
+}
+
 // psill * exp(-h / range) with the exponent carried as an fp32 hi/lo pair:
 // t = h * (chi + clo) = -h / range * log2(e); 2^t = 2^n * 2^f.  Relative error ~1e-7.
 __device__ __forceinline__ float exp2_neg_split(float h, float chi, float clo)
@@ -124,7 +133,15 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
 // does not spill the register-resident matrix to chase a higher occupancy)
 // (measured per bucket on the C2 bench: more resident work-groups beat the few spilled registers)
-#define TWX_UK_WAVES(NB) ((NB) >= 9 ? 3 : ((NB) >= 7 ? 4 : ((NB) == 6 ? 5 : ((NB) == 5 ? 6 : 7))))
+#ifndef TWX_UK_WV
+#define TWX_UK_WV 3, 3, 4, 4, 5, 6, 7   // NB = 10, 9, 8, 7, 6, 5, 4
+#endif
+__host__ __device__ constexpr int twx_uk_waves(int nb)
+{
+    constexpr int w[7] = {TWX_UK_WV};
+    return w[10 - nb];
+}
+#define TWX_UK_WAVES(NB) twx_uk_waves(NB)
 
 template <int NB>
 __global__ __launch_bounds__(256)
@@ -133,14 +150,21 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
-    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * 6];          // four scaled columns of the current panel, [row][4]
+    __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];            // four scaled columns of the current panel, [row][4]
+    __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];             // the same four columns before the panel is factorised
     __shared__ double s_B[7][NP];
     __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
     __shared__ double s_cphi[NP];                // cos(lat) per neighbour
     __shared__ double s_red[4][4];
     __shared__ int s_err;
 
-    const int t = threadIdx.x, tr = t & 15, tc = t >> 4, lane = t & 63, wv = t >> 6, tcl = lane >> 4;
+    const int t = threadIdx.x, tr = t & 15, lane = t & 63, wv = t >> 6, tcl = lane >> 4;
+    // Which wave holds which four columns of a block is rotated per work-group: the work-groups resident on
+    // a CU run in near lockstep, and without the rotation their panel factorisations (one wave each) would
+    // all queue on the same SIMD while the other three idle.
+    const int rot = (int)((blockIdx.x * 2654435761u) >> 13) & 3;
+    const int wvp = (wv + rot) & 3;              // column group of this wave
+    const int tc = 4 * wvp + tcl;
     if ((int)blockIdx.x >= nitems) return;
     const int item = item_list[blockIdx.x];
     const int64_t lc = item / 12;
@@ -221,104 +245,112 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 }
             }
             if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1
-            A[tri(a, b)] = v;
+            A[tri(a, b)] = -v;                               // the registers hold N = -M: updates are pure fmacs
         });
     });
 
     // ---- elimination: panels of four columns ------------------------------------------------------
-    int pbuf = 0;
+    int errf = 0;
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
         const int ncb = (ablate & 1) ? 0 : k - 16 * bp;      // C columns left (ablate: timing experiments only)
         if (ncb > 0) {
             const int npan = min(4, (ncb + 3) >> 2);
+#pragma nounroll
             for (int s = 0; s < npan; ++s) {
                 const int ncol = min(4, ncb - 4 * s);        // real columns in this panel
-                double *pan = s_pan[pbuf];
-                if (wv == s) {                               // the wave holding the panel's columns
-                    // Columns are exchanged between the four lane groups through the slab
-                    // itself (LDS operations of one wave execute in order).
-                    sfor<0, 4>([&](auto cc_) __attribute__((always_inline)) {
-                        constexpr int cc = decltype(cc_)::value;
-                        if (cc < ncol) {                     // uniform
-                            const int q = 4 * s + cc;        // column within the block
-                            double d = readlane_d(A[tri(bp, bp)], 16 * cc + q);
-                            // singular / indefinite system: pivot not clearly positive (relative to the sill)
-                            const bool bad = !(d > 1e-9 * c00) || !finite_d(d);
-                            const double rinv = bad ? 0.0 : rsqrt_nr(d);
-                            if (bad && lane == 0) s_err = 1;
-                            if (tcl == cc) {                 // lanes of column cc: scale and publish
-                                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                                    constexpr int a = decltype(a_)::value;
-                                    double v = A[tri(a, bp)] * rinv;
-                                    if (a == bp && tr <= q) v = 0.0;      // rows at / above the diagonal
-                                    A[tri(a, bp)] = v;
-                                    pan[(16 * a + tr) * PS + cc] = v;
-                                });
-                            }
-                            if constexpr (cc < 3) {          // remaining columns: a(i,p') -= l(i,p) l(p',p)
-                                __builtin_amdgcn_wave_barrier();
-                                const double lpp = pan[(16 * bp + 4 * s + tcl) * PS + cc];
-                                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                                    constexpr int a = decltype(a_)::value;
-                                    const double li = pan[(16 * a + tr) * PS + cc];
-                                    if (tcl > cc) A[tri(a, bp)] = fma(-li, lpp, A[tri(a, bp)]);
-                                });
-                            }
-                        } else if (tcl == cc) {
-                            sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                                constexpr int a = decltype(a_)::value;
-                                A[tri(a, bp)] = 0.0;
-                                pan[(16 * a + tr) * PS + cc] = 0.0;
-                            });
-                        }
+                // (1) the wave holding the panel's four columns publishes them as they are
+                if (wvp == s) {
+                    sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                        constexpr int a = decltype(a_)::value;
+                        s_raw[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
                     });
                 }
                 __syncthreads();
-                // rank-4 update of this thread's elements, two block columns at a time: the slab rows of
-                // two columns (8 doubles) stay in registers while the rows a >= b stream through; keeping
-                // all NB column rows live instead costs (NB-2)*8 VGPRs, i.e. occupancy or spills
-                sfor2<bp, NB>([&](auto b_) __attribute__((always_inline)) {
-                    constexpr int b = decltype(b_)::value;
-                    constexpr bool two = (b + 1 < NB);
-                    const double2 p0 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS]);
-                    const double2 p1 = *reinterpret_cast<const double2 *>(&pan[(16 * b + tc) * PS + 2]);
-                    double2 q0 = p0, q1 = p1;
-                    if constexpr (two) {
-                        q0 = *reinterpret_cast<const double2 *>(&pan[(16 * (b + 1) + tc) * PS]);
-                        q1 = *reinterpret_cast<const double2 *>(&pan[(16 * (b + 1) + tc) * PS + 2]);
-                    }
-                    sfor<b, NB>([&](auto a_) __attribute__((always_inline)) {
-                        constexpr int a = decltype(a_)::value;
-                        const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
-                        const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
-                        {
-                            double acc = A[tri(a, b)];
-                            acc = fma(-u0.x, p0.x, acc);
-                            acc = fma(-u0.y, p0.y, acc);
-                            acc = fma(-u1.x, p1.x, acc);
-                            acc = fma(-u1.y, p1.y, acc);
-                            A[tri(a, b)] = acc;
-                        }
-                        if constexpr (two && a >= b + 1) {
-                            double acc = A[tri(a, b + 1)];
-                            acc = fma(-u0.x, q0.x, acc);
-                            acc = fma(-u0.y, q0.y, acc);
-                            acc = fma(-u1.x, q1.x, acc);
-                            acc = fma(-u1.y, q1.y, acc);
-                            A[tri(a, b + 1)] = acc;
-                        }
+                // (2) every thread: its own row of the panel (one row per thread), the 4x4 diagonal block
+                //     (uniform addresses: LDS broadcasts), the block's Cholesky factor (redundantly: a chain of
+                //     four dependent rsqrt that no longer passes through LDS or another wave), then the row
+                //     solve l(i, 0..3) -- the same fma sequence per element as a column-by-column sweep.
+                const int myrow = 16 * bp + t;                       // rows 16bp .. NP-1, one per thread
+                const bool has_row = t < 16 * (NB - bp);
+                double2 n01 = {0, 0}, n23 = {0, 0};
+                if (has_row) {
+                    n01 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4]);
+                    n23 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4 + 2]);
+                }
+                const double *dg = &s_raw[(16 * bp + 4 * s) * 4];
+                const double g00 = dg[0];
+                const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
+                const double2 g2 = *reinterpret_cast<const double2 *>(&dg[8]);
+                const double g22 = dg[10];
+                const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
+                const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
+                bool bad = false;
+                // the registers hold N = -M: pivot d = -n, l = n * (-1/sqrt(d)), updates n += l l
+                auto pivot = [&](double nd, bool valid) __attribute__((always_inline)) {
+                    const double d = -nd;
+                    const bool b = !(d > 1e-9 * c00) || !finite_d(d);   // singular / indefinite system
+                    bad = bad || (valid && b);
+                    return (valid && !b) ? -rsqrt_nr(d) : 0.0;
+                };
+                const double r0 = pivot(g00, true);
+                const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
+                const double r1 = pivot(fma(l10, l10, g1.y), ncol > 1);
+                const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
+                const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)), ncol > 2);
+                const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
+                const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
+                if (bad) errf = 1;
+                if (has_row) {
+                    double L0 = n01.x * r0;
+                    double L1 = fma(L0, l10, n01.y) * r1;
+                    double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                    double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
+                    const int q = t - 4 * s;                         // rows at / above the diagonal (block bp only)
+                    if (q <= 0) L0 = 0.0;
+                    if (q <= 1) L1 = 0.0;
+                    if (q <= 2) L2 = 0.0;
+                    if (q <= 3) L3 = 0.0;
+                    *reinterpret_cast<double2 *>(&s_pan[myrow * PS]) = double2{L0, L1};
+                    *reinterpret_cast<double2 *>(&s_pan[myrow * PS + 2]) = double2{L2, L3};
+                }
+                __syncthreads();
+                // (3) rank-4 update N(i,j) += l(i,:) . l(j,:).  The column factors l(16b+tc, 0..3) are common to
+                // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bp) + column) once
+                // per panel and every fmac picks its operand with row_newbcast; the row factors l(16a+tr, 0..3)
+                // are read once per block row.  LDS reads per panel: 2(NB-bp) b128 + 3 b64 per lane.
+                const double *pan = s_pan;
+                constexpr int NE = 4 * (NB - bp), NR = (NE + 15) / 16;
+                double P[NR];
+                sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    const int e = min(16 * r + tr, NE - 1);
+                    P[r] = pan[(16 * (bp + (e >> 2)) + tc) * PS + (e & 3)];
+                });
+                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
+                    sfor<bp, a + 1>([&](auto b_) __attribute__((always_inline)) {
+                        constexpr int b = decltype(b_)::value;
+                        constexpr int e = 4 * (b - bp);
+                        double acc = A[tri(a, b)];
+                        fmac_rowbcast<(e + 0) % 16>(acc, P[(e + 0) / 16], u0.x);
+                        fmac_rowbcast<(e + 1) % 16>(acc, P[(e + 1) / 16], u0.y);
+                        fmac_rowbcast<(e + 2) % 16>(acc, P[(e + 2) / 16], u1.x);
+                        fmac_rowbcast<(e + 3) % 16>(acc, P[(e + 3) / 16], u1.y);
+                        A[tri(a, b)] = acc;
                     });
                 });
-                pbuf ^= 1;
             }
         }
     });
+    if (errf && t == 0) s_err = 1;
 
     // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
     if (tr >= 9 && tc >= 9 && tr >= tc) {
         const int r = tr - 9, cq = tc - 9;
-        ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = -A[tri(NB - 1, NB - 1)];
+        ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[tri(NB - 1, NB - 1)];
     }
     __syncthreads();
     if (t == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = s_err ? 1.0 : 0.0;
