@@ -7,17 +7,22 @@
 //        M = [ C   B ]      C = k x k covariance, B = [1 x1 x2 x3 x4 | y | c0]
 //            [ B'  0 ]
 //
-// is held ENTIRELY IN REGISTERS, distributed 2-D block-cyclically over the 16x16
-// thread grid: thread (tr, tc) owns element (16a+tr, 16b+tc) of every 16x16 block
-// (a >= b).  Right-looking Cholesky eliminates the C part in PANELS of four
-// columns: the four columns of a panel live in exactly one wavefront (lanes =
-// 4 columns x 16 rows), which factorises them with lane shuffles only, publishes
-// the four scaled columns through a double-buffered LDS slab, and after ONE
-// workgroup barrier every thread applies the rank-4 update to its own elements
-// (all register indices compile-time).  What is left in the trailing 7x7 block is
-// -B'C^-1 B, i.e. every inner product the GLS predictor needs (X'C^-1X, X'C^-1y,
-// X'C^-1c0, c0'C^-1c0, c0'C^-1y) -- no triangular solves.  The seven RHS rows sit
-// at the fixed rows NP-7..NP-1 so the Schur complement lands in a fixed block.
+// is held ENTIRELY IN REGISTERS (negated: the registers hold N = -M, so every update is a pure
+// fmac), distributed 2-D block-cyclically over the 16x16 thread grid: thread (tr, tc) owns element
+// (16a+tr, 16b+tc) of every 16x16 block (a >= b).  Right-looking Cholesky eliminates the C part in
+// PANELS of four columns, three steps per panel with a work-group barrier between them:
+//   (1) the one wavefront that holds the panel's four columns (lanes = 4 columns x 16 rows) publishes
+//       them unfactorised in LDS;
+//   (2) every thread takes ONE row of the panel, reads the 4x4 diagonal block through LDS broadcasts,
+//       factorises it redundantly (the chain of four dependent rsqrt passes through neither LDS nor
+//       another wave) and solves its row -- the same fma sequence per element as a column sweep;
+//   (3) every thread applies the rank-4 update to its own elements (all register indices
+//       compile-time).  The column factors are common to the 16 lanes of a DPP row, so each lane loads
+//       ONE of them per 16 and every v_fmac_f64 picks its operand with a row_newbcast DPP source: the
+//       update issues one LDS read per 8-16 fmacs and runs at ~85 % of the fp64 vector rate.
+// What is left in the trailing 7x7 block is -B'C^-1 B, i.e. every inner product the GLS predictor
+// needs (X'C^-1X, X'C^-1y, X'C^-1c0, c0'C^-1c0, c0'C^-1y) -- no triangular solves.  The seven RHS
+// rows sit at the fixed rows NP-7..NP-1 so the Schur complement lands in a fixed block.
 //
 // Pair distances h_ij (sp/gstat WGS84 great-circle, B.1) come from per-station
 // half-angle sines/cosines staged in LDS: six angle-addition products in fp64
