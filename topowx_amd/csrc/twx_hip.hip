@@ -17,7 +17,7 @@
 #include "twx_daily.h"
 #include "twx_out.h"
 #include "twx_uk.h"
-#include "twx_uk1.h"
+#include "twx_ukw.h"
 #include "twx_vario.h"
 #include "twx_agg.h"
 #include "twx_sample.h"
@@ -151,7 +151,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
     HIPCHK(w.cstat.ensure((size_t)ncell * 4));
     HIPCHK(w.kmaxc.ensure((size_t)ncell * 4));
-    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 13 * 4));
+    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 15 * 4));
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
@@ -175,8 +175,9 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.ncand_max = w.small.as<int32_t>();          // [0]
     s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16..31]
     {
-        static const int small_kmax = getenv("TWX_UK1_MAXK") ? atoi(getenv("TWX_UK1_MAXK")) : 72;
-        s.small_kmax = std::min(std::max(small_kmax, 0), 72);
+        // largest k handled by the one-wave kernel (k + 8 <= 96 rows); tuning knob, measured on the C2 bench
+        static const int small_kmax = getenv("TWX_UKW_MAXK") ? atoi(getenv("TWX_UKW_MAXK")) : 88;
+        s.small_kmax = std::min(std::max(small_kmax, 0), 88);
     }
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
@@ -196,10 +197,10 @@ void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int3
     hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt, ablate);
 }
 
-template <int NB8>
-void launch_uk1(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
+template <int NBR, int HALF>
+void launch_ukw(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_uk1<NB8>), dim3(cnt), dim3(64), 0, s, st, src, ws, cells, cnt);
+    hipLaunchKernelGGL((k_ukw<NBR, HALF>), dim3(cnt), dim3(64), 0, s, st, src, ws, cells, cnt);
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
@@ -239,16 +240,18 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     HIPCHK(hipStreamSynchronize(stream));
     {
         EvScope ev(ctx, stream, EV_UK);
-        for (int b = 0; b < 13; ++b) {
+        for (int b = 0; b < 15; ++b) {
             if (cnt[b] <= 0) continue;
             const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell * 12;
             switch (b) {
-            case 0: launch_uk1<5>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 1: launch_uk1<6>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 2: launch_uk1<7>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 3: launch_uk1<8>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 4: launch_uk1<9>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 5: launch_uk1<10>(st, src, w.ws, cells, cnt[b], stream); break;
+            case 13: launch_ukw<6, 1>(st, src, w.ws, cells, cnt[b], stream); break;  // k + 8 <= 88
+            case 14: launch_ukw<6, 0>(st, src, w.ws, cells, cnt[b], stream); break;  // k + 8 <= 96
+            case 0: launch_ukw<3, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 40
+            case 1: launch_ukw<3, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 48
+            case 2: launch_ukw<4, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 56
+            case 3: launch_ukw<4, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 64
+            case 4: launch_ukw<5, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 72
+            case 5: launch_ukw<5, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 80
             case 6: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
             case 7: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
             case 8: launch_uk<6>(st, src, w.ws, cells, cnt[b], stream); break;

@@ -17,7 +17,7 @@ struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
     int cmax;            // candidate slots per tile
     int init_nnghs;
-    int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_uk1)
+    int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_ukw)
     int64_t cell0;       // first global cell id of the batch
     int64_t ncell;       // cells in the batch
     int64_t tile0;       // first tile id of the batch
@@ -34,8 +34,8 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *kmaxc;      // [ncell] largest kk / ka of the cell
-    int32_t *bucket_cnt; // [16]: 0..5 one-wave kernel NB8 = 5..10, 6..12 four-wave kernel NB = 4..10
-    int32_t *bucket_cells; // [13][ncell * 12] (cell, month) items per matrix-size bucket
+    int32_t *bucket_cnt; // [16]: 0..5 and 13, 14 one-wave kernel (8-row units 5..10, 11, 12), 6..12 four-wave kernel NB = 4..10
+    int32_t *bucket_cells; // [15][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         if (k > 0) {
             if (k <= ws.small_kmax) {
                 int nb8 = (k + 8 + 7) / 8;
-                id = (nb8 < 5 ? 5 : nb8) - 5;
+                id = nb8 <= 10 ? (nb8 < 5 ? 5 : nb8) - 5 : 13 + (nb8 - 11);      // 11, 12 -> 13, 14
             } else {
                 int nb = (k + 8 + 15) / 16;
                 id = 6 + (nb < 4 ? 4 : nb) - 4;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         }
     }
     __syncthreads();
-    if (t < 13 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
+    if (t < 15 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
     __syncthreads();
     if (id >= 0) ws.bucket_cells[(int64_t)id * ws.ncell * 12 + s_base[id] + rank] = (int32_t)item;
 }

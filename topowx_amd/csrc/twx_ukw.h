@@ -1,0 +1,237 @@
+// twx_ukw.h -- universal-kriging kernel for SMALL systems (k + 8 <= 96 rows): one wavefront per
+// (cell, month) item, no work-group barrier anywhere.
+//
+// Same algorithm and the same three-step panel scheme as k_uk (twx_uk.h): bordered matrix
+// [[C, B], [B', 0]] held negated in registers, right-looking Cholesky in 4-column panels, Schur
+// complement -B'C^-1B in the trailing 7x7 block.  The 64 lanes form a 16 x 4 grid, lane (tr, tc) =
+// (lane & 15, lane >> 4), and hold element (16a + tr, 4b + tc) of every 16-row x 4-column block with
+// 4b <= 16a + 15.  A panel is exactly one block column, so
+//   * all 64 lanes hold a piece of the panel and publish it;
+//   * the 16 lanes of a DPP row share their column, i.e. the column factor of the rank-4 update is a
+//     row_newbcast DPP operand of v_fmac_f64 (one LDS read per 16 of them), as in k_uk;
+//   * a finished block column is dead: updates start at the next one, and block columns that hold only
+//     padding (between the last C column and the RHS rows) are skipped at run time.
+// The covariance build, the slab layout and the GLS epilogue (k_uk_solve) are shared with k_uk.
+#pragma once
+#include "twx_uk.h"
+
+// waves per SIMD the register budget is sized for (min == max, see twx_uk.h)
+#ifndef TWX_UKW_WV
+#define TWX_UKW_WV 2, 3, 4, 5   // NBR = 6, 5, 4, 3 (measured on the C2 bench)
+#endif
+__host__ __device__ constexpr int twx_ukw_waves(int nbr)
+{
+    constexpr int w[4] = {TWX_UKW_WV};
+    return w[6 - nbr];
+}
+
+__device__ __forceinline__ constexpr int widx(int a, int b) { return 2 * a * (a + 1) + b; }   // blocks of rows < a: 4a' + 4 each
+
+// HALF = 1: the system has only 16 NBR - 8 rows; the seven RHS rows then sit in the upper half of the last block
+// row (rows RHS0 = NP-15 .. NP-9) and what lies below / to the right of them is padding that is never touched.
+template <int NBR, int HALF>
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(twx_ukw_waves(NBR), twx_ukw_waves(NBR))))
+void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
+{
+    constexpr int NP = NBR * 16, NC = NP / 4, NT = 2 * NBR * (NBR + 1);
+    constexpr int R0 = HALF ? 1 : 9, RHS0 = 16 * (NBR - 1) + R0;       // first RHS row / column
+    constexpr int PS = 6;       // slab row stride (doubles): 48-byte rows, 16-B aligned
+    __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];
+    __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];
+    __shared__ double s_B[7][NP];
+    __shared__ double s_trig[NP * 4];
+    __shared__ double s_cphi[NP];
+
+    const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
+    if ((int)blockIdx.x >= nitems) return;
+    const int item = item_list[blockIdx.x];
+    const int64_t lc = item / 12;
+    const int m0 = item % 12;
+    const int64_t c = ws.cell0 + lc;
+    const int k = ws.kk[lc * 12 + m0];
+    const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    const double nug = ws.vario[(lc * 12 + m0) * 3 + 0];
+    const double psill = ws.vario[(lc * 12 + m0) * 3 + 1];
+    const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
+    const double c00 = nug + psill;
+    const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
+    const float chi = (float)c2, clo = (float)(c2 - (double)chi);
+
+    // ---- staging: neighbours t = lane, lane + 64 (NP <= 96) -----------------------------------
+    double xs[2][4], yv[2], c0v[2];
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * u;
+        xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
+        if (t < NP) {
+            double sp = 0, cp = 1, sl = 0, cl = 1;
+            if (t < k) {
+                const int j = ws.near_idx[lc * ws.ksel + t];
+                sp = st.sph[j]; cp = st.cph[j]; sl = st.slh[j]; cl = st.clh[j];
+                const double lo = st.lon[j], la = st.lat[j];
+                xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev;
+                xs[u][3] = st.lst[m0 * n + j] - plst;
+                yv[u] = st.norm[m0 * n + j];
+                const double *ct = ws.ctrig + lc * 4;
+                const float h0 = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0])),
+                                                 sp, cp, sl, cl, fma(cp, cp, -(sp * sp)));
+                const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+                c0v[u] = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
+                e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
+                e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
+            }
+            s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
+            s_cphi[t] = fma(cp, cp, -(sp * sp));
+        }
+    }
+    e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
+    const double sc0 = e0 > 0.0 ? 1.0 / e0 : 1.0, sc1 = e1 > 0.0 ? 1.0 / e1 : 1.0;
+    const double sc2 = e2 > 0.0 ? 1.0 / e2 : 1.0, sc3 = e3 > 0.0 ? 1.0 / e3 : 1.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * u;
+        if (t < NP) {
+            s_B[0][t] = t < k ? 1.0 : 0.0;
+            s_B[1][t] = xs[u][0] * sc0; s_B[2][t] = xs[u][1] * sc1; s_B[3][t] = xs[u][2] * sc2; s_B[4][t] = xs[u][3] * sc3;
+            s_B[5][t] = yv[u]; s_B[6][t] = c0v[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- build this lane's elements (negated: the registers hold N = -M) ---------------------------------
+    double A[NT];
+    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        const int i = 16 * a + tr;
+        const double spi = s_trig[i * 4], cpi = s_trig[i * 4 + 1], sli = s_trig[i * 4 + 2], cli = s_trig[i * 4 + 3];
+        const double cphi = s_cphi[i];
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            const int j = 4 * b + tc;
+            double v = 0.0;
+            if (4 * b < k) {                                     // uniform: block column holds C columns
+                if (i < k && j < k) {
+                    if (i == j) v = c00;
+                    else if (j < i) {
+                        const float h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1],
+                                                        s_trig[j * 4 + 2], s_trig[j * 4 + 3], s_cphi[j]);
+                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h, chi, clo));
+                    }
+                }
+                if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
+            }
+            A[widx(a, b)] = -v;
+        });
+    });
+
+    // ---- elimination: one panel per block column ----------------------------------------------------------
+    int errf = 0;
+    sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_)::value;
+        constexpr int a0 = b / 4;                            // first block row holding columns 4b..4b+3
+        const int ncol = min(4, k - 4 * b);                  // real columns in this panel
+        if (ncol > 0) {                                      // uniform
+            // (1) publish the panel as it is (LDS operations of one wave execute in order: no barrier)
+            sfor<a0, NBR>([&](auto a_) __attribute__((always_inline)) {
+                constexpr int a = decltype(a_)::value;
+                s_raw[(16 * a + tr) * 4 + tc] = A[widx(a, b)];
+            });
+            __builtin_amdgcn_wave_barrier();
+            // (2) the 4x4 diagonal block (uniform addresses: broadcasts), its Cholesky factor, then one row
+            //     solve per lane and round -- the same fma sequence per element as a column-by-column sweep
+            const double *dg = &s_raw[(4 * b) * 4];
+            const double g00 = dg[0];
+            const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
+            const double2 g2 = *reinterpret_cast<const double2 *>(&dg[8]);
+            const double g22 = dg[10];
+            const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
+            const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
+            bool bad = false;
+            auto pivot = [&](double nd, bool valid) __attribute__((always_inline)) {
+                const double d = -nd;
+                const bool bb = !(d > 1e-9 * c00) || !finite_d(d);   // singular / indefinite system
+                bad = bad || (valid && bb);
+                return (valid && !bb) ? -rsqrt_nr(d) : 0.0;
+            };
+            const double r0 = pivot(g00, true);
+            const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
+            const double r1 = pivot(fma(l10, l10, g1.y), ncol > 1);
+            const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
+            const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)), ncol > 2);
+            const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
+            const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
+            if (bad) errf = 1;
+            constexpr int NROW = NP - 16 * a0;               // rows 16 a0 .. NP-1
+#pragma unroll
+            for (int u = 0; u < (NROW + 63) / 64; ++u) {
+                if (u) __builtin_amdgcn_wave_barrier();      // one round's registers at a time
+                const int row = 16 * a0 + lane + 64 * u;
+                if (row < NP) {
+                    const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[row * 4]);
+                    const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[row * 4 + 2]);
+                    double L0 = n01.x * r0;
+                    double L1 = fma(L0, l10, n01.y) * r1;
+                    double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                    double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
+                    const int q = row - 4 * b;               // rows at / above the diagonal
+                    if (q <= 0) L0 = 0.0;
+                    if (q <= 1) L1 = 0.0;
+                    if (q <= 2) L2 = 0.0;
+                    if (q <= 3) L3 = 0.0;
+                    *reinterpret_cast<double2 *>(&s_pan[row * PS]) = double2{L0, L1};
+                    *reinterpret_cast<double2 *>(&s_pan[row * PS + 2]) = double2{L2, L3};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (3) rank-4 update of the block columns b+1 .. (the panel's own block column is finished)
+            if constexpr (b + 1 < NC) {
+                constexpr int NE = 4 * (NC - b - 1), NR = (NE + 15) / 16;
+                double P[NR];
+                sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    const int e = min(16 * r + tr, NE - 1);
+                    P[r] = s_pan[(4 * (b + 1 + (e >> 2)) + tc) * PS + (e & 3)];
+                });
+                constexpr int a1 = (b + 1) / 4;              // first block row with a block column > b
+                sfor<a1, NBR>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS + 2]);
+                    // block columns right of the RHS columns (HALF) are padding; the (at most two) padding block
+                    // columns between the last C column and the RHS columns are updated like the rest -- a run-time
+                    // test per block would cost more issue slots than their four fmacs
+                    constexpr int BHI = (RHS0 + 6) / 4 + 1;
+                    sfor<b + 1, (4 * a + 4 < BHI ? 4 * a + 4 : BHI)>([&](auto bb_) __attribute__((always_inline)) {
+                        constexpr int bb = decltype(bb_)::value;
+                        constexpr int e = 4 * (bb - b - 1);
+                        double acc = A[widx(a, bb)];
+                        fmac_rowbcast<(e + 0) % 16>(acc, P[(e + 0) / 16], u0.x);
+                        fmac_rowbcast<(e + 1) % 16>(acc, P[(e + 1) / 16], u0.y);
+                        fmac_rowbcast<(e + 2) % 16>(acc, P[(e + 2) / 16], u1.x);
+                        fmac_rowbcast<(e + 3) % 16>(acc, P[(e + 3) / 16], u1.y);
+                        A[widx(a, bb)] = acc;
+                    });
+                });
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    });
+
+    // ---- Schur complement out (k_uk_solve finishes): rows / columns RHS0 .. RHS0+6 ------------------------------
+    if (tr >= R0 && tr < R0 + 7) {
+        const int r = tr - R0;
+        constexpr int B0 = RHS0 / 4;                         // the two block columns holding the RHS columns
+        sfor<B0, B0 + 2>([&](auto bb_) __attribute__((always_inline)) {
+            constexpr int bb = decltype(bb_)::value;
+            const int cq = 4 * bb + tc - RHS0;
+            if (cq >= 0 && r >= cq)
+                ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[widx(NBR - 1, bb)];
+        });
+    }
+    errf = __any(errf);
+    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = errf ? 1.0 : 0.0;
+}

@@ -6,7 +6,7 @@
 //           semivariogram (5 km bins of the sp/gstat distance, cutoff 1.4 x the largest neighbour
 //           distance), nugget fixed at min(gamma), total sill at var(residuals), range fitted by
 //           weighted Gauss-Newton (weights np/h^2); pure-nugget fallback (interp.R:63-80)
-//   GLS trend with that model: the kriging kernels (k_uk / k_uk1 + k_uk_solve) deliver
+//   GLS trend with that model: the kriging kernels (k_uk / k_ukw + k_uk_solve) deliver
 //           beta = (X'C^-1X)^-1 X'C^-1 y for the same neighbourhood (interp.R:82-84)
 //   pass 1: the same on the GLS residuals -> (nug, psill, range) (interp.R:85-112)
 // gstat cannot run here: the estimator and the optimiser's stopping rule are restated (scheme in
