@@ -50,14 +50,14 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0;
     int cmax = 512;
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0})
             b->release();
     }
 };
@@ -157,6 +157,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
     HIPCHK(w.ctrig.ensure((size_t)ncell * 32));
     HIPCHK(w.uk_S.ensure((size_t)ncell * 12 * TWX_UK_SLEN * 8));
+    HIPCHK(w.dist.ensure((size_t)ncell * TWX_DIST_BLOCKS * 256 * 4));   // pair distances shared by a cell's 12 systems
+    HIPCHK(w.h0.ensure((size_t)ncell * ksel * 4));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
@@ -186,6 +188,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.bucket_cells = w.bucket_cells.as<int32_t>();
     s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
+    s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     return 0;
 }
@@ -240,6 +243,9 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     HIPCHK(hipStreamSynchronize(stream));
     {
         EvScope ev(ctx, stream, EV_UK);
+        // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
+        hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
+        ctx->t_launches++;
         for (int b = 0; b < 15; ++b) {
             if (cnt[b] <= 0) continue;
             const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell * 12;

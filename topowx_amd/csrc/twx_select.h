@@ -11,6 +11,8 @@
 #include "twx_device.h"
 
 #define TWX_UK_SLEN 29
+#define TWX_DIST_NB ((TWX_MAX_NNGHS + 15) / 16)                 // block rows of the distance cache
+#define TWX_DIST_BLOCKS (TWX_DIST_NB * (TWX_DIST_NB + 1) / 2)
 
 // Workspace of one (batch, variable)
 struct SelWs {
@@ -43,6 +45,9 @@ struct SelWs {
     double *uk_beta;     // [ncell][12][5] GLS trend coefficients (shifted / scaled basis of k_uk)
     double *vfit;        // [ncell][12][3] fitted variogram (8f-1)
     double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
+    float *dist;         // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr] station-pair distances (km) of the cell's kriging
+                         // neighbourhood in rank order, 16x16 blocks (a >= b) -- shared by the cell's 12 monthly systems
+    float *h0;           // [ncell][ksel] cell -> neighbour distance (km, sp/gstat formula)
 };
 
 // ---------------------------------------------------------------------------------

@@ -138,6 +138,53 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
 // does not spill the register-resident matrix to chase a higher occupancy)
 // (measured per bucket on the C2 bench: more resident work-groups beat the few spilled registers)
+// ---------------------------------------------------------------------------------
+// k_cell_dist: one work-group per cell.  The kriging neighbourhoods of a cell's 12 months are nested
+// (the k nearest of the same ranked list), so the pair distances of the largest one serve all twelve
+// systems: h(i, j) of the ranked neighbours i, j < max_m k_m as fp32 in 16x16 blocks (a >= b), block
+// element order [tc][tr] = the order in which the kriging kernels' lanes read them (256-B rows), plus the
+// cell -> neighbour distances.  12 x fewer evaluations of the distance formula than per system.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs ws)
+{
+    __shared__ double s_trig[TWX_KSEL_MAX * 4];
+    __shared__ double s_cphi[TWX_KSEL_MAX];
+    const int64_t lc = blockIdx.x;
+    if (lc >= ws.ncell || ws.cstat[lc] != 0) return;
+    const int t = threadIdx.x, tr = t & 15, tc = t >> 4;
+    int kmax = 0;
+#pragma unroll
+    for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
+    if (kmax <= 0) return;
+    if (t < kmax) {
+        const int j = ws.near_idx[lc * ws.ksel + t];
+        const double sp = st.sph[j], cp = st.cph[j], sl = st.slh[j], cl = st.clh[j];
+        s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
+        const double cph = fma(cp, cp, -(sp * sp));
+        s_cphi[t] = cph;
+        const double *ct = ws.ctrig + lc * 4;
+        ws.h0[lc * ws.ksel + t] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0])),
+                                                  sp, cp, sl, cl, cph);
+    }
+    __syncthreads();
+    const int nbk = (kmax + 15) >> 4;
+    float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
+    for (int a = 0; a < nbk; ++a) {
+        const int i = 16 * a + tr;
+        const bool iv = i < kmax;
+        const double spi = iv ? s_trig[i * 4] : 0.0, cpi = iv ? s_trig[i * 4 + 1] : 1.0;
+        const double sli = iv ? s_trig[i * 4 + 2] : 0.0, cli = iv ? s_trig[i * 4 + 3] : 1.0, cphi = iv ? s_cphi[i] : 1.0;
+        for (int b = 0; b <= a; ++b) {
+            const int j = 16 * b + tc;
+            float h = 0.f;
+            if (iv && j < kmax && i != j)
+                h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1], s_trig[j * 4 + 2],
+                                    s_trig[j * 4 + 3], s_cphi[j]);
+            out[(a * (a + 1) / 2 + b) * 256 + t] = h;        // t = tc * 16 + tr
+        }
+    }
+}
+
 #ifndef TWX_UK_WV
 #define TWX_UK_WV 3, 3, 4, 4, 5, 6, 7   // NB = 10, 9, 8, 7, 6, 5, 4
 #endif
@@ -158,8 +205,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];            // four scaled columns of the current panel, [row][4]
     __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];             // the same four columns before the panel is factorised
     __shared__ double s_B[7][NP];
-    __shared__ double s_trig[NP * 4];            // sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2) per neighbour
-    __shared__ double s_cphi[NP];                // cos(lat) per neighbour
     __shared__ double s_red[4][4];
     __shared__ int s_err;
 
@@ -189,23 +234,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
 
     // ---- staging: one neighbour per thread (NP <= 160 < 256) ------------------------------
     double x0 = 0, x1 = 0, x2 = 0, x3 = 0, yv = 0, c0v = 0;
-    if (t < NP) {
-        double sp = 0, cp = 1, sl = 0, cl = 1;
-        if (t < k) {
-            const int j = ws.near_idx[lc * ws.ksel + t];
-            sp = st.sph[j]; cp = st.cph[j]; sl = st.slh[j]; cl = st.clh[j];
-            const double lo = st.lon[j], la = st.lat[j];
-            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
-            yv = st.norm[m0 * n + j];
-            // cell -> station (B.1); a coincident point gets the full sill (exact interpolator)
-            const double *ct = ws.ctrig + lc * 4;
-            const float h0 = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0])),
-                                             sp, cp, sl, cl, fma(cp, cp, -(sp * sp)));
-            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
-        }
-        s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
-        s_cphi[t] = fma(cp, cp, -(sp * sp));
+    if (t < k) {
+        const int j = ws.near_idx[lc * ws.ksel + t];
+        const double lo = st.lon[j], la = st.lat[j];
+        x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
+        yv = st.norm[m0 * n + j];
+        // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
+        const float h0 = ws.h0[lc * ws.ksel + t];
+        const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+        c0v = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
     }
     {
         double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
@@ -227,26 +264,28 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     }
     __syncthreads();
 
-    // ---- build this thread's elements ---------------------------------------------------------
+    // ---- build this thread's elements: covariance of the cached pair distance (k_cell_dist) --------------
     double A[NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
-        double spi = 0, cpi = 1, sli = 0, cli = 1, cphi = 1;
-        if (a < nbk) { spi = s_trig[i * 4]; cpi = s_trig[i * 4 + 1]; sli = s_trig[i * 4 + 2]; cli = s_trig[i * 4 + 3]; cphi = s_cphi[i]; }
+        // all loads of the block row in flight before the first use (entries outside the neighbourhood are
+        // never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
+        float h[a + 1];
+        sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            h[b] = (a < TWX_DIST_NB) ? __builtin_nontemporal_load(&dist[tri(a, b) * 256]) : 0.f;
+        });
         sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 16 * b + tc;
             double v = 0.0;
-            if (a < nbk) {                                   // uniform
-                if (i < k && j < k) {
-                    if (i == j) v = c00;
-                    else {
-                        if (ablate & 2) { v = 0.001 * (double)((i * 7 + j) & 15); } else {
-                        const float h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1],
-                                                        s_trig[j * 4 + 2], s_trig[j * 4 + 3], s_cphi[j]);
-                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h, chi, clo)); }
-                    }
+            if (i < k && j < k) {
+                if (i == j) v = c00;
+                else {
+                    const float hh = (ablate & 2) ? 1.f : h[b];
+                    v = hh == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(hh, chi, clo));
                 }
             }
             if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1

@@ -40,8 +40,6 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
     __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];
     __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];
     __shared__ double s_B[7][NP];
-    __shared__ double s_trig[NP * 4];
-    __shared__ double s_cphi[NP];
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
     if ((int)blockIdx.x >= nitems) return;
@@ -67,25 +65,17 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
     for (int u = 0; u < 2; ++u) {
         const int t = lane + 64 * u;
         xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
-        if (t < NP) {
-            double sp = 0, cp = 1, sl = 0, cl = 1;
-            if (t < k) {
-                const int j = ws.near_idx[lc * ws.ksel + t];
-                sp = st.sph[j]; cp = st.cph[j]; sl = st.slh[j]; cl = st.clh[j];
-                const double lo = st.lon[j], la = st.lat[j];
-                xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev;
-                xs[u][3] = st.lst[m0 * n + j] - plst;
-                yv[u] = st.norm[m0 * n + j];
-                const double *ct = ws.ctrig + lc * 4;
-                const float h0 = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0])),
-                                                 sp, cp, sl, cl, fma(cp, cp, -(sp * sp)));
-                const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-                c0v[u] = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
-                e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
-                e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
-            }
-            s_trig[t * 4 + 0] = sp; s_trig[t * 4 + 1] = cp; s_trig[t * 4 + 2] = sl; s_trig[t * 4 + 3] = cl;
-            s_cphi[t] = fma(cp, cp, -(sp * sp));
+        if (t < k) {
+            const int j = ws.near_idx[lc * ws.ksel + t];
+            const double lo = st.lon[j], la = st.lat[j];
+            xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev;
+            xs[u][3] = st.lst[m0 * n + j] - plst;
+            yv[u] = st.norm[m0 * n + j];
+            const float h0 = ws.h0[lc * ws.ksel + t];          // cell -> station distance (k_cell_dist)
+            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+            c0v[u] = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
+            e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
+            e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
         }
     }
     e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
@@ -102,28 +92,29 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
     }
     __syncthreads();
 
-    // ---- build this lane's elements (negated: the registers hold N = -M) ---------------------------------
+    // ---- build this lane's elements (negated: the registers hold N = -M): covariance of the cached pair
+    //      distance (k_cell_dist; 16x16 blocks, element order [column][row]) -------------------------------------
     double A[NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
-        const double spi = s_trig[i * 4], cpi = s_trig[i * 4 + 1], sli = s_trig[i * 4 + 2], cli = s_trig[i * 4 + 3];
-        const double cphi = s_cphi[i];
+        // all loads of the block row in flight before the first use (entries outside the neighbourhood are
+        // never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
+        float h[4 * a + 4];
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            h[b] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
+        });
         sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 4 * b + tc;
             double v = 0.0;
-            if (4 * b < k) {                                     // uniform: block column holds C columns
-                if (i < k && j < k) {
-                    if (i == j) v = c00;
-                    else if (j < i) {
-                        const float h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1],
-                                                        s_trig[j * 4 + 2], s_trig[j * 4 + 3], s_cphi[j]);
-                        v = h == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h, chi, clo));
-                    }
-                }
-                if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
+            if (i < k && j < k) {
+                if (i == j) v = c00;
+                else if (j < i) v = h[b] == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h[b], chi, clo));
             }
+            if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
             A[widx(a, b)] = -v;
         });
     });
