@@ -145,7 +145,8 @@ def main():
         tj = json.load(open(tpath))
         traffic = tj["FETCH_SIZE"]["k_uk_per_launch_bytes"] + tj["WRITE_SIZE"]["k_uk_per_launch_bytes"]
         traffic_src = "profiles/r1_bench_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE, KB units x 1024, per launch; " \
-                      "8-byte gathers: the guide's x2 wide-read correction does not apply, width uncalibrated)"
+                      "4/8-byte loads: the guide's x2 wide-read correction does not apply; almost all of it is the " \
+                      "per-cell pair-distance cache that the cell's 12 monthly systems share, DESIGN.md section 4)"
 
     res = {
         "metric": "grid-cell-days interpolated/sec",
@@ -163,7 +164,7 @@ def main():
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_MONTH * solves / launches,
-                     "kernel": "k_uk<NB> (universal kriging, %d launches per step)" % launches,
+                     "kernel": "universal kriging: k_cell_dist + k_ukw<..> + k_uk<..> (%d launches per step)" % launches,
                      "kernel_ms_per_step": uk_ms,
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},
         "fp64": {"achieved": ach_tflops, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Collect the round's bench line, the rocprofv3 kernel summary and the two HBM-traffic PMC passes of bench.py
+# (run on the GPU box from the repo root: `gpurun -- bash tests/tools/collect_profiles.sh`); everything lands in
+# gpurun_out/prof_round/ and is reduced by tests/tools/reduce_profiles.py into the files kept under profiles/.
+set -u
+OUT=gpurun_out/prof_round
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py --steps 20 --warmup 3 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline 2>$OUT/stats.err | tail -1 > $OUT/bench_profiled.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > $OUT/write.log 2>&1
+python3 tests/tools/reduce_profiles.py $OUT
+ls $OUT
