@@ -298,3 +298,28 @@ def test_api_misuse_is_reported_not_crashed(env):
     with pytest.raises(lib.TwxError, match="month"):
         ctx.krig_points(lib.TMIN, pts, 13)
     ctx.close()
+
+
+def test_krig_every_matrix_size_bucket(env, orc):
+    """Explicit bandwidths on both sides of every kernel / template boundary (one-wave kernel: 8-row steps up
+    to 96 rows; four-wave kernel: 16-row steps up to 160 rows), with full and partial 4-column panels, a
+    pure-nugget model and a long-range one."""
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    ks = [7, 8, 9, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63, 64, 65, 71, 72, 73, 79, 80, 81, 87, 88, 89,
+          95, 96, 97, 103, 104, 105, 110, 119, 120, 121, 135, 136, 137, 147, 150, 152]
+    cells = np.argwhere(np.asarray(grid["mask"]) != 0)[::37][:len(ks)]
+    assert len(cells) == len(ks)
+    pts = _pts(ctx, grid, cells, "tmin")
+    varios = [None, (0.25, 1.4, 60.0), (0.8, 0.0, 0.0), (0.05, 2.0, 900.0)]
+    for vi, vario in enumerate(varios):
+        mth = 1 + (vi * 5) % 12
+        mean, var, used, st, _ = ctx.krig_points(lib.TMIN, pts, mth, nnghs=ks,
+                                                 vario=None if vario is None else [vario] * len(ks))
+        assert np.all(st == 0), st
+        assert np.array_equal(used, ks)
+        for i, (r, c) in enumerate(cells):
+            pt = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c],
+                             grid["lst_night"][:, r, c])
+            rc, m, v, u, _ = orc.krig(env["dbn"], env["prm"], pt, mth, nnghs=ks[i], vario=vario)
+            assert rc == 0 and u == ks[i]
+            assert abs(mean[i] - m) < TOL and abs(var[i] - v) < TOL, (ks[i], vario, mean[i], m, var[i], v)
