@@ -10,16 +10,17 @@
 // is held ENTIRELY IN REGISTERS (negated: the registers hold N = -M, so every update is a pure
 // fmac), distributed 2-D block-cyclically over the 16x16 thread grid: thread (tr, tc) owns element
 // (16a+tr, 16b+tc) of every 16x16 block (a >= b).  Right-looking Cholesky eliminates the C part in
-// PANELS of four columns, three steps per panel with a work-group barrier between them:
-//   (1) the one wavefront that holds the panel's four columns (lanes = 4 columns x 16 rows) publishes
-//       them unfactorised in LDS;
-//   (2) every thread takes ONE row of the panel, reads the 4x4 diagonal block through LDS broadcasts,
-//       factorises it redundantly (the chain of four dependent rsqrt passes through neither LDS nor
-//       another wave) and solves its row -- the same fma sequence per element as a column sweep;
-//   (3) every thread applies the rank-4 update to its own elements (all register indices
-//       compile-time).  The column factors are common to the 16 lanes of a DPP row, so each lane loads
-//       ONE of them per 16 and every v_fmac_f64 picks its operand with a row_newbcast DPP source: the
-//       update issues one LDS read per 8-16 fmacs and runs at ~85 % of the fp64 vector rate.
+// PANELS of four columns with ONE work-group barrier per panel:
+//   (1) the one wavefront that holds the panel's four columns (lanes = 4 columns x 16 rows) writes them
+//       unfactorised to LDS, reads the 4x4 diagonal block back through LDS broadcasts, factorises it
+//       (the chain of four dependent rsqrt passes through neither LDS nor another wave) and solves the
+//       panel's rows, 64 per round (one row per lane) -- the same fma sequence per element as a column
+//       sweep -- into a double-buffered slab; the other three waves are still applying the previous
+//       panel meanwhile;
+//   (2) after the barrier every thread applies the rank-4 update to its own elements (all register
+//       indices compile-time).  The column factors are common to the 16 lanes of a DPP row, so each
+//       lane loads ONE of them per 16 and every v_fmac_f64 picks its operand with a row_newbcast DPP
+//       source: the update issues one LDS read per 8-16 fmacs and runs at ~85 % of the fp64 vector rate.
 // What is left in the trailing 7x7 block is -B'C^-1 B, i.e. every inner product the GLS predictor
 // needs (X'C^-1X, X'C^-1y, X'C^-1c0, c0'C^-1c0, c0'C^-1y) -- no triangular solves.  The seven RHS
 // rows sit at the fixed rows NP-7..NP-1 so the Schur complement lands in a fixed block.
@@ -202,7 +203,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
-    __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];            // four scaled columns of the current panel, [row][4]
+    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * PS];         // four scaled columns of a panel, [row][4]; double-buffered:
+                                                                              // the next panel is factorised while this one is still being applied
     __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];             // the same four columns before the panel is factorised
     __shared__ double s_B[7][NP];
     __shared__ double s_red[4][4];
@@ -294,7 +296,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     });
 
     // ---- elimination: panels of four columns ------------------------------------------------------
-    int errf = 0;
+    int errf = 0, pbuf = 0;
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
         const int ncb = (ablate & 1) ? 0 : k - 16 * bp;      // C columns left (ablate: timing experiments only)
@@ -303,25 +305,18 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
 #pragma nounroll
             for (int s = 0; s < npan; ++s) {
                 const int ncol = min(4, ncb - 4 * s);        // real columns in this panel
-                // (1) the wave holding the panel's four columns publishes them as they are
+                // (1)+(2) the wave holding the panel's four columns: publish them as they are (LDS operations of
+                //     one wave execute in order: no barrier), read the 4x4 diagonal block back through LDS
+                //     broadcasts, factorise it (a chain of four dependent rsqrt that passes through neither LDS
+                //     nor another wave), then solve the panel's rows, 64 per round -- the same fma sequence per
+                //     element as a column-by-column sweep.  One wave, not all four: the chain is ~50 instructions
+                //     and would otherwise be issued on every SIMD.
                 if (wvp == s) {
-                    sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
-                        constexpr int a = decltype(a_)::value;
-                        s_raw[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
-                    });
-                }
-                __syncthreads();
-                // (2) every thread: its own row of the panel (one row per thread), the 4x4 diagonal block
-                //     (uniform addresses: LDS broadcasts), the block's Cholesky factor (redundantly: a chain of
-                //     four dependent rsqrt that no longer passes through LDS or another wave), then the row
-                //     solve l(i, 0..3) -- the same fma sequence per element as a column-by-column sweep.
-                const int myrow = 16 * bp + t;                       // rows 16bp .. NP-1, one per thread
-                const bool has_row = t < 16 * (NB - bp);
-                double2 n01 = {0, 0}, n23 = {0, 0};
-                if (has_row) {
-                    n01 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4]);
-                    n23 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4 + 2]);
-                }
+                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    s_raw[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
+                });
+                __builtin_amdgcn_wave_barrier();
                 const double *dg = &s_raw[(16 * bp + 4 * s) * 4];
                 const double g00 = dg[0];
                 const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
@@ -345,25 +340,35 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
                 const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
                 if (bad) errf = 1;
-                if (has_row) {
-                    double L0 = n01.x * r0;
-                    double L1 = fma(L0, l10, n01.y) * r1;
-                    double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
-                    double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
-                    const int q = t - 4 * s;                         // rows at / above the diagonal (block bp only)
-                    if (q <= 0) L0 = 0.0;
-                    if (q <= 1) L1 = 0.0;
-                    if (q <= 2) L2 = 0.0;
-                    if (q <= 3) L3 = 0.0;
-                    *reinterpret_cast<double2 *>(&s_pan[myrow * PS]) = double2{L0, L1};
-                    *reinterpret_cast<double2 *>(&s_pan[myrow * PS + 2]) = double2{L2, L3};
+                constexpr int NROW = 16 * (NB - bp), RPR = 64;
+#pragma unroll
+                for (int u = 0; u < (NROW + RPR - 1) / RPR; ++u) {
+                    const int rr = lane + RPR * u;                       // row within the panel
+                    if (rr < NROW) {
+                        const int myrow = 16 * bp + rr;
+                        const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4]);
+                        const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4 + 2]);
+                        double L0 = n01.x * r0;
+                        double L1 = fma(L0, l10, n01.y) * r1;
+                        double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                        double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
+                        const int q = rr - 4 * s;                        // rows at / above the diagonal (block bp only)
+                        if (q <= 0) L0 = 0.0;
+                        if (q <= 1) L1 = 0.0;
+                        if (q <= 2) L2 = 0.0;
+                        if (q <= 3) L3 = 0.0;
+                        *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS]) = double2{L0, L1};
+                        *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS + 2]) = double2{L2, L3};
+                    }
+                }
                 }
                 __syncthreads();
                 // (3) rank-4 update N(i,j) += l(i,:) . l(j,:).  The column factors l(16b+tc, 0..3) are common to
                 // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bp) + column) once
                 // per panel and every fmac picks its operand with row_newbcast; the row factors l(16a+tr, 0..3)
                 // are read once per block row.  LDS reads per panel: 2(NB-bp) b128 + 3 b64 per lane.
-                const double *pan = s_pan;
+                const double *pan = s_pan[pbuf];
+                pbuf ^= 1;
                 constexpr int NE = 4 * (NB - bp), NR = (NE + 15) / 16;
                 double P[NR];
                 sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
