@@ -32,9 +32,9 @@ def main():
     t1 = time.time()
     tm = ctx.timing()
     ncd = 250 * 250 * days.size * 2
-    print("host call %.1f s (D2H of %.1f GB int16), device %.2f s %s" % (
+    print("host call %.1f s (D2H of %.1f GB int16), device %.3f s %s (ms)" % (
         t1 - t0, 2 * out["daily_tmin"].nbytes / 1e9, tm["total_ms"] / 1e3,
-        {k: round(v / 1e3, 2) for k, v in tm.items() if k.endswith("_ms")}))
+        {k: round(v, 1) for k, v in tm.items() if k.endswith("_ms")}))
     print("C4 tile: %.3g cell-days/s on one GPU (device); status %s; cells with fixed days %d, max ninvalid %d" % (
         ncd / (tm["total_ms"] * 1e-3), dict(zip(*np.unique(out["status"], return_counts=True))),
         (out["ninvalid"] > 0).sum(), out["ninvalid"].max()))

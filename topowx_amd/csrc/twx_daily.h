@@ -22,6 +22,7 @@ struct GwrWs {
     double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank
     double *zc;       // [ncell][12]          pt_norm - sum_j z_j norm_j
     int32_t *gstat;   // [ncell]
+    uint32_t *noff;   // [ncell][ksel] byte offset of each ranked neighbour's observation row (k_row_offsets)
 };
 
 // ---------------------------------------------------------------------------------
@@ -145,9 +146,50 @@ __device__ __forceinline__ double daily_value(const StnDev &st, const SelWs &ws,
     const double *z = gw.z + (lc * 12 + m0) * TWX_KZ;
     const int32_t *ni = ws.near_idx + lc * ws.ksel;
     double acc = 0.0;
+#pragma unroll 8
     for (int r = 0; r < ka; ++r)
         acc = fma(z[r], (double)st.obs[(size_t)ni[r] * ndays + dm], acc);
     return acc + gw.zc[lc * 12 + m0];
+}
+
+// Tmin and Tmax of one (cell, month-major day) together: the two fma chains are independent, so twice as many
+// observation loads are in flight; each chain keeps daily_value's order, bit for bit.  When the observation
+// matrix is smaller than 4 GiB (OFF32) the element address is base + a 32-bit byte offset: the neighbours' row
+// offsets are precomputed per cell (k_row_offsets), so a step is one add, the load, one convert and the fma.
+template <bool OFF32>
+__device__ __forceinline__ void daily_value2(const StnDev &sn, const SelWs &wn, const GwrWs &gn, const StnDev &sx,
+                                             const SelWs &wx, const GwrWs &gx, int64_t lc, int m0, int ndays, int dm,
+                                             double &vn, double &vx)
+{
+    const int kn = wn.ka[lc * 12 + m0], kx = wx.ka[lc * 12 + m0];
+    const double *zn = gn.z + (lc * 12 + m0) * TWX_KZ, *zx = gx.z + (lc * 12 + m0) * TWX_KZ;
+    const int32_t *nn = wn.near_idx + lc * wn.ksel, *nx = wx.near_idx + lc * wx.ksel;
+    const float *on = sn.obs + dm, *ox = sx.obs + dm;
+    const char *bn = reinterpret_cast<const char *>(sn.obs), *bx = reinterpret_cast<const char *>(sx.obs);
+    const uint32_t *fn = gn.noff + lc * wn.ksel, *fx = gx.noff + lc * wx.ksel;   // byte offsets of the neighbours' rows
+    const unsigned dm4 = 4u * (unsigned)dm;
+    auto ldn = [&](int r) __attribute__((always_inline)) {
+        if (OFF32) return *reinterpret_cast<const float *>(bn + (fn[r] + dm4));
+        return on[(size_t)nn[r] * ndays];
+    };
+    auto ldx = [&](int r) __attribute__((always_inline)) {
+        if (OFF32) return *reinterpret_cast<const float *>(bx + (fx[r] + dm4));
+        return ox[(size_t)nx[r] * ndays];
+    };
+    double an = 0.0, ax = 0.0;
+    const int kc = min(kn, kx);
+    int r = 0;
+#pragma unroll 8
+    for (; r < kc; ++r) {
+        an = fma(zn[r], (double)ldn(r), an);
+        ax = fma(zx[r], (double)ldx(r), ax);
+    }
+#pragma unroll 4
+    for (int q = r; q < kn; ++q) an = fma(zn[q], (double)ldn(q), an);
+#pragma unroll 4
+    for (int q = r; q < kx; ++q) ax = fma(zx[q], (double)ldx(q), ax);
+    vn = an + gn.zc[lc * 12 + m0];
+    vx = ax + gx.zc[lc * 12 + m0];
 }
 
 // step25:163-164: np.round(x, 2) / np.float32(0.01) assigned into int16
@@ -180,6 +222,15 @@ __global__ __launch_bounds__(256) void k_daily_points(StnDev st, CellSrc src, Se
     }
 }
 
+// byte offset of every ranked neighbour's observation row (valid when the matrix is smaller than 4 GiB)
+__global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ws.ncell * ws.ksel) return;
+    const int j = ws.near_idx[i];
+    gw.noff[i] = j < 0 ? 0u : (uint32_t)j * (uint32_t)ndays * 4u;
+}
+
 // ---------------------------------------------------------------------------------
 // k_daily_grid: (64-cell row strip) x (month) x (64 month-major days).  Lane = day
 // (coalesced obs reads), each wave walks 16 cells; results are staged in LDS and
@@ -191,8 +242,14 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
                                                     twx_grid_out out, int32_t *flag, int nblk_max)
 {
     __shared__ int16_t s_v[2][64][66];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave index as a scalar: the cell a wave works on is then provably wave-uniform, and its hat row and
+    // neighbour indices come through scalar loads -- the only vector loads left are the observations
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SelWs &w0 = has_n ? wn : wx;
+    // both observation matrices below 4 GiB and every index / row pitch below 2^24: 32-bit element offsets
+    const bool off32 = (uint64_t)max(stn.n, stx.n) * (uint64_t)da.ndays < (1ull << 30) && max(stn.n, stx.n) < (1 << 24) &&
+                       da.ndays < (1 << 22);
     const int64_t strip = blockIdx.x;               // 64 consecutive local cells
     const int m0 = blockIdx.y / nblk_max;
     const int blk = blockIdx.y % nblk_max;
@@ -209,9 +266,12 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
         if (ok && has_x) ok = wx.cstat[lc] == 0 && wx.uk_stat[lc] == 0 && gx.gstat[lc] == 0;
         double vn = 0.0, vx = 0.0;
         if (ok && day_ok) {
-            if (has_n) vn = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
-            if (has_x) vx = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
-            if (has_n && has_x && vn >= vx) flag[lc] = 1;
+            if (has_n && has_x) {
+                if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
+                else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
+                if (vn >= vx) flag[lc] = 1;
+            } else if (has_n) vn = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
+            else vx = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
         }
         s_v[0][lane][cl] = (ok && day_ok) ? pack_i16(vn) : TWX_FILL_I2;
         s_v[1][lane][cl] = (ok && day_ok) ? pack_i16(vx) : TWX_FILL_I2;
@@ -228,8 +288,12 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
         const int dl = wv * 16 + i;
         if (dm0 + dl >= da.moff[m0 + 1]) break;
         const int64_t d = da.mm2chron[dm0 + dl];
+#ifndef TWX_ABL_NOSTORE
         if (has_n && out.daily_tmin) out.daily_tmin[d * yx + c] = s_v[0][dl][lane];
         if (has_x && out.daily_tmax) out.daily_tmax[d * yx + c] = s_v[1][dl][lane];
+#else
+        if (s_v[0][dl][lane] == 12345 && s_v[1][dl][lane] == 12346) out.daily_tmin[d * yx + c] = 1;
+#endif
     }
 }
 

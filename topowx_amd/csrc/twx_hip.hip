@@ -50,14 +50,14 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff;
     int cmax = 512;
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff})
             b->release();
     }
 };
@@ -161,6 +161,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.h0.ensure((size_t)ncell * ksel * 4));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
+        HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
     }
@@ -190,6 +191,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
+    w.gw.noff = w.noff.as<uint32_t>();
     return 0;
 }
 
@@ -924,6 +926,12 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             int32_t *d_count = d_flag + ncell;
             {
                 EvScope ev(ctx, stream, EV_DAILY);
+                for (int v = 0; v < 2; ++v)
+                    if (v == 0 ? has_n : has_x) {
+                        const SelWs &wsv = ctx->work[v].ws;
+                        hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((wsv.ncell * wsv.ksel + 255) / 256)), dim3(256), 0,
+                                           stream, wsv, ctx->work[v].gw, (int)ctx->ndays);
+                    }
                 hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
                                    stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
                                    ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk);
