@@ -890,7 +890,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
     const int ts = ctx->p.tile_cells;
     const int Y = g->Y, X = g->X;
     const int ntx = (X + ts - 1) / ts;
-    int64_t batch = ctx->p.batch_cells > 0 ? ctx->p.batch_cells : (daily ? 32768 : 262144);
+    int64_t batch = ctx->p.batch_cells > 0 ? ctx->p.batch_cells : (daily ? 32768 : 131072);
     int band = (int)std::max<int64_t>(ts, batch / X / ts * ts);
     ctx->ev_used = 0; ctx->t_cells = 0; ctx->t_solves = 0; ctx->t_launches = 0;
     HIPCHK(hipEventRecord(ctx->ev_total_a, stream));
