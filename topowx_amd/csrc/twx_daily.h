@@ -288,12 +288,8 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
         const int dl = wv * 16 + i;
         if (dm0 + dl >= da.moff[m0 + 1]) break;
         const int64_t d = da.mm2chron[dm0 + dl];
-#ifndef TWX_ABL_NOSTORE
         if (has_n && out.daily_tmin) out.daily_tmin[d * yx + c] = s_v[0][dl][lane];
         if (has_x && out.daily_tmax) out.daily_tmax[d * yx + c] = s_v[1][dl][lane];
-#else
-        if (s_v[0][dl][lane] == 12345 && s_v[1][dl][lane] == 12346) out.daily_tmin[d * yx + c] = 1;
-#endif
     }
 }
 
