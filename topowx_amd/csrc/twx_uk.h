@@ -251,6 +251,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
         if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
     }
     if (t == 0) s_err = 0;
+    for (int q = t; q < 2 * NP * PS; q += 256) (&s_pan[0][0])[q] = 0.0;   // finished rows are never written: keep them finite
     __syncthreads();
     if (t < NP) {
         double sc[4];
@@ -343,20 +344,17 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 constexpr int NROW = 16 * (NB - bp), RPR = 64;
 #pragma unroll
                 for (int u = 0; u < (NROW + RPR - 1) / RPR; ++u) {
-                    const int rr = lane + RPR * u;                       // row within the panel
+                    // only the rows below the panel are needed (by the update of live elements); the finished rows
+                    // keep whatever the slab held, which reaches finished elements only
+                    const int rr = 4 * s + 4 + lane + RPR * u;           // row within the block rows bp..
                     if (rr < NROW) {
                         const int myrow = 16 * bp + rr;
                         const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4]);
                         const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4 + 2]);
-                        double L0 = n01.x * r0;
-                        double L1 = fma(L0, l10, n01.y) * r1;
-                        double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
-                        double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
-                        const int q = rr - 4 * s;                        // rows at / above the diagonal (block bp only)
-                        if (q <= 0) L0 = 0.0;
-                        if (q <= 1) L1 = 0.0;
-                        if (q <= 2) L2 = 0.0;
-                        if (q <= 3) L3 = 0.0;
+                        const double L0 = n01.x * r0;
+                        const double L1 = fma(L0, l10, n01.y) * r1;
+                        const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                        const double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
                         *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS]) = double2{L0, L1};
                         *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS + 2]) = double2{L2, L3};
                     }

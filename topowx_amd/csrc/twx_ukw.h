@@ -90,6 +90,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             s_B[5][t] = yv[u]; s_B[6][t] = c0v[u];
         }
     }
+    for (int q = lane; q < NP * PS; q += 64) s_pan[q] = 0.0;   // finished rows are never written: keep them finite
     __syncthreads();
 
     // ---- build this lane's elements (negated: the registers hold N = -M): covariance of the cached pair
@@ -156,23 +157,20 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
             const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
             if (bad) errf = 1;
-            constexpr int NROW = NP - 16 * a0;               // rows 16 a0 .. NP-1
+            // only the rows below the panel are needed (by the update of live elements); the finished rows keep
+            // whatever the slab held, which reaches finished elements only
+            constexpr int ROW0 = 4 * b + 4, NROW = NP - ROW0;
 #pragma unroll
             for (int u = 0; u < (NROW + 63) / 64; ++u) {
                 if (u) __builtin_amdgcn_wave_barrier();      // one round's registers at a time
-                const int row = 16 * a0 + lane + 64 * u;
+                const int row = ROW0 + lane + 64 * u;
                 if (row < NP) {
                     const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[row * 4]);
                     const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[row * 4 + 2]);
-                    double L0 = n01.x * r0;
-                    double L1 = fma(L0, l10, n01.y) * r1;
-                    double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
-                    double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
-                    const int q = row - 4 * b;               // rows at / above the diagonal
-                    if (q <= 0) L0 = 0.0;
-                    if (q <= 1) L1 = 0.0;
-                    if (q <= 2) L2 = 0.0;
-                    if (q <= 3) L3 = 0.0;
+                    const double L0 = n01.x * r0;
+                    const double L1 = fma(L0, l10, n01.y) * r1;
+                    const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                    const double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
                     *reinterpret_cast<double2 *>(&s_pan[row * PS]) = double2{L0, L1};
                     *reinterpret_cast<double2 *>(&s_pan[row * PS + 2]) = double2{L2, L3};
                 }
