@@ -323,3 +323,26 @@ def test_krig_every_matrix_size_bucket(env, orc):
             rc, m, v, u, _ = orc.krig(env["dbn"], env["prm"], pt, mth, nnghs=ks[i], vario=vario)
             assert rc == 0 and u == ks[i]
             assert abs(mean[i] - m) < TOL and abs(var[i] - v) < TOL, (ks[i], vario, mean[i], m, var[i], v)
+
+
+def test_grid_many_small_batches_equal_one_batch(env, golden_case):
+    """Ragged window (37 x 57 cells, a partly masked column range) cut into many device batches (row bands of one
+    tile height) gives the same arrays, bit for bit, as one batch: batching, tile candidate lists and the per-cell
+    distance cache do not leak across band edges."""
+    lib, grid = env["lib"], dict(env["grid"])
+    mask = np.array(grid["mask"], copy=True)
+    mask[10:14, 20:31] = 0
+    grid["mask"] = mask
+    rs, cs = slice(3, 40), slice(5, 62)
+    outs = []
+    for batch in (0, 300):                       # default (one batch) vs bands of a single tile row
+        ctx = lib.Context(batch_cells=batch)
+        ctx.set_stations(lib.TMIN, golden_case[1])
+        ctx.set_stations(lib.TMAX, golden_case[2])
+        outs.append(ctx.interp_grid(grid, daily=True, rows=rs, cols=cs))
+        ctx.close()
+    a, b = outs
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    m = mask[rs, cs] != 0
+    assert np.all(a["status"][m] == 0) and np.all(a["status"][~m] == -1)
