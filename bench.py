@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the interpolation hot path on MI355X.
 
-One "step" = one pass of the hot path (twx_interp_grid_dev) over one synthetic
-250x250 30-arcsec tile with ~10k stations, 12 monthly Tmin normals + standard
-errors (BASELINE.json configs[1]); inputs are resident in HBM before the timed
-region.  With N > 1 every rank interpolates its OWN tile against a replicated
-station table (tiles partition embarrassingly): weak scaling, no
-data-path collective.
+Headline: one "step" = one pass of the hot path (twx_interp_grid_dev) over one synthetic 250x250 30-arcsec
+tile with ~10k stations, 12 monthly Tmin normals + standard errors (BASELINE.json configs[1]); inputs are
+resident in HBM before the timed region.  With N > 1 every rank interpolates its OWN tile against a replicated
+station table (tiles partition embarrassingly): weak scaling, no data-path collective.
 
-Prints ONE JSON line on rank 0 (contract in the task description) carrying
-``roofline`` (dominant kernel = k_uk, HIP-event timed inside the library on the
-launch stream) and ``cpu_baseline`` (the CPU oracle on a bounded sample of the
-same workload, all host cores).
+``python bench.py --gpus N`` without a torchrun environment starts N ranks itself (child processes through
+``python -m torch.distributed.run``, spawned before this process touches the GPU) and relays rank 0's line;
+under torchrun (WORLD_SIZE set) it is a rank.
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying
+  roofline      dominant kernels = the universal-kriging launches, HIP-event timed inside the library on the
+                launch stream; HBM as BASELINE.json asks, the binding fp64-vector figure next to it (``fp64``)
+  daily         (N = 1) the cell-DAY producing path, timed the same way: the same tile, Tmin + Tmax, normals +
+                GWR + 10 years of daily int16 values + Tmin>=Tmax fixer, outputs resident in HBM
+  cpu_baseline  (N = 1) the CPU oracle on bounded samples of the headline workload: all host cores (>= 64 cells
+                per thread) and one core
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_CELL_MONTH = 13.1   # Tmin-only normals, 61 B in + 96 B out per cell / 12
+ALG_BYTES_PER_CELL_DAY = 2.03     # int16 out + amortised inputs / observation matrix
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6       # vendor fp64 vector peak
 
@@ -36,7 +45,7 @@ def uk_flops(k):
     return k ** 3 / 3.0 + (p + 3) * k ** 2 + 60.0 * k * (k - 1) / 2.0
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -44,8 +53,49 @@ def main():
     ap.add_argument("--size", type=int, default=250, help="tile edge in cells (default: the C2 tile)")
     ap.add_argument("--nstns", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=56, help="edge of the CPU-baseline sample window")
-    args = ap.parse_args()
+    ap.add_argument("--no-daily", action="store_true", help="skip the daily (cell-days) record")
+    ap.add_argument("--daily-years", type=int, default=10, help="years of days of the daily record (1981-...)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
+    return ap.parse_args()
+
+
+def spawn(args):
+    """--gpus N outside torchrun: start N ranks as children.  Nothing in this process has touched the GPU
+    (device_count() does not initialise it), and it never re-executes itself: it waits and exits with the
+    children's code."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus:
+        # fewer GPUs than ranks (1-GPU box): control-flow run, all ranks share GPU 0, rendezvous over gloo
+        env["TWX_BENCH_SHARE_GPU"] = "1"
+        env["TWX_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def latest_traffic():
+    """HBM bytes per kriging launch from the newest committed PMC reduction (profiles/r*_bench_hbm_traffic.json)."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_hbm_traffic.json")))
+    if not paths:
+        return None, None
+    tj = json.load(open(paths[-1]))
+    traffic = tj["FETCH_SIZE"]["k_uk_per_launch_bytes"] + tj["WRITE_SIZE"]["k_uk_per_launch_bytes"]
+    src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this workload, KB units x "
+           "1024, per kriging launch; 4-byte loads of the fp32 pair-distance cache: the guide's x2 correction for "
+           "16-B/lane streaming reads does not apply)" % os.path.basename(paths[-1]))
+    return traffic, src
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -56,7 +106,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # TWX_BENCH_BACKEND=gloo + TWX_BENCH_SHARE_GPU=1: control-flow check of the N > 1 path on a 1-GPU box
     backend = os.environ.get("TWX_BENCH_BACKEND", "nccl")
-    if os.environ.get("TWX_BENCH_SHARE_GPU") == "1":
+    shared = os.environ.get("TWX_BENCH_SHARE_GPU") == "1"
+    if shared:
         local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -86,47 +137,48 @@ def main():
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     a = ctx.grid_arrays(grid)
-    d_in = {k: up(v) for k, v in a.items() if k != "lst_day"}
+    d_in = {k: up(v) for k, v in a.items()}
     d_norm = torch.full((12, Y, X), float(_lib.FILL_F4), dtype=torch.float32, device=dev)
     d_se = torch.full((12, Y, X), float(_lib.FILL_F4), dtype=torch.float32, device=dev)
     d_ninv = torch.full((Y, X), int(_lib.FILL_I4), dtype=torch.int32, device=dev)
     d_stat = torch.full((Y, X), -1, dtype=torch.int32, device=dev)
     g = _lib.TwxGrid(Y, X, d_in["mask"].data_ptr(), d_in["lat"].data_ptr(), d_in["lon"].data_ptr(),
                      d_in["elev"].data_ptr(), d_in["tdi"].data_ptr(), d_in["climdiv"].data_ptr(),
-                     d_in["lst_night"].data_ptr(), None)
+                     d_in["lst_night"].data_ptr(), d_in["lst_day"].data_ptr())
     o = _lib.TwxGridOut(d_norm.data_ptr(), d_se.data_ptr(), None, None, None, None, d_ninv.data_ptr(),
                         d_stat.data_ptr())
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        ctx.interp_grid_dev(g, o, _lib.VAR_TMIN_BIT, stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kern = []
-    for _ in range(args.steps):
-        step()
-        kern.append(ctx.timing())       # HIP events on the launch stream (synchronises this step)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(step):
+        """W untimed + K timed steps between barrier + synchronize; max over ranks; per-step kernel timings."""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        kern = []
+        for _ in range(args.steps):
+            step()
+            kern.append(ctx.timing())       # HIP events on the launch stream (synchronises this step)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, kern
 
+    elapsed, kern = timed(lambda: ctx.interp_grid_dev(g, o, _lib.VAR_TMIN_BIT, stream))
     status = d_stat.cpu().numpy()
     ncell_ok = int((status == 0).sum())
     units_per_step = ncell_ok * 12                     # (cell, month) outputs, each mean + SE
     value = world * units_per_step * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (k_uk) --------------------------------------------
+    # ---- roofline of the dominant kernels (universal kriging) ---------------------------------
     uk_ms = float(np.mean([t["uk_ms"] for t in kern]))
     launches = max(1, int(kern[-1]["uk_launches"]))
     solves = int(kern[-1]["uk_solves"])
@@ -135,18 +187,10 @@ def main():
     ks = ctx.last_bandwidths(_lib.TMIN).ravel()
     flops_per_solve = float(uk_flops(ks[ks > 0]).mean())
     ach_tflops = flops_per_solve * solves / (uk_ms * 1e-3) / 1e12
-
-    # HBM bytes per k_uk launch from the PMC passes of THIS workload (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs; summary committed under profiles/): PMC counters cannot be read
-    # from inside the process, so the committed measurement is quoted when the workload matches.
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r1_bench_hbm_traffic.json")
-    if world == 1 and args.size == 250 and args.nstns == 10000 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic = tj["FETCH_SIZE"]["k_uk_per_launch_bytes"] + tj["WRITE_SIZE"]["k_uk_per_launch_bytes"]
-        traffic_src = "profiles/r1_bench_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE, KB units x 1024, per launch; " \
-                      "4/8-byte loads: the guide's x2 wide-read correction does not apply; almost all of it is the " \
-                      "per-cell pair-distance cache that the cell's 12 monthly systems share, DESIGN.md section 4)"
+    # PMC counters cannot be read from inside the process: the committed measurement of THIS workload is quoted
+    traffic, traffic_src = (None, None)
+    if world == 1 and args.size == 250 and args.nstns == 10000:
+        traffic, traffic_src = latest_traffic()
 
     res = {
         "metric": "grid-cell-days interpolated/sec",
@@ -172,22 +216,77 @@ def main():
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},
     }
+    if shared:
+        res["note"] = "control-flow run: %d ranks share ONE GPU over gloo (fewer GPUs than ranks); not a scaling figure" % world
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload ---------------------
+    # ---- daily record: the path that produces cell-DAYS (N = 1) --------------------------------------
+    if world == 1 and not args.no_daily:
+        import datetime as dt
+        from topowx_amd.dates import get_days_metadata
+        days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + args.daily_years, 12, 31))
+        nd = int(days.size)
+        sn = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmin", days, with_obs=True)
+        sx = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmax", days, with_obs=True)
+        ctx.set_stations(_lib.TMIN, sn)
+        ctx.set_stations(_lib.TMAX, sx)
+        del sn, sx
+        outs = {k: torch.full((12, Y, X), float(_lib.FILL_F4), dtype=torch.float32, device=dev)
+                for k in ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")}
+        d_dn = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
+        d_dx = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
+        o2 = _lib.TwxGridOut(outs["norm_tmin"].data_ptr(), outs["se_tmin"].data_ptr(), outs["norm_tmax"].data_ptr(),
+                             outs["se_tmax"].data_ptr(), d_dn.data_ptr(), d_dx.data_ptr(), d_ninv.data_ptr(),
+                             d_stat.data_ptr())
+        both = _lib.VAR_TMIN_BIT | _lib.VAR_TMAX_BIT
+        el2, k2 = timed(lambda: ctx.interp_grid_dev(g, o2, both, stream))
+        ok2 = int((d_stat.cpu().numpy() == 0).sum())
+        cell_days = ok2 * nd * 2
+        tm = {k: float(np.mean([t[k] for t in k2])) for k in ("tile_cand_ms", "select_ms", "uk_ms", "gwr_ms",
+                                                              "daily_ms", "fix_ms", "total_ms")}
+        kan = ctx.last_bandwidths(_lib.TMIN).ravel()      # kriging bandwidths (GWR ones are of the same ladder)
+        dgbs = ALG_BYTES_PER_CELL_DAY * cell_days / (tm["daily_ms"] * 1e-3) / 1e9
+        res["daily"] = {
+            "value": cell_days * args.steps / el2, "unit": "cell-days/s (whole path: selection + 24 normals per cell + GWR + "
+                                                          "daily int16 + fixer, outputs resident in HBM)",
+            "workload": "the same %dx%d tile and %d stations per variable, Tmin + Tmax, %d days (%d years), int16 daily "
+                        "outputs + normals + SE + ninvalid" % (Y, X, args.nstns, nd, args.daily_years),
+            "ms_per_step": el2 / args.steps * 1e3, "cell_days_per_step": cell_days, "cells_ok": ok2,
+            "timing_ms": tm,
+            "daily_kernel": {"kernel": "k_row_offsets + k_daily_grid", "ms_per_step": tm["daily_ms"],
+                             "cell_days_per_s": cell_days / (tm["daily_ms"] * 1e-3),
+                             "roofline": {"bound": "hbm", "achieved": dgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": dgbs / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_DAY * cell_days,
+                                          "note": "gather-bound (every cell-day is a ~80-term dot product over rows "
+                                                  "of the observation matrix read through L1/L2), DESIGN.md section 4"}},
+            "mean_nnghs": float(kan[kan > 0].mean()),
+        }
+        del d_dn, d_dx
+
+    # ---- CPU baseline: the oracle on bounded samples of the headline workload ---------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         orc.build()
-        n = min(args.cpu_sample, Y)
         cores = os.cpu_count() or 1
         db = orc.Db(stn)
+        # all cores: >= 64 cells per thread so that the threads are loaded (not fork/join time)
+        n_all = args.cpu_sample or int(min(Y, max(16, np.ceil(np.sqrt(64.0 * cores)))))
         t1 = time.perf_counter()
-        ref = orc.interp_grid(db, None, orc.params(), grid, nthreads=cores, rows=slice(0, n), cols=slice(0, n))
-        dt = time.perf_counter() - t1
-        okc = int((ref["status"] == 0).sum())
-        res["cpu_baseline"] = {"value": okc * 12 / dt, "unit": "cell-months/s", "cores": cores, "kind": "port",
-                               "sample": "%dx%d cell window of the same tile, all 12 months, OpenMP over cells "
-                                         "(%.1f s wall)" % (n, n, dt)}
-        got = d_norm[:, :n, :n].cpu().numpy()
+        ref = orc.interp_grid(db, None, orc.params(), grid, nthreads=cores, rows=slice(0, n_all), cols=slice(0, n_all))
+        dt_all = time.perf_counter() - t1
+        ok_all = int((ref["status"] == 0).sum())
+        n_one = min(Y, 16)
+        t1 = time.perf_counter()
+        ref1 = orc.interp_grid(db, None, orc.params(), grid, nthreads=1, rows=slice(0, n_one), cols=slice(0, n_one))
+        dt_one = time.perf_counter() - t1
+        ok_one = int((ref1["status"] == 0).sum())
+        res["cpu_baseline"] = {
+            "value": ok_all * 12 / dt_all, "unit": "cell-months/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d cell window of the same tile (%.0f cells per thread), all 12 months, OpenMP over cells "
+                      "(%.1f s wall)" % (n_all, n_all, ok_all / cores, dt_all),
+            "single_core": {"value": ok_one * 12 / dt_one, "unit": "cell-months/s", "cores": 1,
+                            "sample": "%dx%d cell window, all 12 months (%.1f s)" % (n_one, n_one, dt_one)}}
+        got = d_norm[:, :n_all, :n_all].cpu().numpy()
         res["parity_max_abs_degC"] = float(np.abs(got.astype(np.float64) - ref["norm_tmin"]).max())
     if rank == 0:
         print(json.dumps(res), flush=True)

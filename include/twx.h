@@ -64,8 +64,13 @@ typedef struct {
     int32_t norm_yr1;        /* 2010 */
     int32_t tile_cells;      /* edge (cells) of the square candidate tile; 0 = default 8 */
     int32_t batch_cells;     /* cells per device batch; 0 = default */
-    int32_t reserved[2];
+    int32_t flags;           /* TWX_FLAG_* */
+    int32_t reserved;
 } twx_params;
+
+/* address the observation matrix with 64-bit element offsets even when it is smaller than 4 GiB (the
+ * path a > 4 GiB matrix takes; results are bit-identical -- a test / diagnostic switch) */
+#define TWX_FLAG_OBS_ADDR64 1
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
  * StationSelect's isnan(bad) mask: station_data.py:126-183,609,

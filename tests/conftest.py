@@ -19,6 +19,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_xval():
+    """Cross-validation goldens (tests/golden/make_golden_xval.py; same seeded inputs as ``golden``)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_xval_v1.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_case(golden):
     """The seeded inputs the goldens were generated on (hash-checked)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -99,6 +99,42 @@ def test_xval_callers(case, golden):
     xa.close()
 
 
+def test_xval_tair_anom_vs_executed_reference(case, golden_xval, orc):
+    """XvalTairAnom.run_xval (optimize.py:505-545) over the full 16-bandwidth ladder against the goldens made by
+    executing the reference's own run_xval, and the raw step23 call shape -- twx_gwr_points with explicit nnghs,
+    the station's own index excluded and rm_zero_dist -- against executed gwr_mth series and the oracle."""
+    from topowx_amd import _lib, stationdb as sdb
+    from topowx_amd.interp import XvalTairAnom
+    g = golden_xval
+    grid, tmin, _ = case
+    good = np.isnan(tmin.stns[sdb.BAD])
+    good_ids = tmin.stns[sdb.STN_ID][good]
+    xa = XvalTairAnom(tmin, "tmin")
+    for i, j in enumerate(g["xa_stn"]):
+        bias, mae, r2 = xa.run_xval(good_ids[j], g["xa_ladder"])
+        assert bias.shape == (16, 12)
+        assert np.abs(bias - g["xa_bias"][i]).max() < 1e-4 and np.abs(mae - g["xa_mae"][i]).max() < 1e-4
+        assert np.abs(r2 - g["xa_r2"][i]).max() < 1e-6
+    # raw C-ABI call in the step23 shape
+    ctx = xa.ctx
+    db, prm = orc.Db(tmin), orc.params()
+    c = db.cols
+    j, k, m = g["gx_probe"].T
+    pts = ctx.make_pts(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j].T)
+    pn = c["norm"][m - 1, j]
+    out, used, st = ctx.gwr_points(_lib.TMIN, pts, pn, m, nnghs=k, excl=j, rm_zero_dist=True)
+    assert np.all(st == 0) and np.array_equal(used, k)
+    for q in range(j.size):
+        nd = tmin.mth_idx[int(m[q])].size
+        assert np.abs(out[q, :nd] - g["gx_series"][q, :nd]).max() < 1e-4            # executed reference
+        pt = orc.make_pt(c["lon"][j[q]], c["lat"][j[q]], c["elev"][j[q]], c["tdi"][j[q]], c["lst"][:, j[q]])
+        rc, want, ku, _, idx = orc.gwr_mth(db, prm, pt, pn[q], int(m[q]), nnghs=int(k[q]), excl=int(j[q]),
+                                           rm_zero_dist=True)
+        assert rc == 0 and ku == k[q] and j[q] not in idx
+        assert np.abs(out[q, :nd] - want).max() < 1e-6                              # oracle, same arithmetic
+    xa.close()
+
+
 def test_variogram_fit_and_krigall(case, orc):
     """BuildKrigParams.get_krig_params / KrigTairAll.krigall / XvalTairNorm /
     StationKrigParams against the oracle's restatement of R get_vario_params (parity with gstat unpinned)."""

@@ -160,3 +160,32 @@ def test_interp_pt_both_variables(orc, golden, golden_case, dbs, pre):
             # 1e-6 degC differences can flip one LSB at a 0.005 rounding boundary
             assert np.max(np.abs(got.astype(int) - want.astype(int))) <= 1
             assert np.mean(got == want) > 0.999
+
+
+def test_xval_anom_oracle_vs_executed_run_xval(orc, golden_xval, golden_case):
+    """a13: the step23 call shape -- gwr_mth(stn, mth, nnghs, stns_rm = own id) on a
+    StationSelect(rm_zero_dist_stns=True) -- and the bias / MAE / r^2 of XvalTairAnom.run_xval
+    (optimize.py:505-545), against goldens made by executing the reference's own code."""
+    g = golden_xval
+    _, tmin, _ = golden_case
+    db, prm = orc.Db(tmin), orc.params()
+    c = db.cols
+    for q, (j, k, m) in enumerate(g["gx_probe"]):
+        pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+        rc, out, ku, _, idx = orc.gwr_mth(db, prm, pt, c["norm"][m - 1, j], int(m), nnghs=int(k), excl=int(j),
+                                          rm_zero_dist=True)
+        assert rc == 0 and ku == k and j not in idx
+        np.testing.assert_allclose(out, g["gx_series"][q, :out.size], rtol=0, atol=1e-9)
+    # full ladder for one station: the statistics as the reference computes them
+    j = int(g["xa_stn"][1])
+    pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+    for x, k in enumerate(g["xa_ladder"]):
+        for m in range(1, 13):
+            nrm = c["norm"][m - 1, j]
+            rc, out, _, _, _ = orc.gwr_mth(db, prm, pt, nrm, m, nnghs=int(k), excl=j, rm_zero_dist=True)
+            assert rc == 0
+            xval_anom = db.obs[db.day_month == m, j].astype(np.float64) - nrm
+            difs = (out - nrm) - xval_anom
+            assert abs(difs.mean() - g["xa_bias"][1][x, m - 1]) < 1e-6
+            assert abs(np.abs(difs).mean() - g["xa_mae"][1][x, m - 1]) < 1e-6
+            assert abs(np.corrcoef(out - nrm, xval_anom)[0, 1] ** 2 - g["xa_r2"][1][x, m - 1]) < 1e-9

@@ -2,6 +2,7 @@
 # Collect the round's bench line, the rocprofv3 kernel summary and the two HBM-traffic PMC passes of bench.py
 # (run on the GPU box from the repo root: `gpurun -- bash tests/tools/collect_profiles.sh`); everything lands in
 # gpurun_out/prof_round/ and is reduced by tests/tools/reduce_profiles.py into the files kept under profiles/.
+# The PMC passes carry --kernel-trace only (no other trace domain), one counter per pass.
 set -u
 OUT=gpurun_out/prof_round
 mkdir -p $OUT

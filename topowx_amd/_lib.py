@@ -21,6 +21,7 @@ MAX_NNGHS = 152
 FILL_I2 = np.int16(-32767)
 FILL_F4 = np.float32(9.969209968386869e36)
 FILL_I4 = np.int32(-2147483647)
+FLAG_OBS_ADDR64 = 1
 
 CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)",
                2: "Cannot determine the optimal # of neighbors to use!",
@@ -39,7 +40,7 @@ _bp = C.POINTER(C.c_uint8)
 class TwxParams(C.Structure):
     _fields_ = [("init_nnghs", C.c_int32), ("fixer_tail", C.c_int32), ("norm_yr0", C.c_int32),
                 ("norm_yr1", C.c_int32), ("tile_cells", C.c_int32), ("batch_cells", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TwxStationTable(C.Structure):
@@ -134,9 +135,9 @@ class Context(object):
     """One GPU context (twx_create / twx_destroy)."""
 
     def __init__(self, device=0, init_nnghs=100, fixer_tail=15, norm_years=(1981, 2010), tile_cells=0,
-                 batch_cells=0):
+                 batch_cells=0, flags=0):
         self.lib = load()
-        prm = TwxParams(init_nnghs, fixer_tail, norm_years[0], norm_years[1], tile_cells, batch_cells)
+        prm = TwxParams(init_nnghs, fixer_tail, norm_years[0], norm_years[1], tile_cells, batch_cells, flags, 0)
         h = C.c_void_p()
         rc = self.lib.twx_create(C.c_int(device), C.byref(prm), C.byref(h))
         if rc != 0:

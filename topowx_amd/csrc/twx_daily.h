@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
     const double plst = cell_lst(src, c, m0);
     const double dbw = ws.near_dist[lc * ws.ksel + ka];
     double row[3][6], w[3], nrm[3];
-    double mx[5] = {0, 0, 0, 0, 0};
+    double mx[5] = {0, 0, 0, 0, 0}, rawmx[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         int r = lane + 64 * s;
@@ -60,20 +60,26 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             int j = ws.near_idx[lc * ws.ksel + r];
             w[s] = bisq(ws.near_dist[lc * ws.ksel + r], dbw);
             row[s][0] = 1.0;
-            row[s][1] = st.lon[j] - cv.lon; row[s][2] = st.lat[j] - cv.lat;
-            row[s][3] = st.elev[j] - cv.elev; row[s][4] = st.tdi[j] - cv.tdi;
-            row[s][5] = st.lst[m0 * n + j] - plst;
+            const double raw[5] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j], st.lst[m0 * n + j]};
+            row[s][1] = raw[0] - cv.lon; row[s][2] = raw[1] - cv.lat;
+            row[s][3] = raw[2] - cv.elev; row[s][4] = raw[3] - cv.tdi;
+            row[s][5] = raw[4] - plst;
             nrm[s] = st.norm[m0 * n + j];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) mx[q] = fmax(mx[q], fabs(row[s][1 + q]));
+            for (int q = 0; q < 5; ++q) { mx[q] = fmax(mx[q], fabs(row[s][1 + q])); rawmx[q] = fmax(rawmx[q], fabs(raw[q])); }
         }
     }
+    bool bad = false;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         double s = wave_max(mx[q]);
         s = s > 0.0 ? 1.0 / s : 1.0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) row[u][1 + q] *= s;
+        // a predictor that is exactly zero at every neighbour (e.g. TDI on flat terrain) gives X'WX an exactly
+        // zero row: np.linalg.inv raises (interp_tair.py:1139) -- with the columns shifted to the cell that case
+        // would otherwise only be collinear, which rounding can hide from the Cholesky pivots below
+        if (wave_max(rawmx[q]) == 0.0) bad = true;
     }
     // M = X'WX (lower triangle, 21 sums)
     double M[6][6];
@@ -87,7 +93,6 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             M[a][b] = wave_sum(s);
         }
     }
-    bool bad = false;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                     GwrWs gn, GwrWs gx, int has_n, int has_x, DayAxis da,
-                                                    twx_grid_out out, int32_t *flag, int nblk_max)
+                                                    twx_grid_out out, int32_t *flag, int nblk_max, int addr64)
 {
     __shared__ int16_t s_v[2][64][66];
     const int lane = threadIdx.x & 63;
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SelWs &w0 = has_n ? wn : wx;
     // both observation matrices below 4 GiB and every index / row pitch below 2^24: 32-bit element offsets
-    const bool off32 = (uint64_t)max(stn.n, stx.n) * (uint64_t)da.ndays < (1ull << 30) && max(stn.n, stx.n) < (1 << 24) &&
-                       da.ndays < (1 << 22);
+    const bool off32 = !addr64 && (uint64_t)max(stn.n, stx.n) * (uint64_t)da.ndays < (1ull << 30) &&
+                       max(stn.n, stx.n) < (1 << 24) && da.ndays < (1 << 22);
     const int64_t strip = blockIdx.x;               // 64 consecutive local cells
     const int m0 = blockIdx.y / nblk_max;
     const int blk = blockIdx.y % nblk_max;

@@ -84,6 +84,11 @@ struct twx_ctx {
     hipEvent_t ev_agg_a = nullptr, ev_agg_b = nullptr;
     // scratch for the point entries / fixer
     DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list;
+    // every context-level device buffer (the per-variable ones live in var[] / work[]): twx_destroy releases these
+    std::vector<DevBuf *> all_bufs()
+    {
+        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list};
+    }
     std::string err;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
@@ -177,11 +182,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
     s.ncand_max = w.small.as<int32_t>();          // [0]
     s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16..31]
-    {
-        // largest k handled by the one-wave kernel (k + 8 <= 96 rows); tuning knob, measured on the C2 bench
-        static const int small_kmax = getenv("TWX_UKW_MAXK") ? atoi(getenv("TWX_UKW_MAXK")) : 88;
-        s.small_kmax = std::min(std::max(small_kmax, 0), 88);
-    }
+    s.small_kmax = TWX_UKW_MAXK;   // largest k handled by the one-wave kernel (k + 8 <= 96 rows; measured on the C2 bench)
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
     s.nnear = w.nnear.as<int32_t>(); s.kk = w.kk.as<int32_t>(); s.ka = w.ka.as<int32_t>();
@@ -198,8 +199,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
 template <int NB>
 void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
 {
-    static const int ablate = getenv("TWX_UK_ABLATE") ? atoi(getenv("TWX_UK_ABLATE")) : 0;  // timing experiments only
-    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt, ablate);
+    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt);
 }
 
 template <int NBR, int HALF>
@@ -342,9 +342,7 @@ void twx_destroy(twx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (int v = 0; v < 2; ++v) { ctx->var[v].cols.release(); ctx->var[v].obs.release(); ctx->work[v].release(); }
-    for (DevBuf *b : {&ctx->day_dev, &ctx->pt_in, &ctx->pt_aux, &ctx->pt_out, &ctx->fix_scratch, &ctx->fix_lists,
-                      &ctx->flags, &ctx->flag_list})
-        b->release();
+    for (DevBuf *b : ctx->all_bufs()) b->release();
     for (auto &e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->ev_total_a) (void)hipEventDestroy(ctx->ev_total_a);
     if (ctx->ev_total_b) (void)hipEventDestroy(ctx->ev_total_b);
@@ -356,6 +354,7 @@ void twx_destroy(twx_ctx *ctx)
 int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const int32_t *day_year)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (ndays <= 0 || !day_month || !day_year) return fail(ctx, "twx_set_days: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     for (int v = 0; v < 2; ++v)
@@ -432,6 +431,7 @@ int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const in
 int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (var < 0 || var > 1 || !t || t->n <= 0) return fail(ctx, "twx_set_stations: bad arguments");
     if (t->n > (1 << 24)) return fail(ctx, "twx_set_stations: too many stations");
     HIPCHK(hipSetDevice(ctx->device));
@@ -542,6 +542,7 @@ int twx_knn(twx_ctx *ctx, int var, int64_t npts, const double *lon, const double
             const int32_t *excl, int rm_zero_dist, int32_t *idx, double *dist, double *wgt, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (check_var(ctx, var, false)) return -1;
     if (npts <= 0 || !lon || !lat || !idx || k < 1 || k >= TWX_KSEL_MAX) return fail(ctx, "twx_knn: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -569,6 +570,7 @@ int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, cons
                     double *mean, double *variance, int32_t *nnghs_used, int32_t *ngh_idx, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (check_var(ctx, var, false)) return -1;
     if (npts <= 0 || !pts || !mth || !mean || !variance || !status) return fail(ctx, "twx_krig_points: bad arguments");
     for (int64_t i = 0; i < npts; ++i)
@@ -608,6 +610,7 @@ int twx_fit_vario_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,
                          int32_t *nnghs_used, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (check_var(ctx, var, false)) return -1;
     if (npts <= 0 || !pts || !mth || !vario || !status) return fail(ctx, "twx_fit_vario_points: bad arguments");
     for (int64_t i = 0; i < npts; ++i)
@@ -641,6 +644,7 @@ int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const
                    double *out, int64_t ld, int32_t *nnghs_used, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (check_var(ctx, var, true)) return -1;
     if (npts <= 0 || !pts || !mth || !pt_norm || !out || !status) return fail(ctx, "twx_gwr_points: bad arguments");
     int maxd = 0;
@@ -680,6 +684,7 @@ int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, co
                       int rm_zero_dist, double *daily, double *norms, double *se, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (check_var(ctx, var, daily != nullptr)) return -1;
     if (npts <= 0 || !pts || !norms || !se || !status) return fail(ctx, "twx_interp_points: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -713,7 +718,16 @@ int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, co
         if (status[i]) continue;
         std::memcpy(norms + i * 12, hn.data() + i * 12, 96);
         std::memcpy(se + i * 12, hs.data() + i * 12, 96);
-        if (daily) HIPCHK(hipMemcpy(daily + i * nd, d_daily + i * nd, (size_t)nd * 8, hipMemcpyDeviceToHost));
+    }
+    if (daily) {
+        // one copy per run of consecutive successful points (failed points keep the caller's values)
+        for (int64_t i = 0; i < npts;) {
+            if (status[i]) { ++i; continue; }
+            int64_t j = i;
+            while (j < npts && status[j] == 0) ++j;
+            HIPCHK(hipMemcpy(daily + i * nd, d_daily + i * nd, (size_t)(j - i) * nd * 8, hipMemcpyDeviceToHost));
+            i = j;
+        }
     }
     return 0;
 }
@@ -722,6 +736,7 @@ int twx_fix_pair(twx_ctx *ctx, int64_t nseries, double *tmin, double *tmax, int3
                  double *norm_tmax, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (nseries <= 0 || !tmin || !tmax || !ninvalid || !status) return fail(ctx, "twx_fix_pair: bad arguments");
     if (ctx->ndays <= 0) return fail(ctx, "twx_fix_pair: call twx_set_days first");
     HIPCHK(hipSetDevice(ctx->device));
@@ -761,6 +776,7 @@ int twx_fix_pair(twx_ctx *ctx, int64_t nseries, double *tmin, double *tmax, int3
 int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (n <= 0 || !x || !out) return fail(ctx, "twx_pack_i16: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(ctx->pt_out.ensure((size_t)n * 10 + 512));
@@ -777,6 +793,7 @@ int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out)
 int twx_aggregate_dims(twx_ctx *ctx, int32_t *nyr, int32_t *nmth)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (ctx->ndays <= 0) return fail(ctx, "twx_aggregate_dims: call twx_set_days first");
     if (nyr) *nyr = ctx->agg.nyr;
     if (nmth) *nmth = ctx->agg.nmth;
@@ -787,6 +804,7 @@ int twx_aggregate(twx_ctx *ctx, const void *daily, int dtype, int64_t ncell, int
                   int16_t *mthly_i16, double *ann, void *hip_stream, float *kernel_ms)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (!daily || ncell <= 0 || dtype < TWX_DT_I16 || dtype > TWX_DT_F64 || (!mthly && !mthly_i16 && !ann))
         return fail(ctx, "twx_aggregate: bad arguments");
     if (ctx->ndays <= 0) return fail(ctx, "twx_aggregate: call twx_set_days first");
@@ -842,6 +860,7 @@ int twx_sample_points(twx_ctx *ctx, const twx_raster *r, int64_t npts, const dou
                       int order, double missing, double *val, int32_t *row, int32_t *col, int32_t *status)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (!r || r->nrows < 2 || r->ncols < 2 || !r->lon || !r->lat || !r->data || npts <= 0 || !lon || !lat || !val ||
         order < 0 || order > 1)
         return fail(ctx, "twx_sample_points: bad arguments");
@@ -876,13 +895,16 @@ int twx_sample_points(twx_ctx *ctx, const twx_raster *r, int64_t npts, const dou
 int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int vars, void *hip_stream)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (!g || !o || g->Y <= 0 || g->X <= 0 || !g->mask || !g->lat || !g->lon || !g->elev || !g->tdi)
         return fail(ctx, "twx_interp_grid: bad grid");
     const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
     if (!has_n && !has_x) return fail(ctx, "twx_interp_grid: no variable requested");
     const bool daily = (has_n && o->daily_tmin) || (has_x && o->daily_tmax);
-    if (has_n && (check_var(ctx, TWX_TMIN, daily) || !g->lst_night)) return ctx->err.empty() ? fail(ctx, "lst_night missing") : -1;
-    if (has_x && (check_var(ctx, TWX_TMAX, daily) || !g->lst_day)) return ctx->err.empty() ? fail(ctx, "lst_day missing") : -1;
+    if (has_n && check_var(ctx, TWX_TMIN, daily)) return -1;
+    if (has_x && check_var(ctx, TWX_TMAX, daily)) return -1;
+    if (has_n && !g->lst_night) return fail(ctx, "twx_interp_grid: lst_night missing (Tmin predictor)");
+    if (has_x && !g->lst_day) return fail(ctx, "twx_interp_grid: lst_day missing (Tmax predictor)");
     if (daily && has_n && has_x && (!o->daily_tmin || !o->daily_tmax))
         return fail(ctx, "twx_interp_grid: with both variables and daily output both daily buffers are needed (fixer)");
     HIPCHK(hipSetDevice(ctx->device));
@@ -913,7 +935,9 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
         }
         const CellSrc &s0 = has_n ? src[0] : src[1];
         hipLaunchKernelGGL(k_finalize_grid, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, s0,
-                           ctx->work[0].ws, ctx->work[1].ws, (int)has_n, (int)has_x, *o, 1);
+                           ctx->work[0].ws, ctx->work[1].ws, (int)has_n, (int)has_x,
+                           (daily && has_n) ? ctx->work[0].gw.gstat : nullptr,
+                           (daily && has_x) ? ctx->work[1].gw.gstat : nullptr, *o, 1);
         ctx->t_cells += ncell;
         if (daily) {
             int maxd = 0;
@@ -934,7 +958,8 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                     }
                 hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
                                    stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
-                                   ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk);
+                                   ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk,
+                                   (ctx->p.flags & TWX_FLAG_OBS_ADDR64) ? 1 : 0);
             }
             if (has_n && has_x) {
                 hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_flag,
@@ -964,6 +989,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
 int twx_interp_grid(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int vars)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (!g || !o || g->Y <= 0 || g->X <= 0) return fail(ctx, "twx_interp_grid: bad grid");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t yx = (size_t)g->Y * g->X, nd = (size_t)ctx->ndays;
@@ -1040,6 +1066,7 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
 int64_t twx_last_bandwidths(twx_ctx *ctx, int var, int32_t *nnghs, int64_t capacity)
 {
     if (!ctx) return -1;
+    ctx->err.clear();
     if (var < 0 || var > 1 || !nnghs || capacity < 0) return fail(ctx, "twx_last_bandwidths: bad arguments");
     const SelWs &ws = ctx->work[var].ws;
     if (!ws.kk || ws.ncell <= 0) return fail(ctx, "twx_last_bandwidths: nothing computed yet");

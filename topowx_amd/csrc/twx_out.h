@@ -5,8 +5,11 @@
 // Grid epilogue (step25:154-172): a cell is written only if BOTH requested
 // variables succeeded; normals / SE cast to f4, SE = sqrt(max(var, 0))
 // (KrigTair.std_err_ci, interp_tair.py:816).
+// gstat_n / gstat_x: GWR status of the batch (k_gwr_z; null when no daily output is asked for).  A cell
+// whose hat row cannot be formed (np.linalg.inv raises in _gwr_series, interp_tair.py:1139) is abandoned as a
+// whole by the worker: normals, SE and ninvalid stay at fill, exactly like a kriging failure.
 __global__ void k_finalize_grid(CellSrc src, SelWs wn, SelWs wx, int has_n, int has_x,
-                                twx_grid_out out, int write_ninvalid)
+                                const int32_t *gstat_n, const int32_t *gstat_x, twx_grid_out out, int write_ninvalid)
 {
     const int64_t lc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const SelWs &w0 = has_n ? wn : wx;
@@ -20,6 +23,8 @@ __global__ void k_finalize_grid(CellSrc src, SelWs wn, SelWs wx, int has_n, int 
     int s = 0;
     if (has_n) s = wn.cstat[lc] ? wn.cstat[lc] : wn.uk_stat[lc];
     if (!s && has_x) s = wx.cstat[lc] ? wx.cstat[lc] : wx.uk_stat[lc];
+    if (!s && has_n && gstat_n) s = gstat_n[lc];
+    if (!s && has_x && gstat_x) s = gstat_x[lc];
     if (out.status) out.status[c] = s;
     if (s) return;
     for (int m = 0; m < 12; ++m) {

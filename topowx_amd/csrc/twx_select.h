@@ -11,6 +11,7 @@
 #include "twx_device.h"
 
 #define TWX_UK_SLEN 29
+#define TWX_UKW_MAXK 88                                            // largest k of the one-wave kriging kernel
 #define TWX_DIST_NB ((TWX_MAX_NNGHS + 15) / 16)                 // block rows of the distance cache
 #define TWX_DIST_BLOCKS (TWX_DIST_NB * (TWX_DIST_NB + 1) / 2)
 

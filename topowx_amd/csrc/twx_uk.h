@@ -199,7 +199,7 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 template <int NB>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
-void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems, int ablate)
+void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
@@ -287,8 +287,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
             if (i < k && j < k) {
                 if (i == j) v = c00;
                 else {
-                    const float hh = (ablate & 2) ? 1.f : h[b];
-                    v = hh == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(hh, chi, clo));
+                    v = h[b] == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h[b], chi, clo));
                 }
             }
             if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1
@@ -300,7 +299,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     int errf = 0, pbuf = 0;
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
-        const int ncb = (ablate & 1) ? 0 : k - 16 * bp;      // C columns left (ablate: timing experiments only)
+        const int ncb = k - 16 * bp;                         // C columns left
         if (ncb > 0) {
             const int npan = min(4, (ncb + 3) >> 2);
 #pragma nounroll

@@ -47,9 +47,13 @@ class XvalTairOverall(_XvalBase):
         d, n, s = self.run_interp_many([stn_id])
         return d[0], n[0], s[0]
 
-    def run_interp_many(self, stn_ids, daily=True):
+    def run_interp_many(self, stn_ids, daily=True, raise_on_error=True):
+        """Batched form.  ``raise_on_error=False`` is the step24 worker's behaviour (step24:52-62): a station that
+        cannot be interpolated keeps NaN outputs and its TWX_CELL_* code is returned as a fourth array."""
         j, pts = self._pts(stn_ids)
         d, norms, se, st = self.ctx.interp_points(self.var, pts, excl=j, rm_zero_dist=True, daily=daily)
+        if not raise_on_error:
+            return d, norms, se, st
         for s in st:
             raise_for_status(s)
         return d, norms, se
