@@ -3,6 +3,9 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- FIRST: the PyTorch ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1;
+#                 whichever HIP runtime is loaded first serves the whole process (same SONAME), and torch finds no
+#                 GPU when it is handed the system runtime that libtwxhip.so would otherwise pull in
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

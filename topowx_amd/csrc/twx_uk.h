@@ -83,17 +83,12 @@ __device__ __forceinline__ void fmac_rowbcast(double &acc, double p, double u)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(u), "n"(N));
 }
 
-// psill * exp(-h / range) with the exponent carried as an fp32 hi/lo pair:
-// t = h * (chi + clo) = -h / range * log2(e); 2^t = 2^n * 2^f.  Relative error ~1e-7.
-__device__ __forceinline__ float exp2_neg_split(float h, float chi, float clo)
+// exp(-h / range) = 2^(h * c), c = -log2(e) / range, in fp32: the product carries a relative error of 2^-24, i.e.
+// |t| * 6e-8 in the exponent and at most 2e-8 * psill absolute on the covariance (largest at t = -1.44);
+// v_exp_f32 itself is good to 1 ulp.  Far inside the 1e-4 degC bar (measured: DESIGN.md section 2).
+__device__ __forceinline__ float exp2_neg(float h, float c)
 {
-    float thi = h * chi;
-    float e1 = fmaf(h, chi, -thi);
-    float tlo = fmaf(h, clo, e1);
-    float n = rintf(thi);
-    float f = (thi - n) + tlo;
-    float e = __builtin_amdgcn_exp2f(f);
-    return ldexpf(e, (int)fmaxf(n, -160.f));
+    return __builtin_amdgcn_exp2f(h * c);
 }
 
 // far pairs (> ~1300 km): full fp64 formula; kept out of line so that the (never taken in practice)
@@ -210,7 +205,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     __shared__ double s_red[4][4];
     __shared__ int s_err;
 
-    const int t = threadIdx.x, tr = t & 15, lane = t & 63, wv = t >> 6, tcl = lane >> 4;
+    const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: branches on the wave's role are s_cbranch
     // Which wave holds which four columns of a block is rotated per work-group: the work-groups resident on
     // a CU run in near lockstep, and without the rotation their panel factorisations (one wave each) would
     // all queue on the same SIMD while the other three idle.
@@ -231,8 +227,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
     const double c00 = nug + psill;
     const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
-    const float chi = (float)c2, clo = (float)(c2 - (double)chi);
-    const int nbk = (k + 15) >> 4;               // block rows holding C rows
+    const float chi = (float)c2;
+    const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
 
     // ---- staging: one neighbour per thread (NP <= 160 < 256) ------------------------------
     double x0 = 0, x1 = 0, x2 = 0, x3 = 0, yv = 0, c0v = 0;
@@ -244,7 +240,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
         // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
         const float h0 = ws.h0[lc * ws.ksel + t];
         const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-        c0v = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
+        c0v = same ? c00 : psill_e * (double)exp2_neg(h0, chi);
     }
     {
         double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
@@ -283,20 +279,18 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
         sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 16 * b + tc;
-            double v = 0.0;
-            if (i < k && j < k) {
-                if (i == j) v = c00;
-                else {
-                    v = h[b] == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h[b], chi, clo));
-                }
-            }
+            // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
+            // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
+            double v = (a == b && tr == tc && !(a == NB - 1 && tr >= 9)) ? 1.0 : 0.0;
+            if (i < k && j < k) v = (i == j || h[b] == 0.f) ? c00 : psill_e * (double)exp2_neg(h[b], chi);
             if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1
             A[tri(a, b)] = -v;                               // the registers hold N = -M: updates are pure fmacs
         });
     });
 
     // ---- elimination: panels of four columns ------------------------------------------------------
-    int errf = 0, pbuf = 0;
+    int pbuf = 0;
+    double dmin = 1.0;                                       // smallest pivot this wave has factorised
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
         const int ncb = k - 16 * bp;                         // C columns left
@@ -304,13 +298,14 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
             const int npan = min(4, (ncb + 3) >> 2);
 #pragma nounroll
             for (int s = 0; s < npan; ++s) {
-                const int ncol = min(4, ncb - 4 * s);        // real columns in this panel
                 // (1)+(2) the wave holding the panel's four columns: publish them as they are (LDS operations of
                 //     one wave execute in order: no barrier), read the 4x4 diagonal block back through LDS
                 //     broadcasts, factorise it (a chain of four dependent rsqrt that passes through neither LDS
                 //     nor another wave), then solve the panel's rows, 64 per round -- the same fma sequence per
-                //     element as a column-by-column sweep.  One wave, not all four: the chain is ~50 instructions
-                //     and would otherwise be issued on every SIMD.
+                //     element as a column-by-column sweep.  One wave, not all four: the chain is ~30 instructions
+                //     and would otherwise be issued on every SIMD.  A non-positive pivot gives NaN factors that
+                //     reach the Schur block (k_uk_solve rejects non-finite results); too small a pivot is caught
+                //     through dmin at the end.
                 if (wvp == s) {
                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value;
@@ -324,22 +319,19 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 const double g22 = dg[10];
                 const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
                 const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
-                bool bad = false;
                 // the registers hold N = -M: pivot d = -n, l = n * (-1/sqrt(d)), updates n += l l
-                auto pivot = [&](double nd, bool valid) __attribute__((always_inline)) {
+                auto pivot = [&](double nd) __attribute__((always_inline)) {
                     const double d = -nd;
-                    const bool b = !(d > 1e-9 * c00) || !finite_d(d);   // singular / indefinite system
-                    bad = bad || (valid && b);
-                    return (valid && !b) ? -rsqrt_nr(d) : 0.0;
+                    dmin = fmin(dmin, d);
+                    return -rsqrt_nr(d);
                 };
-                const double r0 = pivot(g00, true);
+                const double r0 = pivot(g00);
                 const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
-                const double r1 = pivot(fma(l10, l10, g1.y), ncol > 1);
+                const double r1 = pivot(fma(l10, l10, g1.y));
                 const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
-                const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)), ncol > 2);
+                const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
                 const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
-                const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
-                if (bad) errf = 1;
+                const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))));
                 constexpr int NROW = 16 * (NB - bp), RPR = 64;
 #pragma unroll
                 for (int u = 0; u < (NROW + RPR - 1) / RPR; ++u) {
@@ -364,9 +356,12 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bp) + column) once
                 // per panel and every fmac picks its operand with row_newbcast; the row factors l(16a+tr, 0..3)
                 // are read once per block row.  LDS reads per panel: 2(NB-bp) b128 + 3 b64 per lane.
+                // In the panel's own block column only the waves holding columns right of the panel (wvp > s)
+                // still have live elements: the others skip it (a scalar branch).
                 const double *pan = s_pan[pbuf];
                 pbuf ^= 1;
                 constexpr int NE = 4 * (NB - bp), NR = (NE + 15) / 16;
+                const bool own_live = wvp > s;
                 double P[NR];
                 sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
@@ -377,7 +372,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                     constexpr int a = decltype(a_)::value;
                     const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
                     const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
-                    sfor<bp, a + 1>([&](auto b_) __attribute__((always_inline)) {
+                    if (own_live) {
+                        double acc = A[tri(a, bp)];
+                        fmac_rowbcast<0>(acc, P[0], u0.x);
+                        fmac_rowbcast<1>(acc, P[0], u0.y);
+                        fmac_rowbcast<2>(acc, P[0], u1.x);
+                        fmac_rowbcast<3>(acc, P[0], u1.y);
+                        A[tri(a, bp)] = acc;
+                    }
+                    sfor<bp + 1, a + 1>([&](auto b_) __attribute__((always_inline)) {
                         constexpr int b = decltype(b_)::value;
                         constexpr int e = 4 * (b - bp);
                         double acc = A[tri(a, b)];
@@ -391,7 +394,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
             }
         }
     });
-    if (errf && t == 0) s_err = 1;
+    if (!(dmin > 1e-9 * c00)) s_err = 1;                     // singular / indefinite system (benign race: all write 1)
 
     // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
     if (tr >= 9 && tc >= 9 && tr >= tc) {

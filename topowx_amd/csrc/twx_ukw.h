@@ -56,7 +56,8 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
     const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
     const double c00 = nug + psill;
     const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
-    const float chi = (float)c2, clo = (float)(c2 - (double)chi);
+    const float chi = (float)c2;
+    const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
 
     // ---- staging: neighbours t = lane, lane + 64 (NP <= 96) -----------------------------------
     double xs[2][4], yv[2], c0v[2];
@@ -73,7 +74,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             yv[u] = st.norm[m0 * n + j];
             const float h0 = ws.h0[lc * ws.ksel + t];          // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v[u] = same ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h0, chi, clo));
+            c0v[u] = same ? c00 : psill_e * (double)exp2_neg(h0, chi);
             e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
             e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
         }
@@ -110,23 +111,21 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
         sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 4 * b + tc;
-            double v = 0.0;
-            if (i < k && j < k) {
-                if (i == j) v = c00;
-                else if (j < i) v = h[b] == 0.f ? c00 : (rng == 0.0 ? 0.0 : psill * (double)exp2_neg_split(h[b], chi, clo));
-            }
+            // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
+            // panel (pivot 1, factors 0), so the panel step has no special cases
+            double v = (i == j && i < RHS0) ? 1.0 : 0.0;
+            if (i < k && j <= i) v = (i == j || h[b] == 0.f) ? c00 : psill_e * (double)exp2_neg(h[b], chi);
             if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
             A[widx(a, b)] = -v;
         });
     });
 
     // ---- elimination: one panel per block column ----------------------------------------------------------
-    int errf = 0;
+    double dmin = 1.0;                                       // smallest pivot
     sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
         constexpr int b = decltype(b_)::value;
         constexpr int a0 = b / 4;                            // first block row holding columns 4b..4b+3
-        const int ncol = min(4, k - 4 * b);                  // real columns in this panel
-        if (ncol > 0) {                                      // uniform
+        if (k - 4 * b > 0) {                                 // uniform: the panel holds a C column
             // (1) publish the panel as it is (LDS operations of one wave execute in order: no barrier)
             sfor<a0, NBR>([&](auto a_) __attribute__((always_inline)) {
                 constexpr int a = decltype(a_)::value;
@@ -134,7 +133,9 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             });
             __builtin_amdgcn_wave_barrier();
             // (2) the 4x4 diagonal block (uniform addresses: broadcasts), its Cholesky factor, then one row
-            //     solve per lane and round -- the same fma sequence per element as a column-by-column sweep
+            //     solve per lane and round -- the same fma sequence per element as a column-by-column sweep.
+            //     A non-positive pivot gives NaN factors that reach the Schur block (k_uk_solve rejects
+            //     non-finite results); too small a pivot is caught through dmin at the end.
             const double *dg = &s_raw[(4 * b) * 4];
             const double g00 = dg[0];
             const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
@@ -142,21 +143,18 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             const double g22 = dg[10];
             const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
             const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
-            bool bad = false;
-            auto pivot = [&](double nd, bool valid) __attribute__((always_inline)) {
+            auto pivot = [&](double nd) __attribute__((always_inline)) {
                 const double d = -nd;
-                const bool bb = !(d > 1e-9 * c00) || !finite_d(d);   // singular / indefinite system
-                bad = bad || (valid && bb);
-                return (valid && !bb) ? -rsqrt_nr(d) : 0.0;
+                dmin = fmin(dmin, d);
+                return -rsqrt_nr(d);
             };
-            const double r0 = pivot(g00, true);
+            const double r0 = pivot(g00);
             const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
-            const double r1 = pivot(fma(l10, l10, g1.y), ncol > 1);
+            const double r1 = pivot(fma(l10, l10, g1.y));
             const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
-            const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)), ncol > 2);
+            const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
             const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
-            const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))), ncol > 3);
-            if (bad) errf = 1;
+            const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))));
             // only the rows below the panel are needed (by the update of live elements); the finished rows keep
             // whatever the slab held, which reaches finished elements only
             constexpr int ROW0 = 4 * b + 4, NROW = NP - ROW0;
@@ -221,6 +219,5 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
                 ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[widx(NBR - 1, bb)];
         });
     }
-    errf = __any(errf);
-    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = errf ? 1.0 : 0.0;
+    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00) ? 0.0 : 1.0;   // singular / indefinite
 }
