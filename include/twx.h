@@ -170,6 +170,17 @@ int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const
                    int rm_zero_dist, double *out, int64_t ld, int32_t *nnghs_used,
                    int32_t *status);
 
+/* XvalTairAnom.run_xval's inner step (twx/interp/optimize.py:521-541) for npts (station, bandwidth, month)
+ * points at once, statistics computed on the device: the GWR series of gwr_mth(pt, mth, nnghs, stns_rm) is
+ * compared with the observations of station obs_idx[i] (the left-out station).  With norm = pt_norm[i]:
+ * xval_anom = obs - norm, interp_anom = series - norm, difs = interp_anom - xval_anom;
+ * bias = mean(difs), mae = mean(|difs|), r2 = squared correlation of interp_anom and xval_anom
+ * (stats.linregress(...)[2] ** 2).  Failed points keep the caller's values. */
+int twx_gwr_xval_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const double *pt_norm,
+                        const int32_t *mth, const int32_t *nnghs, const int32_t *excl, int rm_zero_dist,
+                        const int32_t *obs_idx, double *bias, double *mae, double *r2,
+                        int32_t *nnghs_used, int32_t *status);
+
 /* InterpTair.interp(pt, stns_rm) (interp_tair.py:396-439): 12 x (krig, gwr).
  * daily [npts][ndays] degC (NULL = normals only), norms/se [npts][12]. */
 int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,

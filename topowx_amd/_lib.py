@@ -85,7 +85,7 @@ class TwxTiming(C.Structure):
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
-           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points")
+           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points")
 
 _LIB = None
 
@@ -272,6 +272,22 @@ class Context(object):
                                           _p(nn, _ip), _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(out, _dp),
                                           C.c_int64(ld), _p(used, _ip), _p(st, _ip)), "twx_gwr_points")
         return out, used, st
+
+    def gwr_xval_points(self, var, pts, pt_norm, mth, nnghs, excl, obs_idx, rm_zero_dist=True):
+        """bias / MAE / r^2 of the GWR series of every (point, month, bandwidth) against the observations of
+        station ``obs_idx`` (XvalTairAnom.run_xval's statistics, computed on the device)."""
+        pts = np.ascontiguousarray(pts, PT_DTYPE)
+        n = pts.size
+        mth, nn, ex, oi = self._i32(mth, n), self._i32(nnghs, n), self._i32(excl, n), self._i32(obs_idx, n)
+        pn = np.ascontiguousarray(np.broadcast_to(np.asarray(pt_norm, np.float64), (n,)))
+        bias, mae, r2 = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+        used = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        self._chk(self.lib.twx_gwr_xval_points(self.h, C.c_int(var), C.c_int64(n), _p(pts), _p(pn, _dp), _p(mth, _ip),
+                                               _p(nn, _ip), _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(oi, _ip),
+                                               _p(bias, _dp), _p(mae, _dp), _p(r2, _dp), _p(used, _ip), _p(st, _ip)),
+                  "twx_gwr_xval_points")
+        return bias, mae, r2, used, st
 
     def interp_points(self, var, pts, excl=None, rm_zero_dist=False, daily=True):
         pts = np.ascontiguousarray(pts, PT_DTYPE)

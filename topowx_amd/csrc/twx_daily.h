@@ -227,6 +227,63 @@ __global__ __launch_bounds__(256) void k_daily_points(StnDev st, CellSrc src, Se
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_xval_stats: XvalTairAnom.run_xval's statistics (optimize.py:521-541) for one (station, bandwidth, month)
+// point per workgroup, without moving the series to the host: interp = GWR series of the month (the point is
+// the left-out station itself), truth = that station's own observations.
+//   xval_anom = obs - norm, interp_anom = interp - norm, difs = interp_anom - xval_anom
+//   bias = mean(difs), mae = mean|difs|, r2 = corr(interp_anom, xval_anom)^2   (stats.linregress: centred sums)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double xv_block_sum(double v, double *s_red /*[4]*/)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_xval_stats(StnDev st, CellSrc src, SelWs ws, GwrWs gw, DayAxis da,
+                                                    const double *pt_norm, const int32_t *obs_idx, double *bias,
+                                                    double *mae, double *r2)
+{
+    __shared__ double s_red[4];
+    const int64_t lc = blockIdx.x;
+    if (lc >= ws.ncell) return;
+    const int64_t c = ws.cell0 + lc;
+    if (ws.cstat[lc] != 0 || gw.gstat[lc] != 0) return;
+    const int m0 = src.mth[c] - 1;
+    const int ka = ws.ka[lc * 12 + m0];
+    if (ka <= 0) return;
+    const double nrm = pt_norm[c];
+    const float *truth = st.obs + (size_t)obs_idx[c] * da.ndays;
+    const int d0 = da.moff[m0], nd = da.moff[m0 + 1] - d0;
+    // pass 1: means
+    double sx = 0, sy = 0, sd = 0, sa = 0;
+    for (int q = threadIdx.x; q < nd; q += 256) {
+        const double ia = daily_value(st, ws, gw, lc, m0, ka, da.ndays, d0 + q) - nrm;
+        const double xa = (double)truth[d0 + q] - nrm;
+        const double dif = ia - xa;
+        sx += ia; sy += xa; sd += dif; sa += fabs(dif);
+    }
+    const double n = (double)nd;
+    const double mx = xv_block_sum(sx, s_red) / n, my = xv_block_sum(sy, s_red) / n;
+    const double b = xv_block_sum(sd, s_red) / n, a = xv_block_sum(sa, s_red) / n;
+    // pass 2: centred second moments
+    double sxx = 0, syy = 0, sxy = 0;
+    for (int q = threadIdx.x; q < nd; q += 256) {
+        const double ia = daily_value(st, ws, gw, lc, m0, ka, da.ndays, d0 + q) - nrm - mx;
+        const double xa = (double)truth[d0 + q] - nrm - my;
+        sxx += ia * ia; syy += xa * xa; sxy += ia * xa;
+    }
+    sxx = xv_block_sum(sxx, s_red); syy = xv_block_sum(syy, s_red); sxy = xv_block_sum(sxy, s_red);
+    if (threadIdx.x == 0) {
+        bias[c] = b; mae[c] = a;
+        const double r = sxy / sqrt(sxx * syy);
+        r2[c] = r * r;
+    }
+}
+
 // byte offset of every ranked neighbour's observation row (valid when the matrix is smaller than 4 GiB)
 __global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
 {

@@ -680,6 +680,54 @@ int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const
     return 0;
 }
 
+int twx_gwr_xval_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const double *pt_norm,
+                        const int32_t *mth, const int32_t *nnghs, const int32_t *excl, int rm_zero_dist,
+                        const int32_t *obs_idx, double *bias, double *mae, double *r2, int32_t *nnghs_used,
+                        int32_t *status)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    if (check_var(ctx, var, true)) return -1;
+    if (npts <= 0 || !pts || !mth || !pt_norm || !obs_idx || !bias || !mae || !r2 || !status)
+        return fail(ctx, "twx_gwr_xval_points: bad arguments");
+    for (int64_t i = 0; i < npts; ++i) {
+        if (mth[i] < 1 || mth[i] > 12) return fail(ctx, "twx_gwr_xval_points: month outside 1..12");
+        if (obs_idx[i] < 0 || obs_idx[i] >= ctx->var[var].n) return fail(ctx, "twx_gwr_xval_points: obs_idx outside the station table");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, pt_norm, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 0, 1);
+    const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
+    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, true, nullptr)) return -1;
+    if (run_gwr(ctx, var, src, pd.pt_norm, nullptr)) return -1;
+    Work &w = ctx->work[var];
+    HIPCHK(ctx->pt_out.ensure((size_t)npts * (3 * 8 + 4) + 4096));
+    HIPCHK(ctx->pt_aux.ensure((size_t)npts * 4 + 256));
+    char *cur = ctx->pt_out.as<char>();
+    double *d_bias = carve<double>(cur, npts), *d_mae = carve<double>(cur, npts), *d_r2 = carve<double>(cur, npts);
+    int32_t *d_oi = ctx->pt_aux.as<int32_t>();
+    HIPCHK(hipMemcpy(d_oi, obs_idx, npts * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->pt_out.p, 0, (size_t)npts * 24));
+    hipLaunchKernelGGL(k_xval_stats, dim3((unsigned)npts), dim3(256), 0, nullptr, ctx->var[var].dev, src, w.ws, w.gw, ctx->da,
+                       pd.pt_norm, d_oi, d_bias, d_mae, d_r2);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> cs(npts), gs(npts), ka((size_t)npts * 12);
+    std::vector<double> hb(npts), hm(npts), hr(npts);
+    HIPCHK(hipMemcpy(cs.data(), w.ws.cstat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gs.data(), w.gw.gstat, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ka.data(), w.ws.ka, npts * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hb.data(), d_bias, npts * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hm.data(), d_mae, npts * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hr.data(), d_r2, npts * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i) {
+        status[i] = cs[i] ? cs[i] : gs[i];
+        if (nnghs_used) nnghs_used[i] = status[i] ? 0 : ka[i * 12 + mth[i] - 1];
+        if (status[i] == 0) { bias[i] = hb[i]; mae[i] = hm[i]; r2[i] = hr[i]; }
+    }
+    return 0;
+}
+
 int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *excl,
                       int rm_zero_dist, double *daily, double *norms, double *se, int32_t *status)
 {

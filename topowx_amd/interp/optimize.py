@@ -61,33 +61,34 @@ class XvalTairOverall(_XvalBase):
 
 class XvalTairAnom(_XvalBase):
     """Leave-one-out GWR anomalies over a ladder of bandwidths (optimize.py:476-545).
-    Returns bias, MAE and r^2, each [n_bandwidths, 12] as the reference does (:510-545)."""
+    Returns bias, MAE and r^2, each [n_bandwidths, 12] as the reference does (:510-545); the statistics are
+    reduced on the device (``twx_gwr_xval_points``), only three numbers per (bandwidth, month) come back."""
 
     def run_xval(self, stn_id, a_nnghs):
+        bias, mae, r2 = self.run_xval_many([stn_id], a_nnghs)
+        return bias[0], mae[0], r2[0]
+
+    def run_xval_many(self, stn_ids, a_nnghs, raise_on_error=True):
+        """Batched form: arrays [n_stations, n_bandwidths, 12].  ``raise_on_error=False`` is the step23 worker's
+        behaviour (step23:56-66): a station for which any (bandwidth, month) fails is reported in a fourth
+        boolean array instead of raising."""
         a_nnghs = np.asarray(a_nnghs, np.int32)
-        j, pt = self._pts([stn_id])
-        nb = a_nnghs.size
-        # one (bandwidth, month) pair per GPU point
+        j, pt = self._pts(stn_ids)
+        ns, nb = len(stn_ids), a_nnghs.size
+        # one GPU point per (station, bandwidth, month)
         pts = np.repeat(pt, nb * 12)
-        mth = np.tile(np.arange(1, 13, dtype=np.int32), nb)
-        nn = np.repeat(a_nnghs, 12)
-        norm = np.array([self.stns[j[0]][get_norm_varname(m)] for m in range(1, 13)])
-        out, _, st = self.ctx.gwr_points(self.var, pts, np.tile(norm, nb), mth, nnghs=nn, excl=np.full(nb * 12, j[0]),
-                                         rm_zero_dist=True)
-        for s in st:
-            raise_for_status(s)
-        obs = self.stn_da.load_obs(stn_id)
-        bias = np.zeros((nb, 12)); mae = np.zeros((nb, 12)); r2 = np.zeros((nb, 12))
-        for x in range(nb):
-            for m in range(1, 13):
-                rows = self.mth_masks[m]
-                xval_anom = obs[rows] - norm[m - 1]
-                interp_anom = out[x * 12 + m - 1, :rows.size] - norm[m - 1]
-                difs = interp_anom - xval_anom
-                bias[x, m - 1] = difs.mean()
-                mae[x, m - 1] = np.abs(difs).mean()
-                r2[x, m - 1] = np.corrcoef(interp_anom, xval_anom)[0, 1] ** 2
-        return bias, mae, r2
+        mth = np.tile(np.arange(1, 13, dtype=np.int32), ns * nb)
+        nn = np.tile(np.repeat(a_nnghs, 12), ns)
+        own = np.repeat(j.astype(np.int32), nb * 12)
+        norm = np.column_stack([self.stns[j][get_norm_varname(m)] for m in range(1, 13)])      # [ns, 12]
+        pn = np.repeat(norm, nb, axis=0).reshape(-1)                                           # (station, bw, month)
+        bias, mae, r2, _, st = self.ctx.gwr_xval_points(self.var, pts, pn, mth, nn, own, own, rm_zero_dist=True)
+        ok = (st.reshape(ns, nb * 12) == 0).all(axis=1)
+        if raise_on_error:
+            for q in st:
+                raise_for_status(q)
+        out = tuple(a.reshape(ns, nb, 12) for a in (bias, mae, r2))
+        return out if raise_on_error else out + (ok,)
 
 
 class XvalTairNorm(_XvalBase):
@@ -97,7 +98,9 @@ class XvalTairNorm(_XvalBase):
     def run_xval(self, stn_id, abw_nngh):
         return self.run_xval_many([stn_id], abw_nngh)[0]
 
-    def run_xval_many(self, stn_ids, abw_nngh):
+    def run_xval_many(self, stn_ids, abw_nngh, raise_on_error=True):
+        """Batched form: err[n_stations, 12, n_bandwidths].  ``raise_on_error=False`` (the step21 worker,
+        step21:55-62) also returns ok[n_stations]: False where any (bandwidth, month) could not be solved."""
         abw = np.asarray(abw_nngh, np.int32)
         j, pt = self._pts(stn_ids)
         ns, nb = len(stn_ids), abw.size
@@ -106,16 +109,22 @@ class XvalTairNorm(_XvalBase):
         mth = np.tile(np.arange(1, 13, dtype=np.int32), ns * nb)
         nn = np.tile(np.repeat(abw, 12), ns)
         excl = np.repeat(j.astype(np.int32), nb * 12)
-        vario, _, st = self.ctx.fit_vario_points(self.var, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
-        for q in st:
-            raise_for_status(q)
-        mean, _, _, st, _ = self.ctx.krig_points(self.var, pts, mth, nnghs=nn, vario=vario, excl=excl,
+        vario, _, st1 = self.ctx.fit_vario_points(self.var, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
+        if raise_on_error:
+            for q in st1:
+                raise_for_status(q)
+        mean, _, _, st2, _ = self.ctx.krig_points(self.var, pts, mth, nnghs=nn, vario=np.nan_to_num(vario), excl=excl,
                                                  rm_zero_dist=True)
-        for q in st:
-            raise_for_status(q)
+        if raise_on_error:
+            for q in st2:
+                raise_for_status(q)
         obs = np.column_stack([self.stns[j][get_norm_varname(m)] for m in range(1, 13)])      # [ns, 12]
         interp = mean.reshape(ns, nb, 12)
-        return np.transpose(interp - obs[:, None, :], (0, 2, 1))                                # [ns, 12, nb]
+        err = np.transpose(interp - obs[:, None, :], (0, 2, 1))                                 # [ns, 12, nb]
+        if raise_on_error:
+            return err
+        ok = ((st1 == 0) & (st2 == 0)).reshape(ns, nb * 12).all(axis=1)
+        return err, ok
 
 
 class StationKrigParams(_XvalBase):

@@ -1,0 +1,251 @@
+"""Config 5 (BASELINE.json configs[4]): the leave-one-out cross-validation farms and the bandwidth optimisation.
+
+Counterpart of the reference's three MPI farms and of the reduction their writer rank runs at the end:
+
+  step21_mpi_optim_nstns_norms.py:34-169   XvalTairNorm.run_xval per station -> |err| -> 'mae'[12, 16, nstn]
+  step23_mpi_optim_nstns_anoms.py:35-180   XvalTairAnom.run_xval per station -> mae / bias / r2
+  step24_mpi_xval_interp.py:36-156         XvalTairOverall.run_interp per station -> daily + normals
+  twx/interp/optimize.py:268-374           set_optim_nstns_tair_norm / _anom: mean MAE per climate division and
+                                           month -> argmin over the bandwidth ladder -> optim_nnghsMM /
+                                           optim_nnghs_anomMM of every station of the division
+
+The reference deals ONE station at a time to a worker that loops over 16 bandwidths x 12 months in Python.  Here a
+rank owns a strided share of the station list and pushes it through the batched C-ABI entries in chunks of a few
+hundred stations: every (station, bandwidth, month) triple is one GPU point.  The statistics of step23 are reduced
+on the device (``twx_gwr_xval_points``), so only three numbers per triple come back.  Ranks exchange results with
+one ``all_gather`` of small arrays (``torch.distributed``: nccl = RCCL on the GPUs, gloo in the CPU tests); the data
+path itself needs no collective -- stations are independent given the replicated table.
+
+Layout choice: the reference's step23 hands its writer ``mae[n_bandwidths, 12]`` for a netCDF
+variable shaped ``[12, n_bandwidths, nstn]``; this module always produces month-major ``[12, n_bandwidths, nstn]``,
+which is what ``set_optim_nstns_tair_*`` index (``mae_climdiv[mth - 1, :, :]``, optimize.py:311).
+"""
+import numpy as np
+
+from .interp.optimize import XvalTairAnom, XvalTairNorm, XvalTairOverall, build_nstn_bandwidths
+from .stationdb import BAD, CLIMDIV, MASK, STN_ID, get_optim_anom_varname, get_optim_varname
+
+__all__ = ["xval_station_ids", "shard", "optim_nstns_norms", "optim_nstns_anoms", "xval_interp", "set_optim_nstns",
+           "set_optim_nstns_tair_norm", "set_optim_nstns_tair_anom", "DFLT_LADDER"]
+
+DFLT_LADDER = build_nstn_bandwidths(35, 150, 0.10)        # step21:198, step23
+
+
+def xval_station_ids(stn_da):
+    """Stations that are cross-validated: inside the interpolation mask and not flagged bad
+    (step21:146-149, step23 proc_coord, step24:135-137)."""
+    s = stn_da.stns
+    return s[STN_ID][np.isfinite(s[MASK]) & np.isnan(s[BAD])]
+
+
+def shard(items, rank, world):
+    """Strided share of ``items`` for ``rank`` (stations cost about the same: no balancing needed)."""
+    return items[rank::world]
+
+
+def _unshard(parts, n):
+    """Inverse of ``shard`` along the last axis: parts[r] holds items r, r + world, ..."""
+    world = len(parts)
+    out = np.empty(parts[0].shape[:-1] + (n,), parts[0].dtype)
+    for r, p in enumerate(parts):
+        out[..., r::world] = p
+    return out
+
+
+def _all_gather(local, n_total, rank, world, device="cpu"):
+    """Every rank's last-axis share -> the full array on every rank (one all_gather of padded blocks)."""
+    if world == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+    nmax = -(-n_total // world)
+    pad = np.zeros(local.shape[:-1] + (nmax,), local.dtype)
+    pad[..., :local.shape[-1]] = local
+    t = torch.from_numpy(pad).to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    sizes = [len(range(r, n_total, world)) for r in range(world)]
+    return _unshard([p.cpu().numpy()[..., :sizes[r]] for r, p in enumerate(parts)], n_total)
+
+
+def _batches(ids, batch):
+    for i in range(0, len(ids), batch):
+        yield i, ids[i:i + batch]
+
+
+def optim_nstns_norms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0, world=1, batch=256, device=0,
+                      gather_device="cpu"):
+    """step21: leave-one-out error of the kriged normals for every station and bandwidth.
+
+    Returns ``(stn_ids, mae)`` with ``mae[12, n_bandwidths, n_stations] = |interpolated - observed|``
+    (step21:124-128); a station that cannot be cross-validated keeps NaN (the reference's worker prints the error
+    and writes nothing: the netCDF fill value, masked in the reduction)."""
+    ids = xval_station_ids(stn_da) if stn_ids is None else np.asarray(stn_ids)
+    mine = shard(ids, rank, world)
+    ladder = np.asarray(ladder)
+    mae = np.full((12, ladder.size, len(mine)), np.nan)
+    xv = XvalTairNorm(stn_da, tair_var, device=device)
+    try:
+        for i, chunk in _batches(mine, batch):
+            err, ok = xv.run_xval_many(chunk, ladder, raise_on_error=False)          # [ns, 12, nb]
+            blk = np.abs(np.transpose(err, (1, 2, 0)))
+            blk[:, :, ~ok] = np.nan
+            mae[:, :, i:i + len(chunk)] = blk
+    finally:
+        xv.close()
+    return ids, _all_gather(mae, len(ids), rank, world, gather_device)
+
+
+def optim_nstns_anoms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0, world=1, batch=128, device=0,
+                      gather_device="cpu"):
+    """step23: leave-one-out GWR anomalies for every station, bandwidth and month.
+
+    Returns ``(stn_ids, mae, bias, r2)``, each ``[12, n_bandwidths, n_stations]`` (month-major, see the module
+    docstring); NaN where the reference's worker would have stored the fill value (step23:60-66)."""
+    ids = xval_station_ids(stn_da) if stn_ids is None else np.asarray(stn_ids)
+    mine = shard(ids, rank, world)
+    ladder = np.asarray(ladder)
+    out = [np.full((12, ladder.size, len(mine)), np.nan) for _ in range(3)]
+    xv = XvalTairAnom(stn_da, tair_var, device=device)
+    try:
+        for i, chunk in _batches(mine, batch):
+            bias, mae, r2, ok = xv.run_xval_many(chunk, ladder, raise_on_error=False)   # [ns, nb, 12]
+            for dst, src in zip(out, (mae, bias, r2)):
+                blk = np.transpose(src, (2, 1, 0)).copy()
+                blk[:, :, ~ok] = np.nan
+                dst[:, :, i:i + len(chunk)] = blk
+    finally:
+        xv.close()
+    mae, bias, r2 = (_all_gather(a, len(ids), rank, world, gather_device) for a in out)
+    return ids, mae, bias, r2
+
+
+def xval_interp(stn_da, tair_var, stn_ids=None, daily=True, rank=0, world=1, batch=512, device=0,
+                gather_device="cpu"):
+    """step24: leave-one-out interpolation of normals (+ daily values) at every station.
+
+    Returns ``(stn_ids, norms[n, 12], se[n, 12], daily[n, ndays] float32 or None, status[n])``; failed stations
+    keep NaN (the reference writes fill values, step24:52-62).  Daily values are gathered as float32, the dtype
+    the reference's output database stores (step24:30-33)."""
+    ids = xval_station_ids(stn_da) if stn_ids is None else np.asarray(stn_ids)
+    mine = shard(ids, rank, world)
+    nd = stn_da.days.size
+    norms = np.full((12, len(mine)), np.nan)
+    se = np.full((12, len(mine)), np.nan)
+    st = np.zeros((1, len(mine)), np.int32)
+    dly = np.full((nd, len(mine)), np.nan, np.float32) if daily else None
+    xv = XvalTairOverall(stn_da, tair_var, device=device)
+    try:
+        for i, chunk in _batches(mine, batch):
+            d, n, s, code = xv.run_interp_many(chunk, daily=daily, raise_on_error=False)
+            norms[:, i:i + len(chunk)] = n.T
+            se[:, i:i + len(chunk)] = s.T
+            st[0, i:i + len(chunk)] = code
+            if daily:
+                dly[:, i:i + len(chunk)] = d.T.astype(np.float32)
+    finally:
+        xv.close()
+    norms = _all_gather(norms, len(ids), rank, world, gather_device).T
+    se = _all_gather(se, len(ids), rank, world, gather_device).T
+    st = _all_gather(st, len(ids), rank, world, gather_device)[0]
+    if daily:
+        dly = _all_gather(dly, len(ids), rank, world, gather_device).T
+    return ids, norms, se, dly, st
+
+
+def set_optim_nstns(stns, stn_ids, mae, ladder, namer):
+    """optimize.py:268-374 on arrays: for every climate division and month the bandwidth with the smallest MAE
+    averaged over the division's cross-validated stations becomes ``namer(mth)`` of EVERY station of the division
+    (``climdiv_mask`` is taken over the whole table, :308).  Failed stations (NaN) are left out of the mean, as the
+    masked fill values are in the reference.  ``stns`` is modified in place and returned together with the chosen
+    bandwidths ``{climdiv: [12]}``."""
+    ladder = np.asarray(ladder)
+    ids = np.asarray(stn_ids)
+    pos = {s: i for i, s in enumerate(stns[STN_ID])}
+    div_of_xval = stns[CLIMDIV][[pos[s] for s in ids]]
+    climdiv_stns = stns[CLIMDIV]
+    divs = np.unique(climdiv_stns[np.isfinite(climdiv_stns)])                    # :300
+    chosen = {}
+    for clim_div in divs:
+        cols = np.nonzero(div_of_xval == clim_div)[0]                            # the division's MAE file (step21:96-104)
+        if cols.size == 0:
+            continue            # the reference would fail opening a file that was never written; nothing to set
+        climdiv_mask = np.nonzero(climdiv_stns == clim_div)[0]                   # :308
+        pick = np.zeros(12, ladder.dtype)
+        for mth in range(1, 13):
+            m = np.ma.masked_invalid(mae[mth - 1][:, cols])
+            mmae = np.ma.mean(m, axis=1)                                         # :312
+            min_idx = int(np.argmin(mmae))                                       # :313 (first minimum)
+            stns[namer(mth)][climdiv_mask] = ladder[min_idx]                     # :314
+            pick[mth - 1] = ladder[min_idx]
+        chosen[float(clim_div)] = pick
+    return stns, chosen
+
+
+def set_optim_nstns_tair_norm(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
+    """optimize.py:268-316 (the end of step21): writes ``optim_nnghsMM``."""
+    return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_varname)[1]
+
+
+def set_optim_nstns_tair_anom(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
+    """optimize.py:318-374 (the end of step23): writes ``optim_nnghs_anomMM``."""
+    return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_anom_varname)[1]
+
+
+def main():
+    """All three farms on a synthetic database, timed: ``python -m topowx_amd.xval --nstns 10000``
+    (under torchrun every rank takes its share)."""
+    import argparse
+    import json
+    import os
+    import time
+    import datetime as dt
+    from . import synth
+    from .dates import get_days_metadata
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nstns", type=int, default=2000)
+    ap.add_argument("--years", type=int, default=3)
+    ap.add_argument("--var", default="tmin")
+    ap.add_argument("--max-stations", type=int, default=0, help="cross-validate only the first N stations (0 = all)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    gdev = "cpu"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        gdev = "cuda:%d" % local
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + args.years, 12, 31))
+    grid = synth.make_grid("C2")
+    stn = synth.make_stations(grid["bbox"], args.nstns, 1, args.var, days, with_obs=True)
+    ids = xval_station_ids(stn)
+    if args.max_stations:
+        ids = ids[:args.max_stations]
+    res = {"stations": int(len(ids)), "ladder": int(DFLT_LADDER.size), "days": int(days.size), "n_gpus": world}
+    t0 = time.perf_counter()
+    _, mae_n = optim_nstns_norms(stn, args.var, stn_ids=ids, rank=rank, world=world, device=local, gather_device=gdev)
+    res["step21_s"] = time.perf_counter() - t0
+    set_optim_nstns_tair_norm(stn, ids, mae_n)
+    t0 = time.perf_counter()
+    _, mae_a, _, _ = optim_nstns_anoms(stn, args.var, stn_ids=ids, rank=rank, world=world, device=local, gather_device=gdev)
+    res["step23_s"] = time.perf_counter() - t0
+    set_optim_nstns_tair_anom(stn, ids, mae_a)
+    t0 = time.perf_counter()
+    _, norms, _, _, st = xval_interp(stn, args.var, stn_ids=ids, daily=True, rank=rank, world=world, device=local,
+                                     gather_device=gdev)
+    res["step24_s"] = time.perf_counter() - t0
+    res["step21_systems_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step21_s"]
+    res["step23_series_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step23_s"]
+    res["step24_station_days_per_s"] = len(ids) * days.size / res["step24_s"]
+    res["failed"] = int((st != 0).sum())
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
