@@ -199,7 +199,26 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
 template <int NB>
 void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
 {
+#ifdef TWX_UK_STAMP   // diagnostic build only: stamp the NB = 7 launch, dump the stamps next to the working directory
+    static unsigned long long *dbg = nullptr;
+    const size_t nb = (size_t)2048 * 40 * 4 * 4 * 8;
+    SelWs w2 = ws;
+    w2.dbg = nullptr;
+    if (NB == 7) {
+        if (!dbg) (void)hipMalloc(&dbg, nb);
+        (void)hipMemsetAsync(dbg, 0, nb, s);
+        w2.dbg = dbg;
+    }
+    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, w2, cells, cnt);
+    if (NB == 7) {
+        std::vector<unsigned long long> h(nb / 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), dbg, nb, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen("gpurun_out/uk_stamps.bin", "wb")) { fwrite(h.data(), 1, nb, f); fclose(f); }
+    }
+#else
     hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt);
+#endif
 }
 
 template <int NBR, int HALF>

@@ -49,6 +49,9 @@ struct SelWs {
     float *dist;         // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr] station-pair distances (km) of the cell's kriging
                          // neighbourhood in rank order, 16x16 blocks (a >= b) -- shared by the cell's 12 monthly systems
     float *h0;           // [ncell][ksel] cell -> neighbour distance (km, sp/gstat formula)
+#ifdef TWX_UK_STAMP      // diagnostic build only (tests/tools/uk_stamps.sh): s_memtime stamps of the panel loop
+    unsigned long long *dbg;
+#endif
 };
 
 // ---------------------------------------------------------------------------------

@@ -191,6 +191,22 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 }
 #define TWX_UK_WAVES(NB) twx_uk_waves(NB)
 
+#ifdef TWX_UK_STAMP
+#ifndef TWX_STAMP_WG0
+#define TWX_STAMP_WG0 60000u   // steady state: well past the first round of work-groups
+#endif
+// diagnostic build: [work-group < 2048][panel < 40][wave][slot < 4] s_memtime stamps
+//   slot 0: barrier passed (update begins)   1: update done
+//   slot 2: (holder) panel published, chain begins   3: (holder) slab written
+#define TWX_STAMP(P, SLOT)                                                                                         \
+    do {                                                                                                           \
+        if (ws.dbg && blockIdx.x - TWX_STAMP_WG0 < 2048u && lane == 0)                                             \
+            ws.dbg[(((size_t)(blockIdx.x - TWX_STAMP_WG0) * 40 + (P)) * 4 + wv) * 4 + (SLOT)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TWX_STAMP(P, SLOT) do { } while (0)
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
@@ -200,7 +216,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
     __shared__ __attribute__((aligned(16))) double s_pan[2][NP * PS];         // four scaled columns of a panel, [row][4]; double-buffered:
                                                                               // the next panel is factorised while this one is still being applied
-    __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];             // the same four columns before the panel is factorised
+    __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
     __shared__ double s_red[4][4];
     __shared__ int s_err;
@@ -307,18 +323,21 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                 //     reach the Schur block (k_uk_solve rejects non-finite results); too small a pivot is caught
                 //     through dmin at the end.
                 if (wvp == s) {
+                TWX_STAMP(4 * bp + s, 2);
                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value;
-                    s_raw[(16 * a + tr) * 4 + tcl] = A[tri(a, bp)];
+                    s_raw[tcl * NP + 16 * a + tr] = A[tri(a, bp)];
                 });
                 __builtin_amdgcn_wave_barrier();
-                const double *dg = &s_raw[(16 * bp + 4 * s) * 4];
+                // column-major panel image: s_raw[column][row] (publishing lanes write consecutive rows, the row solve
+                // reads consecutive rows: no bank conflicts); the diagonal block comes back as broadcasts
+                const double *dg = &s_raw[16 * bp + 4 * s];
                 const double g00 = dg[0];
-                const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
-                const double2 g2 = *reinterpret_cast<const double2 *>(&dg[8]);
-                const double g22 = dg[10];
-                const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
-                const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
+                const double2 g1 = double2{dg[1], dg[NP + 1]};
+                const double2 g2 = double2{dg[2], dg[NP + 2]};
+                const double g22 = dg[2 * NP + 2];
+                const double2 g3 = double2{dg[3], dg[NP + 3]};
+                const double2 g3b = double2{dg[2 * NP + 3], dg[3 * NP + 3]};
                 // the registers hold N = -M: pivot d = -n, l = n * (-1/sqrt(d)), updates n += l l
                 auto pivot = [&](double nd) __attribute__((always_inline)) {
                     const double d = -nd;
@@ -340,8 +359,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                     const int rr = 4 * s + 4 + lane + RPR * u;           // row within the block rows bp..
                     if (rr < NROW) {
                         const int myrow = 16 * bp + rr;
-                        const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4]);
-                        const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[myrow * 4 + 2]);
+                        const double2 n01 = double2{s_raw[myrow], s_raw[NP + myrow]};
+                        const double2 n23 = double2{s_raw[2 * NP + myrow], s_raw[3 * NP + myrow]};
                         const double L0 = n01.x * r0;
                         const double L1 = fma(L0, l10, n01.y) * r1;
                         const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
@@ -350,8 +369,10 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                         *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS + 2]) = double2{L2, L3};
                     }
                 }
+                TWX_STAMP(4 * bp + s, 3);
                 }
                 __syncthreads();
+                TWX_STAMP(4 * bp + s, 0);
                 // (3) rank-4 update N(i,j) += l(i,:) . l(j,:).  The column factors l(16b+tc, 0..3) are common to
                 // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bp) + column) once
                 // per panel and every fmac picks its operand with row_newbcast; the row factors l(16a+tr, 0..3)
@@ -391,6 +412,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
                         A[tri(a, b)] = acc;
                     });
                 });
+                TWX_STAMP(4 * bp + s, 1);
             }
         }
     });

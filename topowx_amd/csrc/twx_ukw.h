@@ -129,20 +129,22 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
             // (1) publish the panel as it is (LDS operations of one wave execute in order: no barrier)
             sfor<a0, NBR>([&](auto a_) __attribute__((always_inline)) {
                 constexpr int a = decltype(a_)::value;
-                s_raw[(16 * a + tr) * 4 + tc] = A[widx(a, b)];
+                s_raw[tc * NP + 16 * a + tr] = A[widx(a, b)];
             });
             __builtin_amdgcn_wave_barrier();
             // (2) the 4x4 diagonal block (uniform addresses: broadcasts), its Cholesky factor, then one row
             //     solve per lane and round -- the same fma sequence per element as a column-by-column sweep.
             //     A non-positive pivot gives NaN factors that reach the Schur block (k_uk_solve rejects
             //     non-finite results); too small a pivot is caught through dmin at the end.
-            const double *dg = &s_raw[(4 * b) * 4];
+            // column-major panel image: s_raw[column][row] (publishing lanes write consecutive rows, the row solve
+            // reads consecutive rows: no bank conflicts); the diagonal block comes back as broadcasts
+            const double *dg = &s_raw[4 * b];
             const double g00 = dg[0];
-            const double2 g1 = *reinterpret_cast<const double2 *>(&dg[4]);
-            const double2 g2 = *reinterpret_cast<const double2 *>(&dg[8]);
-            const double g22 = dg[10];
-            const double2 g3 = *reinterpret_cast<const double2 *>(&dg[12]);
-            const double2 g3b = *reinterpret_cast<const double2 *>(&dg[14]);
+            const double2 g1 = double2{dg[1], dg[NP + 1]};
+            const double2 g2 = double2{dg[2], dg[NP + 2]};
+            const double g22 = dg[2 * NP + 2];
+            const double2 g3 = double2{dg[3], dg[NP + 3]};
+            const double2 g3b = double2{dg[2 * NP + 3], dg[3 * NP + 3]};
             auto pivot = [&](double nd) __attribute__((always_inline)) {
                 const double d = -nd;
                 dmin = fmin(dmin, d);
@@ -163,8 +165,8 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
                 if (u) __builtin_amdgcn_wave_barrier();      // one round's registers at a time
                 const int row = ROW0 + lane + 64 * u;
                 if (row < NP) {
-                    const double2 n01 = *reinterpret_cast<const double2 *>(&s_raw[row * 4]);
-                    const double2 n23 = *reinterpret_cast<const double2 *>(&s_raw[row * 4 + 2]);
+                    const double2 n01 = double2{s_raw[row], s_raw[NP + row]};
+                    const double2 n23 = double2{s_raw[2 * NP + row], s_raw[3 * NP + row]};
                     const double L0 = n01.x * r0;
                     const double L1 = fma(L0, l10, n01.y) * r1;
                     const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
