@@ -109,9 +109,10 @@ typedef struct {
 } twx_grid;
 
 /* Outputs of a grid call in the dtypes / layout of the reference's result
- * arrays (step25:68-88,163-172).  Any pointer may be NULL.  Buffers must be
- * pre-filled by the caller (fill values); failed and masked cells are not
- * written. */
+ * arrays (step25:68-88,163-172).  Any pointer may be NULL.  Every grid entry first
+ * fills the buffers with the netCDF fill values below (TWX_FILL_*; status: every
+ * cell is written), then writes the cells that succeed: failed and masked cells
+ * hold the fill values, as in the reference's result arrays (step25:68-88,154-160). */
 typedef struct {
     float *norm_tmin, *se_tmin; /* [12][Y][X] */
     float *norm_tmax, *se_tmax; /* [12][Y][X] */
@@ -211,10 +212,27 @@ int twx_pack_i16(twx_ctx *ctx, int64_t n, const double *x, int16_t *out);
 int twx_interp_grid(twx_ctx *ctx, const twx_grid *grid, const twx_grid_out *out, int vars);
 
 /* same, but every pointer in grid / out is a DEVICE pointer and the work is
- * enqueued on hip_stream (a hipStream_t; NULL = default stream).  Inputs must
- * stay valid until the stream has drained. */
+ * enqueued on hip_stream (a hipStream_t; NULL = default stream) WITHOUT any host
+ * synchronisation: candidate lists, matrix-size buckets and the list of cells for
+ * the Tmin >= Tmax fixer are sized and counted on the device.  Inputs must stay
+ * valid until the stream has drained.  (The first call of a shape may allocate
+ * workspace, which synchronises the device once.) */
 int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *grid_dev, const twx_grid_out *out_dev,
                         int vars, void *hip_stream);
+
+/* ---- streamed tiles: the worker writes every chunk as soon as it is finished (step25:177-185,
+ * tiling.py:488-537).  A twx_stream owns two device images and nslots pinned host blocks for tiles of one shape;
+ * twx_stream_submit copies the predictors of a tile (host pointers) up, enqueues its kernels on the stream's own
+ * compute stream and the copy-out of all outputs on a second (copy) stream, and returns at once: the copy-out of
+ * tile t overlaps the kernels of tile t + 1.  twx_stream_wait blocks until the slot's outputs are in host memory
+ * and returns pointers into the slot's pinned block (valid until the slot is submitted again); device_ms
+ * (optional) = device time of the tile's kernels.  One stream per context at a time; do not mix with other
+ * calls on the context while tiles are in flight. */
+typedef struct twx_stream twx_stream;
+int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslots, twx_stream **out);
+int twx_stream_submit(twx_stream *st, int slot, const twx_grid *grid);
+int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device_ms);
+void twx_stream_destroy(twx_stream *st);
 
 /* kernel times of the last grid call (synchronises on its events) */
 int twx_get_timing(twx_ctx *ctx, twx_timing *t);

@@ -102,3 +102,18 @@ def test_tiler_work_chunk_layout():
     assert np.array_equal(w[5], grid["elev"][0:5, 10:15].astype(np.float64))
     assert np.array_equal(w[8 + 6], grid["lst_night"][6, 0:5, 10:15]) and np.array_equal(w[20 + 11], grid["lst_day"][11, 0:5, 10:15])
     assert len(list(t)) == 19
+
+
+def test_gather_mosaic_with_edge_tiles():
+    """A grid that the tile size does not divide: edge tiles are smaller, the mosaic is clipped (single process)."""
+    from topowx_amd import driver
+    rng = np.random.default_rng(3)
+    Y, X, T = 10, 14, 4
+    mask = np.ones((Y, X), np.uint8)
+    truth = rng.random((12, Y, X)).astype(np.float32)
+    tiles = driver.tile_list(mask, T, T)
+    assert len(tiles) == 12                                            # 3 x 4 tiles, the last row / column partial
+    a = driver.assign_tiles(tiles, 1)
+    local = {k: {"norm_tmin": truth[:, i:i + T, j:j + T]} for k, i, j, _ in a[0]}
+    mos = driver.gather_mosaic(local, a, (Y, X), T, T, ("norm_tmin",), 0, 1)
+    assert np.array_equal(mos["norm_tmin"], truth)

@@ -1,0 +1,100 @@
+"""GPU: the asynchronous grid path -- streamed tiles (twx_stream_*), dense station clusters (candidate lists longer
+than the LDS fast path), the step25 chunk loop's resume / per-tile log."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tile_stream_equals_synchronous_entry(golden_case):
+    """Six 20 x 25 tiles (one partly masked, one fully masked) through a 2-slot stream: every slot reused three
+    times, tiles in flight while earlier ones are read back; results identical to twx_interp_grid, bit for bit."""
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    grid = dict(grid)
+    mask = np.array(grid["mask"], copy=True)
+    mask[25:33, 30:50] = 0
+    mask[40:60, 0:25] = 0
+    grid["mask"] = mask
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    tiles = [(slice(r, r + 20), slice(c, c + 25)) for r in (20, 40) for c in (0, 25, 50)]
+    want = [ctx.interp_grid(grid, daily=True, rows=rs, cols=cs) for rs, cs in tiles]
+    st = ctx.stream(20, 25, daily=True, nslots=2)
+    got = [None] * len(tiles)
+    for i, (rs, cs) in enumerate(tiles):
+        st.submit(i & 1, grid, rs, cs)
+        if i >= 1:
+            got[i - 1] = {k: (np.array(v) if hasattr(v, "shape") else v) for k, v in st.wait((i - 1) & 1).items()}
+    got[-1] = {k: (np.array(v) if hasattr(v, "shape") else v) for k, v in st.wait((len(tiles) - 1) & 1).items()}
+    st.close()
+    ctx.close()
+    for g, w in zip(got, want):
+        assert g["device_ms"] > 0
+        for k in w:
+            assert np.array_equal(g[k], w[k]), k
+    assert np.all(got[3]["status"] == -1) and np.all(got[3]["daily_tmin"] == _lib.FILL_I2)      # the fully masked tile
+
+
+@pytest.mark.parametrize("nclust,expect_range", [(1500, False), (6000, True)])
+def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
+    """A cluster of stations far denser than the tile size: the candidate lists of its tiles outgrow the 512-slot LDS
+    path.  Up to 2 048 candidates the full-list kernel ranks them (results = oracle, which searches all stations);
+    beyond that the cells fail with TWX_CELL_RANGE instead of using a truncated list."""
+    from topowx_amd import _lib, stationdb as sdb, synth
+    grid, tmin, _ = golden_case
+    rng = np.random.default_rng(9)
+    base = tmin.stns
+    extra = synth.make_stations((45.55, 45.85, -110.7, -110.4), nclust, 77, "tmin", expand_deg=0.0).stns
+    extra[sdb.STN_ID] = ["T%07d" % i for i in range(extra.size)]                    # sorts after the 'S...' ids
+    stns = np.concatenate([base, extra])
+    db = sdb.StationDataWrkChk(stns, "tmin", tmin.days, None)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, db, with_obs=False)
+    rs, cs = slice(30, 46), slice(44, 60)                                             # inside the cluster's box
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
+    ctx.close()
+    if expect_range:
+        assert np.all(got["status"] == 6) and np.all(got["norm_tmin"] == _lib.FILL_F4)
+        return
+    assert np.all(got["status"] == 0)
+    want = orc.interp_grid(orc.Db(db), None, orc.params(), grid, nthreads=8, rows=rs, cols=cs)
+    assert np.array_equal(want["status"], got["status"])
+    assert np.abs(got["norm_tmin"].astype(np.float64) - want["norm_tmin"]).max() < 1e-4
+    assert np.abs(got["se_tmin"].astype(np.float64) - want["se_tmin"]).max() < 1e-4
+
+
+def test_step25_resume_and_tile_log(golden_case, tmp_path):
+    """A second run skips the tiles whose output exists (tiling.py:258-275, step25:354-356); an interrupted tile
+    (temporary name only) is redone; every tile leaves one JSON record."""
+    from topowx_amd import step25
+    grid, tmin, tmax = golden_case
+    sub = {k: (v[:40, :40] if k in ("mask", "elev", "tdi", "climdiv") else v) for k, v in grid.items()}
+    sub["lat"], sub["lon"] = grid["lat"][:40], grid["lon"][:40]
+    sub["lst_night"], sub["lst_day"] = grid["lst_night"][:, :40, :40], grid["lst_day"][:, :40, :40]
+    lines = []
+    out = str(tmp_path)
+    stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=out, log=lines.append)
+    assert stores == {}                                                  # written and dropped, nothing kept in memory
+    recs = [json.loads(x) for x in lines]
+    assert sorted(r["tile"] for r in recs) == ["h00v00", "h00v01", "h01v00", "h01v01"]
+    assert all(r["cells"] == 400 and r["ok"] == 400 and r["failures"] == {} and r["device_ms"] > 0 and r["bytes"] > 0
+               for r in recs)
+    assert sorted(os.listdir(out)) == ["h00v00.npz", "h00v01.npz", "h01v00.npz", "h01v01.npz"]
+    first = {t: dict(np.load(os.path.join(out, t + ".npz"))) for t in ("h00v00", "h01v01")}
+    # simulate an interrupted tile and a lost one
+    os.replace(os.path.join(out, "h01v01.npz"), os.path.join(out, "h01v01.part.npz"))
+    os.remove(os.path.join(out, "h00v00.npz"))
+    lines2 = []
+    step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=out, log=lines2.append)
+    log2 = step25.proc_work.last_log
+    assert sorted(r["tile"] for r in log2 if r.get("skipped")) == ["h00v01", "h01v00"]
+    assert sorted(json.loads(x)["tile"] for x in lines2) == ["h00v00", "h01v01"]
+    for t, a in first.items():                                           # redone tiles are identical
+        b = np.load(os.path.join(out, t + ".npz"))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (t, k)

@@ -85,7 +85,8 @@ class TwxTiming(C.Structure):
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
-           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points")
+           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
+           "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy")
 
 _LIB = None
 
@@ -108,6 +109,8 @@ def load():
         L.twx_destroy.argtypes = [C.c_void_p]
         L.twx_destroy.restype = None
         L.twx_last_bandwidths.restype = C.c_int64
+        L.twx_stream_destroy.argtypes = [C.c_void_p]
+        L.twx_stream_destroy.restype = None
         _LIB = L
     return _LIB
 
@@ -420,6 +423,10 @@ class Context(object):
         self._chk(self.lib.twx_interp_grid(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask)), "twx_interp_grid")
         return out
 
+    def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2):
+        """Streamed tiles of one shape (twx_stream_*): see ``TileStream``."""
+        return TileStream(self, Y, X, variables, daily, nslots)
+
     def interp_grid_dev(self, g, o, vars_mask, stream=0):
         """Device-pointer entry (TwxGrid / TwxGridOut hold device addresses)."""
         self._chk(self.lib.twx_interp_grid_dev(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask),
@@ -437,3 +444,55 @@ class Context(object):
         t = TwxTiming()
         self._chk(self.lib.twx_get_timing(self.h, C.byref(t)), "twx_get_timing")
         return {k: getattr(t, k) for k, _ in TwxTiming._fields_}
+
+
+class TileStream(object):
+    """Pipelined tiles (twx_stream_create / submit / wait): the outputs of tile t travel to pinned host memory while
+    the kernels of tile t + 1 run.  ``wait(slot)`` returns numpy views of the slot's pinned block; they stay valid
+    until the slot is submitted again (copy or write them out before that)."""
+
+    def __init__(self, ctx, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2):
+        self.ctx, self.Y, self.X, self.daily, self.nslots = ctx, Y, X, daily, nslots
+        self.vars_mask = (VAR_TMIN_BIT if "tmin" in variables else 0) | (VAR_TMAX_BIT if "tmax" in variables else 0)
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.twx_stream_create(ctx.h, C.c_int(Y), C.c_int(X), C.c_int(self.vars_mask), C.c_int(int(daily)),
+                                           C.c_int(nslots), C.byref(h)), "twx_stream_create")
+        self.h = h
+
+    def submit(self, slot, grid, rows=None, cols=None):
+        a = Context.grid_arrays(grid, rows, cols)
+        if a["mask"].shape != (self.Y, self.X):
+            raise ValueError("tile shape differs from the stream's")
+        g = TwxGrid(self.Y, self.X, *[a[k].ctypes.data for k in ("mask", "lat", "lon", "elev", "tdi", "climdiv",
+                                                                 "lst_night", "lst_day")])
+        self.ctx._chk(self.ctx.lib.twx_stream_submit(self.h, C.c_int(slot), C.byref(g)), "twx_stream_submit")
+
+    def wait(self, slot):
+        o = TwxGridOut()
+        ms = C.c_float()
+        self.ctx._chk(self.ctx.lib.twx_stream_wait(self.h, C.c_int(slot), C.byref(o), C.byref(ms)), "twx_stream_wait")
+        Y, X, nd = self.Y, self.X, self.ctx.ndays
+        spec = (("norm_tmin", np.float32, (12, Y, X)), ("se_tmin", np.float32, (12, Y, X)),
+                ("norm_tmax", np.float32, (12, Y, X)), ("se_tmax", np.float32, (12, Y, X)),
+                ("daily_tmin", np.int16, (nd, Y, X)), ("daily_tmax", np.int16, (nd, Y, X)),
+                ("ninvalid", np.int32, (Y, X)), ("status", np.int32, (Y, X)))
+        out = {}
+        for name, dt, shape in spec:
+            ptr = getattr(o, name)
+            if ptr:
+                n = int(np.prod(shape, dtype=np.int64))
+                buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+                out[name] = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+        out["device_ms"] = ms.value
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.twx_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
 // ---------------------------------------------------------------------------------
 struct FixArgs {
     const int32_t *cells;   // flagged local cells (grid mode) or null
-    int ncells;
+    int ncells;             // twx_fix_pair: number of series
+    const int32_t *ncells_dev; // grid mode: number of flagged cells (k_compact_flags), read on the device
     double *scratch;        // [gridDim][2][ndays]
     int32_t *lists;         // [gridDim][ndays]
     double *series_min;     // twx_fix_pair: [nseries][ndays] in/out (chronological), else null
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(256) void k_fix_cells(StnDev stn, StnDev stx, CellS
     double *tmax = tmin + da.ndays;
     int32_t *list = fa.lists + (size_t)blockIdx.x * da.ndays;
     const int64_t yx = (int64_t)src.Y * src.X;
-    for (int it = blockIdx.x; it < fa.ncells; it += gridDim.x) {
+    const int ncells = *fa.ncells_dev;
+    for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
         const int64_t c = wn.cell0 + lc;
         for (int dm = threadIdx.x; dm < da.ndays; dm += 256) {

@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff;
-    int cmax = 512;
+    int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
     void release()
@@ -84,16 +84,20 @@ struct twx_ctx {
     hipEvent_t ev_agg_a = nullptr, ev_agg_b = nullptr;
     // scratch for the point entries / fixer
     DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list;
+    DevBuf grid_in, grid_out;     // persistent device images of the host-buffer grid entry
     // every context-level device buffer (the per-variable ones live in var[] / work[]): twx_destroy releases these
     std::vector<DevBuf *> all_bufs()
     {
-        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list};
+        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list, &stats,
+                &grid_in, &grid_out};
     }
     std::string err;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
     twx_timing timing{};
-    int64_t t_cells = 0, t_solves = 0, t_launches = 0;
+    int64_t t_cells = 0;
+    DevBuf stats;                 // [2] int64: kriging systems solved, kriging launches with work (device-side counters)
+    int ncu = 256;                // compute units (sizes the fixed grids of the kriging launches)
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     bool have_total = false;
 };
@@ -196,9 +200,18 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     return 0;
 }
 
-template <int NB>
-void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
+// Fixed grids: the item count of a bucket is only known on the device.  wpc = work-groups that fit a CU; a few
+// rounds' worth of work-groups stride over the list (at most one work-group per possible item).
+inline unsigned krig_grid(const twx_ctx *ctx, int64_t max_items, int wpc)
 {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_items, (int64_t)ctx->ncu * wpc * 8));
+}
+
+template <int NB>
+void launch_uk(const twx_ctx *ctx, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+{
+    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
+    const unsigned grid = krig_grid(ctx, max_items, TWX_UK_WAVES(NB));
 #ifdef TWX_UK_STAMP   // diagnostic build only: stamp the NB = 7 launch, dump the stamps next to the working directory
     static unsigned long long *dbg = nullptr;
     const size_t nb = (size_t)2048 * 40 * 4 * 4 * 8;
@@ -209,7 +222,7 @@ void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int3
         (void)hipMemsetAsync(dbg, 0, nb, s);
         w2.dbg = dbg;
     }
-    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, w2, cells, cnt);
+    hipLaunchKernelGGL((k_uk<NB>), dim3(grid), dim3(256), 0, s, st, src, w2, cells, ws.bucket_cnt + bucket);
     if (NB == 7) {
         std::vector<unsigned long long> h(nb / 8);
         (void)hipStreamSynchronize(s);
@@ -217,14 +230,16 @@ void launch_uk(const StnDev &st, const CellSrc &src, const SelWs &ws, const int3
         if (FILE *f = fopen("gpurun_out/uk_stamps.bin", "wb")) { fwrite(h.data(), 1, nb, f); fclose(f); }
     }
 #else
-    hipLaunchKernelGGL((k_uk<NB>), dim3(cnt), dim3(256), 0, s, st, src, ws, cells, cnt);
+    hipLaunchKernelGGL((k_uk<NB>), dim3(grid), dim3(256), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 #endif
 }
 
 template <int NBR, int HALF>
-void launch_ukw(const StnDev &st, const CellSrc &src, const SelWs &ws, const int32_t *cells, int cnt, hipStream_t s)
+void launch_ukw(const twx_ctx *ctx, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_ukw<NBR, HALF>), dim3(cnt), dim3(64), 0, s, st, src, ws, cells, cnt);
+    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
+    const unsigned grid = krig_grid(ctx, max_items, 4 * twx_ukw_waves(NBR));
+    hipLaunchKernelGGL((k_ukw<NBR, HALF>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
@@ -234,62 +249,46 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
     const int nblk = (int)std::min<int64_t>(ntile, 2048);
-    for (;;) {
-        if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario)) return -1;
-        HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
-        {
-            EvScope ev(ctx, stream, EV_TILE);
-            hipLaunchKernelGGL(k_tile_cand, dim3(nblk), dim3(256), 0, stream, st, src, w.ws);
-        }
-        int32_t cmax_seen = 0;
-        HIPCHK(hipMemcpyAsync(&cmax_seen, w.ws.ncand_max, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        if (cmax_seen <= w.cmax) break;
-        if (cmax_seen > 4096) return fail(ctx, "candidate list of a tile exceeds 4096 stations (station density too high for tile_cells)");
-        w.cmax = (cmax_seen + 127) / 128 * 128;
+    // No host read-back anywhere below: candidate lists have a fixed stride (a tile with more candidates fails its
+    // cells with TWX_CELL_RANGE), the bucket counts stay on the device and the kriging launches have fixed grids.
+    w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
+    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario)) return -1;
+    HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
+    {
+        EvScope ev(ctx, stream, EV_TILE);
+        hipLaunchKernelGGL(k_tile_cand, dim3(nblk), dim3(256), 0, stream, st, src, w.ws);
     }
     {
-        size_t lds = (size_t)4 * w.cmax * sizeof(double);
-        if (lds > 32768)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         EvScope ev(ctx, stream, EV_SELECT);
-        hipLaunchKernelGGL(k_select, dim3((unsigned)((ncell + 3) / 4)), dim3(256), lds, stream, st, src, w.ws);
+        hipLaunchKernelGGL((k_select<4>), dim3((unsigned)((ncell + 3) / 4)), dim3(256), (size_t)4 * TWX_CAND_SMALL * sizeof(double),
+                           stream, st, src, w.ws, 0, TWX_CAND_SMALL);
+        if (w.cmax > TWX_CAND_SMALL)      // cells of tiles with long candidate lists (dense station clusters)
+            hipLaunchKernelGGL((k_select<1>), dim3((unsigned)ncell), dim3(64), (size_t)w.cmax * sizeof(double), stream, st, src,
+                               w.ws, TWX_CAND_SMALL, w.cmax);
     }
     if (!src.do_krig) return 0;
     if (fit_vario)   // model 1: OLS-residual variogram -> ws.vario, then the kriging kernels give the GLS trend
         hipLaunchKernelGGL(k_vario<0>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
-    int32_t cnt[16];
-    HIPCHK(hipMemcpyAsync(cnt, w.ws.bucket_cnt, sizeof cnt, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(ctx->stats.ensure(64));
+    hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
     {
         EvScope ev(ctx, stream, EV_UK);
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
         hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
-        ctx->t_launches++;
-        for (int b = 0; b < 15; ++b) {
-            if (cnt[b] <= 0) continue;
-            const int32_t *cells = w.ws.bucket_cells + (int64_t)b * ncell * 12;
-            switch (b) {
-            case 13: launch_ukw<6, 1>(st, src, w.ws, cells, cnt[b], stream); break;  // k + 8 <= 88
-            case 14: launch_ukw<6, 0>(st, src, w.ws, cells, cnt[b], stream); break;  // k + 8 <= 96
-            case 0: launch_ukw<3, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 40
-            case 1: launch_ukw<3, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 48
-            case 2: launch_ukw<4, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 56
-            case 3: launch_ukw<4, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 64
-            case 4: launch_ukw<5, 1>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 72
-            case 5: launch_ukw<5, 0>(st, src, w.ws, cells, cnt[b], stream); break;   // k + 8 <= 80
-            case 6: launch_uk<4>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 7: launch_uk<5>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 8: launch_uk<6>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 9: launch_uk<7>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 10: launch_uk<8>(st, src, w.ws, cells, cnt[b], stream); break;
-            case 11: launch_uk<9>(st, src, w.ws, cells, cnt[b], stream); break;
-            default: launch_uk<10>(st, src, w.ws, cells, cnt[b], stream); break;
-            }
-            ctx->t_launches++;
-            ctx->t_solves += (int64_t)cnt[b];
-        }
+        const int64_t mi = ncell * 12;
+        launch_ukw<6, 1>(ctx, st, src, w.ws, 13, mi, stream);   // k + 8 <= 88
+        launch_ukw<6, 0>(ctx, st, src, w.ws, 14, mi, stream);   // k + 8 <= 96
+        launch_ukw<3, 1>(ctx, st, src, w.ws, 0, mi, stream);    // k + 8 <= 40
+        launch_ukw<3, 0>(ctx, st, src, w.ws, 1, mi, stream);    // k + 8 <= 48
+        launch_ukw<4, 1>(ctx, st, src, w.ws, 2, mi, stream);    // k + 8 <= 56
+        launch_ukw<4, 0>(ctx, st, src, w.ws, 3, mi, stream);    // k + 8 <= 64
+        launch_ukw<5, 1>(ctx, st, src, w.ws, 4, mi, stream);    // k + 8 <= 72
+        launch_ukw<5, 0>(ctx, st, src, w.ws, 5, mi, stream);    // k + 8 <= 80
+        launch_uk<7>(ctx, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: four-wave kernel)
+        launch_uk<8>(ctx, st, src, w.ws, 10, mi, stream);
+        launch_uk<9>(ctx, st, src, w.ws, 11, mi, stream);
+        launch_uk<10>(ctx, st, src, w.ws, 12, mi, stream);
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit
@@ -349,6 +348,10 @@ int twx_create(int device, const twx_params *params, twx_ctx **out)
     if (ctx->p.norm_yr0 == 0 && ctx->p.norm_yr1 == 0) { ctx->p.norm_yr0 = 1981; ctx->p.norm_yr1 = 2010; }
     if (ctx->p.tile_cells <= 0) ctx->p.tile_cells = 8;
     if (ctx->p.init_nnghs > TWX_MAX_NNGHS) { delete ctx; return -5; }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->ncu = prop.multiProcessorCount;
+    }
     (void)hipEventCreate(&ctx->ev_total_a);
     (void)hipEventCreate(&ctx->ev_total_b);
     *out = ctx;
@@ -981,7 +984,21 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
     const int ntx = (X + ts - 1) / ts;
     int64_t batch = ctx->p.batch_cells > 0 ? ctx->p.batch_cells : (daily ? 32768 : 131072);
     int band = (int)std::max<int64_t>(ts, batch / X / ts * ts);
-    ctx->ev_used = 0; ctx->t_cells = 0; ctx->t_solves = 0; ctx->t_launches = 0;
+    ctx->ev_used = 0; ctx->t_cells = 0;
+    // outputs start at the netCDF fill values the reference's worker pre-fills with (step25:68-88): failed and
+    // masked cells are never written afterwards
+    {
+        const size_t yx = (size_t)g->Y * g->X;
+        uint32_t f4bits; const float f4 = TWX_FILL_F4; std::memcpy(&f4bits, &f4, 4);
+        for (float *pf : {has_n ? o->norm_tmin : nullptr, has_n ? o->se_tmin : nullptr, has_x ? o->norm_tmax : nullptr,
+                          has_x ? o->se_tmax : nullptr})
+            if (pf) HIPCHK(hipMemsetD32Async(pf, (int)f4bits, yx * 12, stream));
+        for (int16_t *pd : {has_n ? o->daily_tmin : nullptr, has_x ? o->daily_tmax : nullptr})
+            if (pd) HIPCHK(hipMemsetD16Async(pd, (unsigned short)TWX_FILL_I2, yx * (size_t)ctx->ndays, stream));
+        if (o->ninvalid) HIPCHK(hipMemsetD32Async(o->ninvalid, (int)TWX_FILL_I4, yx, stream));
+    }
+    HIPCHK(ctx->stats.ensure(64));
+    HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 64, stream));
     HIPCHK(hipEventRecord(ctx->ev_total_a, stream));
     ctx->have_total = true;
     for (int r0 = 0; r0 < Y; r0 += band) {
@@ -1031,20 +1048,16 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             if (has_n && has_x) {
                 hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_flag,
                                    ncell, ctx->flag_list.as<int32_t>(), d_count);
-                int32_t nflag = 0;
-                HIPCHK(hipMemcpyAsync(&nflag, d_count, 4, hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
-                if (nflag > 0) {
-                    const int nb = std::min(nflag, 1024);
-                    HIPCHK(ctx->fix_scratch.ensure((size_t)nb * 2 * ctx->ndays * 8));
-                    HIPCHK(ctx->fix_lists.ensure((size_t)nb * ctx->ndays * 4));
-                    FixArgs fa{};
-                    fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells = nflag;
-                    fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
-                    EvScope ev(ctx, stream, EV_FIX);
-                    hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
-                                       ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
-                }
+                // the number of flagged cells stays on the device: a fixed grid strides over the list
+                const int nb = (int)std::min<int64_t>(ncell, 512);
+                HIPCHK(ctx->fix_scratch.ensure((size_t)nb * 2 * ctx->ndays * 8));
+                HIPCHK(ctx->fix_lists.ensure((size_t)nb * ctx->ndays * 4));
+                FixArgs fa{};
+                fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count;
+                fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
+                EvScope ev(ctx, stream, EV_FIX);
+                hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
+                                   ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
             }
         }
     }
@@ -1053,58 +1066,204 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
     return 0;
 }
 
+namespace {
+// device images of a grid call's inputs / outputs carved out of two persistent buffers
+struct GridDev {
+    twx_grid g{};
+    twx_grid_out o{};
+    struct Item { void *host; void *dev; size_t bytes; };
+    std::vector<Item> in_items, out_items;
+};
+
+size_t grid_in_bytes(int Y, int X) { return (size_t)Y * X * (1 + 4 + 4 + 24 * 4) + (size_t)(Y + X) * 8 + 16 * 256; }
+size_t grid_out_bytes(int Y, int X, int64_t ndays, bool dn, bool dx)
+{
+    return (size_t)Y * X * (4 * 48 + 8) + ((dn ? 1 : 0) + (dx ? 1 : 0)) * (size_t)Y * X * (size_t)ndays * 2 + 16 * 256;
+}
+
+// lay the device images out in din / dout; host pointers that are null stay null
+void carve_grid(const twx_grid *g, const twx_grid_out *o, int vars, int64_t ndays, char *din, char *dout, GridDev &gd)
+{
+    const size_t yx = (size_t)g->Y * g->X, nd = (size_t)ndays;
+    const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
+    auto in = [&](const void *h, size_t bytes) -> void * {
+        if (!h) return nullptr;
+        void *d = carve<char>(din, bytes);
+        gd.in_items.push_back({const_cast<void *>(h), d, bytes});
+        return d;
+    };
+    auto out = [&](void *h, size_t bytes) -> void * {
+        if (!h) return nullptr;
+        void *d = carve<char>(dout, bytes);
+        gd.out_items.push_back({h, d, bytes});
+        return d;
+    };
+    gd.g = *g;
+    gd.g.mask = (const uint8_t *)in(g->mask, yx);
+    gd.g.lat = (const double *)in(g->lat, (size_t)g->Y * 8);
+    gd.g.lon = (const double *)in(g->lon, (size_t)g->X * 8);
+    gd.g.elev = (const float *)in(g->elev, yx * 4);
+    gd.g.tdi = (const float *)in(g->tdi, yx * 4);
+    gd.g.climdiv = nullptr;
+    gd.g.lst_night = has_n ? (const float *)in(g->lst_night, yx * 48) : nullptr;
+    gd.g.lst_day = has_x ? (const float *)in(g->lst_day, yx * 48) : nullptr;
+    gd.o.norm_tmin = (float *)out(o->norm_tmin, yx * 48); gd.o.se_tmin = (float *)out(o->se_tmin, yx * 48);
+    gd.o.norm_tmax = (float *)out(o->norm_tmax, yx * 48); gd.o.se_tmax = (float *)out(o->se_tmax, yx * 48);
+    gd.o.daily_tmin = (int16_t *)out(o->daily_tmin, yx * nd * 2); gd.o.daily_tmax = (int16_t *)out(o->daily_tmax, yx * nd * 2);
+    gd.o.ninvalid = (int32_t *)out(o->ninvalid, yx * 4); gd.o.status = (int32_t *)out(o->status, yx * 4);
+}
+}  // namespace
+
 int twx_interp_grid(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int vars)
 {
     if (!ctx) return -1;
     ctx->err.clear();
     if (!g || !o || g->Y <= 0 || g->X <= 0) return fail(ctx, "twx_interp_grid: bad grid");
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t yx = (size_t)g->Y * g->X, nd = (size_t)ctx->ndays;
+    // persistent device images (grown on demand, released by twx_destroy): no allocation per call, and the outputs
+    // are filled on the device -- nothing but the 61 B / cell of predictors goes up
+    HIPCHK(ctx->grid_in.ensure(grid_in_bytes(g->Y, g->X)));
+    HIPCHK(ctx->grid_out.ensure(grid_out_bytes(g->Y, g->X, ctx->ndays, o->daily_tmin != nullptr, o->daily_tmax != nullptr)));
+    GridDev gd;
+    carve_grid(g, o, vars, ctx->ndays, ctx->grid_in.as<char>(), ctx->grid_out.as<char>(), gd);
+    for (auto &it : gd.in_items) HIPCHK(hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, nullptr));
+    if (twx_interp_grid_dev(ctx, &gd.g, &gd.o, vars, nullptr)) return -1;
+    for (auto &it : gd.out_items) HIPCHK(hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, nullptr));
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(ctx, "twx_interp_grid: kernel execution failed", hipGetLastError());
+    return 0;
+}
+
+// ---- streamed tiles (step25:177-185, tiling.py:488-537: every chunk is written as soon as it is finished) ---------
+struct twx_stream {
+    twx_ctx *ctx = nullptr;
+    int Y = 0, X = 0, vars = 0, daily = 0, nslots = 0;
+    size_t in_bytes = 0, out_bytes = 0;
+    hipStream_t s_comp = nullptr, s_copy = nullptr;
+    DevBuf din[2], dout[2];                       // double-buffered device images
+    std::vector<char *> hin, hout;                // pinned host staging per slot
+    std::vector<GridDev> views;                   // per slot: where its outputs live in hout[slot]
+    std::vector<hipEvent_t> ev_start, ev_comp, ev_done;   // per slot
+    hipEvent_t ev_free[2] = {nullptr, nullptr};   // device set d has been copied out
+    bool used[2] = {false, false};
+    int64_t nsub = 0;
+};
+
+void twx_stream_destroy(twx_stream *st);
+
+int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslots, twx_stream **out)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    if (!out || Y <= 0 || X <= 0 || nslots < 1 || nslots > 16 || !(vars & 3)) return fail(ctx, "twx_stream_create: bad arguments");
+    if (daily && ctx->ndays <= 0) return fail(ctx, "twx_stream_create: daily output needs the day axis (twx_set_days)");
+    HIPCHK(hipSetDevice(ctx->device));
+    twx_stream *st = new twx_stream();
+    st->ctx = ctx; st->Y = Y; st->X = X; st->vars = vars; st->daily = daily; st->nslots = nslots;
     const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
-    DevBuf in, outb;
-    size_t ib = yx * (1 + 4 + 4 + 24 * 4) + (size_t)(g->Y + g->X) * 8 + 8192;
-    size_t ob = yx * (4 * 48 + 8) + ((o->daily_tmin ? 1 : 0) + (o->daily_tmax ? 1 : 0)) * yx * nd * 2 + 8192;
-    int rc = -1;
-    twx_grid gd = *g;
-    twx_grid_out od{};
-    do {
-        if (in.ensure(ib) != hipSuccess || outb.ensure(ob) != hipSuccess) { fail(ctx, "twx_interp_grid: device allocation failed"); break; }
-        char *cur = in.as<char>();
-        auto up = [&](const void *h, size_t bytes) -> void * {
-            if (!h) return nullptr;
-            void *d = carve<char>(cur, bytes);
-            return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? d : nullptr;
-        };
-        gd.mask = (const uint8_t *)up(g->mask, yx);
-        gd.lat = (const double *)up(g->lat, (size_t)g->Y * 8);
-        gd.lon = (const double *)up(g->lon, (size_t)g->X * 8);
-        gd.elev = (const float *)up(g->elev, yx * 4);
-        gd.tdi = (const float *)up(g->tdi, yx * 4);
-        gd.climdiv = nullptr;
-        gd.lst_night = has_n ? (const float *)up(g->lst_night, yx * 48) : nullptr;
-        gd.lst_day = has_x ? (const float *)up(g->lst_day, yx * 48) : nullptr;
-        char *oc = outb.as<char>();
-        struct Item { void *host; void *dev; size_t bytes; };
-        std::vector<Item> items;
-        auto mk = [&](void *h, size_t bytes) -> void * {
-            if (!h) return nullptr;
-            void *d = carve<char>(oc, bytes);
-            items.push_back({h, d, bytes});
-            return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? d : nullptr;  // keep the caller's fill values
-        };
-        od.norm_tmin = (float *)mk(o->norm_tmin, yx * 48); od.se_tmin = (float *)mk(o->se_tmin, yx * 48);
-        od.norm_tmax = (float *)mk(o->norm_tmax, yx * 48); od.se_tmax = (float *)mk(o->se_tmax, yx * 48);
-        od.daily_tmin = (int16_t *)mk(o->daily_tmin, yx * nd * 2); od.daily_tmax = (int16_t *)mk(o->daily_tmax, yx * nd * 2);
-        od.ninvalid = (int32_t *)mk(o->ninvalid, yx * 4); od.status = (int32_t *)mk(o->status, yx * 4);
-        if (twx_interp_grid_dev(ctx, &gd, &od, vars, nullptr)) break;
-        if (hipDeviceSynchronize() != hipSuccess) { fail(ctx, "twx_interp_grid: kernel execution failed", hipGetLastError()); break; }
-        bool ok = true;
-        for (auto &it : items) ok = ok && hipMemcpy(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) { fail(ctx, "twx_interp_grid: copy back failed"); break; }
-        rc = 0;
-    } while (0);
-    in.release(); outb.release();
-    return rc;
+    st->in_bytes = grid_in_bytes(Y, X);
+    st->out_bytes = grid_out_bytes(Y, X, ctx->ndays, daily && has_n, daily && has_x);
+    bool ok = hipStreamCreateWithFlags(&st->s_comp, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->s_copy, hipStreamNonBlocking) == hipSuccess;
+    for (int d = 0; ok && d < 2; ++d)
+        ok = st->din[d].ensure(st->in_bytes) == hipSuccess && st->dout[d].ensure(st->out_bytes) == hipSuccess &&
+             hipEventCreateWithFlags(&st->ev_free[d], hipEventDisableTiming) == hipSuccess;
+    st->hin.assign(nslots, nullptr); st->hout.assign(nslots, nullptr);
+    st->views.resize(nslots); st->ev_start.assign(nslots, nullptr); st->ev_comp.assign(nslots, nullptr); st->ev_done.assign(nslots, nullptr);
+    for (int i = 0; ok && i < nslots; ++i)
+        ok = hipHostMalloc((void **)&st->hin[i], st->in_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void **)&st->hout[i], st->out_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreate(&st->ev_start[i]) == hipSuccess && hipEventCreate(&st->ev_comp[i]) == hipSuccess &&
+             hipEventCreate(&st->ev_done[i]) == hipSuccess;
+    if (!ok) { twx_stream_destroy(st); return fail(ctx, "twx_stream_create: allocation failed (device images / pinned host staging)"); }
+    *out = st;
+    return 0;
+}
+
+void twx_stream_destroy(twx_stream *st)
+{
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    if (st->s_comp) (void)hipStreamSynchronize(st->s_comp);
+    if (st->s_copy) (void)hipStreamSynchronize(st->s_copy);
+    for (int d = 0; d < 2; ++d) { st->din[d].release(); st->dout[d].release(); if (st->ev_free[d]) (void)hipEventDestroy(st->ev_free[d]); }
+    for (char *p : st->hin) if (p) (void)hipHostFree(p);
+    for (char *p : st->hout) if (p) (void)hipHostFree(p);
+    for (auto *v : {&st->ev_start, &st->ev_comp, &st->ev_done})
+        for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+    if (st->s_comp) (void)hipStreamDestroy(st->s_comp);
+    if (st->s_copy) (void)hipStreamDestroy(st->s_copy);
+    delete st;
+}
+
+int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
+{
+    if (!st) return -1;
+    twx_ctx *ctx = st->ctx;
+    ctx->err.clear();
+    if (!g || slot < 0 || slot >= st->nslots || g->Y != st->Y || g->X != st->X) return fail(ctx, "twx_stream_submit: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int d = (int)(st->nsub & 1);
+    const bool has_n = st->vars & TWX_VAR_TMIN_BIT, has_x = st->vars & TWX_VAR_TMAX_BIT;
+    // output layout of this slot inside its pinned block (pointers only mark which outputs exist)
+    twx_grid_out want{};
+    char *const mark = st->hout[slot];
+    if (has_n) { want.norm_tmin = (float *)mark; want.se_tmin = (float *)mark; if (st->daily) want.daily_tmin = (int16_t *)mark; }
+    if (has_x) { want.norm_tmax = (float *)mark; want.se_tmax = (float *)mark; if (st->daily) want.daily_tmax = (int16_t *)mark; }
+    want.ninvalid = (int32_t *)mark; want.status = (int32_t *)mark;
+    GridDev dev;
+    carve_grid(g, &want, st->vars, ctx->ndays, st->din[d].as<char>(), st->dout[d].as<char>(), dev);
+    // stage the predictors in pinned memory (61 B / cell), then everything else is asynchronous
+    char *hin = st->hin[slot];
+    HIPCHK(hipEventSynchronize(st->ev_done[slot]));                 // the slot's previous tile has left the device
+    for (auto &it : dev.in_items) {
+        std::memcpy(hin, it.host, it.bytes);
+        if (st->used[d]) HIPCHK(hipStreamWaitEvent(st->s_comp, st->ev_free[d], 0));   // device set d copied out
+        HIPCHK(hipMemcpyAsync(it.dev, hin, it.bytes, hipMemcpyHostToDevice, st->s_comp));
+        hin += (it.bytes + 255) / 256 * 256;
+    }
+    HIPCHK(hipEventRecord(st->ev_start[slot], st->s_comp));
+    if (twx_interp_grid_dev(ctx, &dev.g, &dev.o, st->vars, st->s_comp)) return -1;
+    HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_comp));
+    // copy stream: device set d -> the slot's pinned block, overlapping the next tile's kernels
+    HIPCHK(hipStreamWaitEvent(st->s_copy, st->ev_comp[slot], 0));
+    GridDev &view = st->views[slot];
+    view = GridDev{};
+    char *hout = st->hout[slot];
+    twx_grid_out hv{};
+    void **fields_dev[8] = {(void **)&dev.o.norm_tmin, (void **)&dev.o.se_tmin, (void **)&dev.o.norm_tmax, (void **)&dev.o.se_tmax,
+                            (void **)&dev.o.daily_tmin, (void **)&dev.o.daily_tmax, (void **)&dev.o.ninvalid, (void **)&dev.o.status};
+    void **fields_host[8] = {(void **)&hv.norm_tmin, (void **)&hv.se_tmin, (void **)&hv.norm_tmax, (void **)&hv.se_tmax,
+                             (void **)&hv.daily_tmin, (void **)&hv.daily_tmax, (void **)&hv.ninvalid, (void **)&hv.status};
+    size_t k = 0;
+    for (int f = 0; f < 8; ++f) {
+        if (!*fields_dev[f]) continue;
+        const size_t bytes = dev.out_items[k++].bytes;
+        *fields_host[f] = hout;
+        HIPCHK(hipMemcpyAsync(hout, *fields_dev[f], bytes, hipMemcpyDeviceToHost, st->s_copy));
+        hout += (bytes + 255) / 256 * 256;
+    }
+    view.o = hv;
+    HIPCHK(hipEventRecord(st->ev_free[d], st->s_copy));
+    HIPCHK(hipEventRecord(st->ev_done[slot], st->s_copy));
+    st->used[d] = true;
+    st->nsub++;
+    return 0;
+}
+
+int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device_ms)
+{
+    if (!st) return -1;
+    twx_ctx *ctx = st->ctx;
+    ctx->err.clear();
+    if (slot < 0 || slot >= st->nslots || !views) return fail(ctx, "twx_stream_wait: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventSynchronize(st->ev_done[slot]));
+    *views = st->views[slot].o;
+    if (device_ms) {
+        *device_ms = 0.f;
+        if (st->views[slot].o.status) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
+    }
+    return 0;
 }
 
 int twx_get_timing(twx_ctx *ctx, twx_timing *t)
@@ -1125,7 +1284,9 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
         HIPCHK(hipEventSynchronize(ctx->ev_total_b));
         HIPCHK(hipEventElapsedTime(&r.total_ms, ctx->ev_total_a, ctx->ev_total_b));
     }
-    r.cells = ctx->t_cells; r.uk_solves = ctx->t_solves; r.uk_launches = ctx->t_launches;
+    long long st[2] = {0, 0};
+    if (ctx->stats.p) HIPCHK(hipMemcpy(st, ctx->stats.p, sizeof st, hipMemcpyDeviceToHost));
+    r.cells = ctx->t_cells; r.uk_solves = st[0]; r.uk_launches = st[1];
     *t = r;
     return 0;
 }

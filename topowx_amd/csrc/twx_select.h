@@ -18,7 +18,7 @@
 // Workspace of one (batch, variable)
 struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
-    int cmax;            // candidate slots per tile
+    int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_RANGE)
     int init_nnghs;
     int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_ukw)
     int64_t cell0;       // first global cell id of the batch
@@ -163,13 +163,18 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
 }
 
 // ---------------------------------------------------------------------------------
-// k_select: one wavefront per cell (4 cells per workgroup).
+// k_select<WPB>: one wavefront per cell (WPB cells per workgroup).
 //   a1/a2  distances to the tile's candidates, rank by counting (ties -> smaller
 //          station index), nearest list by rank
 //   a3     nnghs / nnghs_anom = int(rint(weighted mean of neighbours' optimum))
 //   a4     variogram parameters = weighted means over Select(nnghs)
-// Dynamic LDS: 4 * cmax doubles.
+// Two launches cover a batch without the host ever looking at the candidate counts: <4> with room for
+// TWX_CAND_SMALL candidates per cell in LDS takes the cells of ordinary tiles, <1> with room for a full list
+// (ws.cmax) the cells of tiles that hold more (dense station clusters); each cell is handled by exactly one of
+// them (clo < ncand <= chi; masked cells belong to the first).  Dynamic LDS: WPB * chi doubles.
 // ---------------------------------------------------------------------------------
+#define TWX_CAND_SMALL 512
+#define TWX_CAND_MAX 2048    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS)
 struct SmoothOut { int status; int k; };
 
 __device__ __forceinline__ double bisq(double d, double dbw)
@@ -207,18 +212,19 @@ __device__ __forceinline__ int smooth3(const double *snd, const int *sidx, int n
     return TWX_CELL_OK;
 }
 
-__global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws)
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, SelWs ws, int clo, int chi)
 {
     extern __shared__ double s_dyn[];
-    __shared__ double s_nd[4][TWX_KSEL_MAX];
-    __shared__ int s_ni[4][TWX_KSEL_MAX];
-    __shared__ int s_np[4][TWX_KSEL_MAX];
+    __shared__ double s_nd[WPB][TWX_KSEL_MAX];
+    __shared__ int s_ni[WPB][TWX_KSEL_MAX];
+    __shared__ int s_np[WPB][TWX_KSEL_MAX];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t lc = (int64_t)blockIdx.x * 4 + wv;        // local cell
-    const bool in_range = lc < ws.ncell;
+    const int64_t lc = (int64_t)blockIdx.x * WPB + wv;      // local cell
+    bool in_range = lc < ws.ncell;
     const int64_t c = ws.cell0 + (in_range ? lc : 0);       // global cell id
-    const bool valid = in_range && cell_valid(src, c);
-    double *sd = s_dyn + (size_t)wv * ws.cmax;
+    bool valid = in_range && cell_valid(src, c);
+    double *sd = s_dyn + (size_t)wv * chi;
     double *snd = s_nd[wv];
     int *sni = s_ni[wv];
     int *snp = s_np[wv];
@@ -227,13 +233,20 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
     const int32_t *cand = nullptr;
     CellVals cv = {0, 0, 0, 0};
     int excl = -1;
+    bool too_many = false;
     if (valid) {
         int64_t tl = cell_tile(src, c) - ws.tile0;
-        ncand = min(ws.ncand[tl], ws.cmax);
+        ncand = ws.ncand[tl];
+        too_many = ncand > ws.cmax;                         // the tile's list was truncated: fail its cells, never guess
+        if (too_many) ncand = 0;
         cand = ws.cand + tl * ws.cmax;
         cv = cell_load(src, c);
         if (src.mode == 1 && src.excl) excl = src.excl[c];
     }
+    // which of the two launches owns this cell (wave-uniform)
+    const int nc_tile = valid ? (too_many ? 0 : ncand) : 0;
+    if (!(nc_tile > clo && nc_tile <= chi) && !(clo == 0 && nc_tile == 0)) in_range = false;
+    if (!in_range) { valid = false; ncand = 0; }
     // phase 1: distances
     int nv = 0;
     for (int j = lane; j < ncand; j += 64) {
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) void k_select(StnDev st, CellSrc src, SelWs ws
         return;
     }
     // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
-    int status = TWX_CELL_OK, kkmax = 0;
+    int status = too_many ? TWX_CELL_RANGE : TWX_CELL_OK, kkmax = 0;
     const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;
@@ -378,4 +391,14 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
     if (t < 15 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
     __syncthreads();
     if (id >= 0) ws.bucket_cells[(int64_t)id * ws.ncell * 12 + s_base[id] + rank] = (int32_t)item;
+}
+
+// launch statistics for twx_get_timing without a host read-back on the launch path: stats[0] += systems solved,
+// stats[1] += kriging launches that had work (+ 1 for k_cell_dist)
+__global__ void k_bucket_stats(SelWs ws, long long *stats)
+{
+    const int b = threadIdx.x;
+    const int c = b < 15 ? ws.bucket_cnt[b] : 0;
+    const int tot = wave_sum_i(c), nz = wave_sum_i(c > 0 ? 1 : 0);
+    if (b == 0) { atomicAdd((unsigned long long *)&stats[0], (unsigned long long)tot); atomicAdd((unsigned long long *)&stats[1], (unsigned long long)(nz + 1)); }
 }

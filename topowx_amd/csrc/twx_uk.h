@@ -210,7 +210,7 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 template <int NB>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
-void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
+void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
     constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
@@ -226,11 +226,14 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     // Which wave holds which four columns of a block is rotated per work-group: the work-groups resident on
     // a CU run in near lockstep, and without the rotation their panel factorisations (one wave each) would
     // all queue on the same SIMD while the other three idle.
-    const int rot = (int)((blockIdx.x * 2654435761u) >> 13) & 3;
+    // The item count of this matrix-size bucket lives in device memory (k_bucket_items): the host never reads it,
+    // the launch has a fixed grid and every work-group strides over the list.
+    const int nitems = *nitems_dev;
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int rot = (int)(((unsigned)it * 2654435761u) >> 13) & 3;
     const int wvp = (wv + rot) & 3;              // column group of this wave
     const int tc = 4 * wvp + tcl;
-    if ((int)blockIdx.x >= nitems) return;
-    const int item = item_list[blockIdx.x];
+    const int item = item_list[it];
     const int64_t lc = item / 12;
     const int m0 = item % 12;
     const int64_t c = ws.cell0 + lc;
@@ -425,6 +428,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems
     }
     __syncthreads();
     if (t == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = s_err ? 1.0 : 0.0;
+    __syncthreads();                             // s_err / the LDS images are reused by the next item
+    }
 }
 
 // ---------------------------------------------------------------------------------

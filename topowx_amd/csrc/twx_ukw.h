@@ -32,7 +32,7 @@ __device__ __forceinline__ constexpr int widx(int a, int b) { return 2 * a * (a 
 template <int NBR, int HALF>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukw_waves(NBR), twx_ukw_waves(NBR))))
-void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitems)
+void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
     constexpr int NP = NBR * 16, NC = NP / 4, NT = 2 * NBR * (NBR + 1);
     constexpr int R0 = HALF ? 1 : 9, RHS0 = 16 * (NBR - 1) + R0;       // first RHS row / column
@@ -42,8 +42,10 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
     __shared__ double s_B[7][NP];
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
-    if ((int)blockIdx.x >= nitems) return;
-    const int item = item_list[blockIdx.x];
+    // fixed grid, device-side item count (see k_uk)
+    const int nitems = *nitems_dev;
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int item = item_list[it];
     const int64_t lc = item / 12;
     const int m0 = item % 12;
     const int64_t c = ws.cell0 + lc;
@@ -222,4 +224,6 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, int nitem
         });
     }
     if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00) ? 0.0 : 1.0;   // singular / indefinite
+    __syncthreads();                             // the LDS images are reused by the next item
+    }
 }

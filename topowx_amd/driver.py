@@ -66,7 +66,8 @@ def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, d
     buf = np.full((nmax, len(keys), 12, tile_y, tile_x), FILL_F4, np.float32)
     for s, (k, _, _, _) in enumerate(assignment[rank]):
         for q, key in enumerate(keys):
-            buf[s, q] = local[k][key]
+            a = local[k][key]                                  # an edge tile may be smaller than tile_y x tile_x
+            buf[s, q, :, :a.shape[1], :a.shape[2]] = a
     t = torch.from_numpy(buf).to(device)
     if world > 1:
         parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
@@ -80,7 +81,8 @@ def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, d
         arr = parts[r].cpu().numpy()
         for s, (k, i, j, _) in enumerate(assignment[r]):
             for q, key in enumerate(keys):
-                mosaic[key][:, i:i + tile_y, j:j + tile_x] = arr[s, q]
+                m = mosaic[key][:, i:i + tile_y, j:j + tile_x]    # clipped at the grid edge
+                m[...] = arr[s, q][:, :m.shape[1], :m.shape[2]]
     return mosaic
 
 

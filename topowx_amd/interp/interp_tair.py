@@ -12,7 +12,7 @@ from ..stationdb import (BAD, CLIMDIV, ELEV, LAT, LON, MASK, TDI, StationDataWrk
 from .station_select import StationSelect, raise_for_status
 
 __all__ = ["GwrTairAnom", "KrigTair", "KrigTairAll", "BuildKrigParams", "InterpTair", "StationDataWrkChk",
-           "PtInterpTair", "build_empty_pt", "tmin_tmax_fixer"]
+           "PtInterpTair", "build_empty_pt", "tmin_tmax_fixer", "chunk_to_grid"]
 
 DFLT_INIT_NNGHS = 100  # interp_tair.py:51
 
@@ -171,6 +171,13 @@ class PredictorGrids(object):
         return out
 
 
+def chunk_to_grid(wrk_chk):
+    """The reference's f8[32, Y, X] work chunk (tiling.py:205-213) as the grid dict the C ABI bindings take."""
+    w = np.asarray(wrk_chk)
+    return dict(lat=w[3, :, 0], lon=w[4, 0, :], mask=(w[2] != 0) & np.isfinite(w[2]),
+                elev=w[5], tdi=w[6], climdiv=np.nan_to_num(w[7]), lst_night=w[8:20], lst_day=w[20:32])
+
+
 class PtInterpTair(object):
     """Tmin and Tmax at a point / over a work chunk (interp_tair.py:441-592).
 
@@ -236,11 +243,8 @@ class PtInterpTair(object):
         ``wrk_chk`` planes: 0 row, 1 col, 2 mask, 3 lat, 4 lon, 5 elev, 6 tdi, 7 climdiv,
         8-19 LST night (tmin01..12), 20-31 LST day (tmax01..12).
         """
-        w = np.asarray(wrk_chk)
-        grid = dict(lat=w[3, :, 0], lon=w[4, 0, :], mask=(w[2] != 0) & np.isfinite(w[2]),
-                    elev=w[5], tdi=w[6], climdiv=np.nan_to_num(w[7]), lst_night=w[8:20], lst_day=w[20:32])
         daily = (not self.norms_only) if daily is None else daily
-        return self.ctx.interp_grid(grid, daily=daily)
+        return self.ctx.interp_grid(chunk_to_grid(wrk_chk), daily=daily)
 
     def close(self):
         self.ctx.close()

@@ -1,20 +1,34 @@
 """Work-chunk level counterpart of ``scripts/step25_mpi_interp_tair.py`` (proc_work, :49-198).
 
-Keeps the reference's structure -- ``Tiler`` yields f8[32, Y, X] work chunks, a ``PtInterpTair``
-interpolates them, a writer stores ``days x Y x X`` int16 / ``12 x Y x X`` f4 blocks per tile -- but
-one ``interp_chunk`` call replaces the 2 500-iteration Python cell loop, and ranks own whole tiles
-(no per-tile write token, step25:177-196).  Tiles are written as ``<tile_id>.npz`` or, with
-``out_format="nc"``, through ``ncio.TileWriter`` as ``<tile_id>/<tile_id>_<var>.nc``.
+Keeps the reference's structure -- ``Tiler`` yields f8[32, Y, X] work chunks, a ``PtInterpTair`` interpolates them,
+a writer stores ``days x Y x X`` int16 / ``12 x Y x X`` f4 blocks per tile -- but one library call replaces the
+2 500-iteration Python cell loop, ranks own whole tiles (no per-tile write token, step25:177-196) and the chunks run
+through a ``TileStream`` (``twx_stream_*``): while the GPU interpolates chunk i + 1, the outputs of chunk i travel
+to pinned host memory and are written into their tile; a finished tile goes to disk and is dropped at once
+(the reference writes every chunk as it is produced, step25:177-185).
+
+* resume: with ``check_tiles_done`` a tile whose output already exists in ``out_dir`` is skipped, as the
+  reference's ``Tiler.get_incomplete_tile_nums`` does from the directory listing (tiling.py:111-122,258-275,
+  step25:354-356).  Outputs are written under a temporary name and renamed when the tile is complete, so an
+  interrupted tile is redone.
+* log: one JSON line per tile (cells, cells ok, failures by TWX_CELL_* code, device ms, output bytes, seconds).
+
+Tiles are written as ``<tile_id>.npz`` or, with ``out_format="nc"``, through ``ncio.TileWriter`` as
+``<tile_id>/<tile_id>_<var>.nc``.
 """
+import json
 import os
+import shutil
+import time
 
 import numpy as np
 
 from . import _lib
 from .driver import assign_tiles, tile_list
 from .interp import PtInterpTair, Tiler
+from .interp.interp_tair import chunk_to_grid
 
-__all__ = ["TileStore", "proc_work"]
+__all__ = ["TileStore", "proc_work", "tiles_done"]
 
 
 class TileStore(object):
@@ -37,37 +51,114 @@ class TileStore(object):
                 y, x = v.shape[-2:]
                 self.a[k][..., str_row:str_row + y, str_col:str_col + x] = v
 
+    def nbytes(self):
+        return int(sum(v.nbytes for v in self.a.values()))
+
     def save(self, path):
         np.savez_compressed(path, **self.a)
 
 
+def tiles_done(out_dir, tile_ids):
+    """Names of the tiles whose output exists in ``out_dir`` (tiling.py:258-275: the directory listing decides)."""
+    if out_dir is None or not os.path.isdir(out_dir):
+        return set()
+    names = set(os.listdir(out_dir))
+    return {t for t in tile_ids if t in names or (t + ".npz") in names}
+
+
+def _write_tile(out_dir, out_format, info, tile_id, store, days):
+    """Write under a temporary name, rename when complete (an interrupted tile is not mistaken for a finished one)."""
+    if out_format == "nc":                                                     # step25:181-185
+        from .ncio import TileWriter
+        tmp = os.path.join(out_dir, tile_id + ".part")
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        writer = TileWriter(info, tmp)      # files go to <tmp>/<tile_id>/<tile_id>_<var>.nc, the directory is moved when complete
+        for v in ("tmin", "tmax"):
+            writer.write_tile_chunk(tile_id, v, days, 0, 0, store.a.get("daily_" + v), store.a["norm_" + v],
+                                    store.a["se_" + v], store.a["ninvalid"])
+        final = os.path.join(out_dir, tile_id)
+        shutil.rmtree(final, ignore_errors=True)
+        os.replace(os.path.join(tmp, tile_id), final)
+        shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        tmp = os.path.join(out_dir, tile_id + ".part.npz")
+        store.save(tmp)
+        os.replace(tmp, os.path.join(out_dir, tile_id + ".npz"))
+
+
 def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, daily=True, out_dir=None,
-              rank=0, world=1, device=0, out_format="npz"):
-    """Interpolate the tiles of this rank chunk by chunk; returns {tile_id: TileStore}."""
+              rank=0, world=1, device=0, out_format="npz", check_tiles_done=True, keep=None, log=None):
+    """Interpolate the tiles of this rank chunk by chunk.
+
+    Returns ``{tile_id: TileStore}`` of the tiles kept in memory (``keep``; default: only when nothing is written
+    to ``out_dir``).  ``log``: a callable or file object receiving one JSON line per tile (default: none); the
+    records are also returned as ``proc_work.last_log``."""
+    keep = (out_dir is None) if keep is None else keep
     tiles = tile_list(grid["mask"], tile_size, tile_size)
     mine = {t[0] for t in assign_tiles(tiles, world)[rank]}
+    probe = Tiler(grid, tile_size, tile_size, chunk_size, chunk_size, process_tiles=())
+    records = []
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        if check_tiles_done:                                                   # step25:354-356
+            done = tiles_done(out_dir, [probe.tile_ids[k] for k in mine])
+            for k in sorted(mine):
+                if probe.tile_ids[k] in done:
+                    records.append({"tile": probe.tile_ids[k], "skipped": True, "rank": rank})
+            mine = {k for k in mine if probe.tile_ids[k] not in done}
     tiler = Tiler(grid, tile_size, tile_size, chunk_size, chunk_size, process_tiles=mine)
     info = tiler.build_tile_grid_info()
     pt_interp = PtInterpTair(stn_da_tmin, stn_da_tmax, norms_only=not daily, device=device)   # step25:53-55
-    stores = {}
-    for tile_num, wrk_chk in tiler:                                   # step25:94-96
-        tile_id = info.get_tile_id(tile_num)
-        store = stores.setdefault(tile_id, TileStore(pt_interp.days.size, tile_size, tile_size, daily))
-        str_row, str_col = int(wrk_chk[0, 0, 0]), int(wrk_chk[1, 0, 0])            # step25:110-111
-        out = pt_interp.interp_chunk(wrk_chk, daily=daily)                         # step25:126-172 in one call
-        store.write_tile_chunk(str_row, str_col, out)                              # step25:181-185
     days = pt_interp.days
-    pt_interp.close()
-    if out_dir is not None:
-        os.makedirs(out_dir, exist_ok=True)
-        if out_format == "nc":                                                     # step25:181-185
-            from .ncio import TileWriter
-            writer = TileWriter(info, out_dir)
-            for tile_id, store in stores.items():
-                for v in ("tmin", "tmax"):
-                    writer.write_tile_chunk(tile_id, v, days, 0, 0, store.a.get("daily_" + v), store.a["norm_" + v],
-                                            store.a["se_" + v], store.a["ninvalid"])
-        else:
-            for tile_id, store in stores.items():
-                store.save(os.path.join(out_dir, tile_id + ".npz"))
+    stream = pt_interp.ctx.stream(chunk_size, chunk_size, daily=daily, nslots=2)
+    stores, open_tiles, pending = {}, {}, None
+
+    def emit(rec):
+        records.append(rec)
+        if log is not None:
+            line = json.dumps(rec)
+            log(line) if callable(log) else log.write(line + "\n")
+
+    def finish(p):
+        slot, tile_id, str_row, str_col = p
+        out = stream.wait(slot)                                                    # outputs of that chunk are on the host
+        st = open_tiles[tile_id]
+        st["store"].write_tile_chunk(str_row, str_col, out)                        # step25:181-185
+        st["device_ms"] += out["device_ms"]
+        st["left"] -= 1
+        if st["left"] == 0:                                                        # last chunk: write, log, drop
+            store = st["store"]
+            status = store.a["status"]
+            codes, counts = np.unique(status[status > 0], return_counts=True)
+            if out_dir is not None:
+                _write_tile(out_dir, out_format, info, tile_id, store, days)
+            emit({"tile": tile_id, "rank": rank, "cells": int((status != -1).sum()), "ok": int((status == 0).sum()),
+                  "failures": {int(c): int(n) for c, n in zip(codes, counts)}, "device_ms": round(st["device_ms"], 3),
+                  "bytes": store.nbytes(), "seconds": round(time.perf_counter() - st["t0"], 3)})
+            if keep:
+                stores[tile_id] = store
+            del open_tiles[tile_id]
+
+    try:
+        for n, (tile_num, wrk_chk) in enumerate(tiler):                              # step25:94-96
+            tile_id = info.get_tile_id(tile_num)
+            if tile_id not in open_tiles:
+                open_tiles[tile_id] = {"store": TileStore(days.size, tile_size, tile_size, daily), "left": info.chks_per_tile,
+                                       "device_ms": 0.0, "t0": time.perf_counter()}
+            str_row, str_col = int(wrk_chk[0, 0, 0]), int(wrk_chk[1, 0, 0])          # step25:110-111
+            slot = n & 1
+            stream.submit(slot, chunk_to_grid(wrk_chk))                              # step25:126-172 in one call, asynchronous
+            if pending is not None:
+                finish(pending)                                                      # overlaps the chunk just submitted
+            pending = (slot, tile_id, str_row, str_col)
+        if pending is not None:
+            finish(pending)
+    finally:
+        stream.close()
+        pt_interp.close()
+    proc_work.last_log = records
     return stores
+
+
+proc_work.last_log = []
