@@ -212,7 +212,7 @@ def test_step25_to_netcdf_tiles_to_monthly(case, tmp_path):
     sub["lat"], sub["lon"] = grid["lat"][:20], grid["lon"][:40]
     sub["lst_night"], sub["lst_day"] = grid["lst_night"][:, :20, :40], grid["lst_day"][:, :20, :40]
     stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=str(tmp_path),
-                              out_format="nc")
+                              out_format="nc", keep=True)
     tiles = sorted(stores)
     assert tiles == ["h00v00", "h01v00"]
     back = ncio.read_tile_stores(str(tmp_path), tiles)

@@ -98,3 +98,20 @@ def test_step25_resume_and_tile_log(golden_case, tmp_path):
         b = np.load(os.path.join(out, t + ".npz"))
         for k in a:
             assert np.array_equal(a[k], b[k]), (t, k)
+
+
+def test_no_host_sync_mode_equals_default(golden_case):
+    """TWX_FLAG_NO_HOST_SYNC (worst-case kriging grids, nothing read back) gives the same bits as the default."""
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    outs = []
+    for flags in (0, _lib.FLAG_NO_HOST_SYNC):
+        ctx = _lib.Context(flags=flags)
+        ctx.set_stations(_lib.TMIN, tmin)
+        ctx.set_stations(_lib.TMAX, tmax)
+        outs.append(ctx.interp_grid(grid, daily=True, rows=slice(5, 41), cols=slice(50, 97)))
+        t = ctx.timing()
+        assert t["uk_solves"] == 36 * 47 * 24 and t["uk_launches"] >= 2
+        ctx.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -200,18 +200,22 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     return 0;
 }
 
-// Fixed grids: the item count of a bucket is only known on the device.  wpc = work-groups that fit a CU; a few
-// rounds' worth of work-groups stride over the list (at most one work-group per possible item).
-inline unsigned krig_grid(const twx_ctx *ctx, int64_t max_items, int wpc)
+// Grid of a kriging launch.  Default: the host reads the 16 bucket counts back once per (batch, variable) -- one
+// 64-byte copy that waits for the selection kernels -- and launches exactly one work-group per system.  With
+// TWX_FLAG_NO_HOST_SYNC the counts stay on the device and every launch covers the worst case (all systems of the
+// batch in one bucket); surplus work-groups exit on their first instruction (measured on the C2 tile: 9 M surplus
+// work-groups per step = +1.2 ms = +9 % kriging time, which is why it is not the default).
+inline unsigned krig_grid(const int32_t *cnt, int bucket, int64_t max_items)
 {
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_items, (int64_t)ctx->ncu * wpc * 8));
+    return (unsigned)std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items);
 }
 
 template <int NB>
-void launch_uk(const twx_ctx *ctx, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
-    const unsigned grid = krig_grid(ctx, max_items, TWX_UK_WAVES(NB));
+    if (cnt && cnt[bucket] <= 0) return;
+    const unsigned grid = krig_grid(cnt, bucket, max_items);
 #ifdef TWX_UK_STAMP   // diagnostic build only: stamp the NB = 7 launch, dump the stamps next to the working directory
     static unsigned long long *dbg = nullptr;
     const size_t nb = (size_t)2048 * 40 * 4 * 4 * 8;
@@ -235,10 +239,11 @@ void launch_uk(const twx_ctx *ctx, const StnDev &st, const CellSrc &src, const S
 }
 
 template <int NBR, int HALF>
-void launch_ukw(const twx_ctx *ctx, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
-    const unsigned grid = krig_grid(ctx, max_items, 4 * twx_ukw_waves(NBR));
+    if (cnt && cnt[bucket] <= 0) return;
+    const unsigned grid = krig_grid(cnt, bucket, max_items);
     hipLaunchKernelGGL((k_ukw<NBR, HALF>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
@@ -249,8 +254,8 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
     const int nblk = (int)std::min<int64_t>(ntile, 2048);
-    // No host read-back anywhere below: candidate lists have a fixed stride (a tile with more candidates fails its
-    // cells with TWX_CELL_RANGE), the bucket counts stay on the device and the kriging launches have fixed grids.
+    // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_RANGE): the host
+    // never looks at them.  The bucket counts are read back once (exact kriging grids) unless TWX_FLAG_NO_HOST_SYNC.
     w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
     if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario)) return -1;
     HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
@@ -272,23 +277,30 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     HIPCHK(ctx->stats.ensure(64));
     hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
+    int32_t cnt_host[16];
+    const int32_t *cnt = nullptr;
+    if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
+        HIPCHK(hipMemcpyAsync(cnt_host, w.ws.bucket_cnt, sizeof cnt_host, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        cnt = cnt_host;
+    }
     {
         EvScope ev(ctx, stream, EV_UK);
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
         hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
         const int64_t mi = ncell * 12;
-        launch_ukw<6, 1>(ctx, st, src, w.ws, 13, mi, stream);   // k + 8 <= 88
-        launch_ukw<6, 0>(ctx, st, src, w.ws, 14, mi, stream);   // k + 8 <= 96
-        launch_ukw<3, 1>(ctx, st, src, w.ws, 0, mi, stream);    // k + 8 <= 40
-        launch_ukw<3, 0>(ctx, st, src, w.ws, 1, mi, stream);    // k + 8 <= 48
-        launch_ukw<4, 1>(ctx, st, src, w.ws, 2, mi, stream);    // k + 8 <= 56
-        launch_ukw<4, 0>(ctx, st, src, w.ws, 3, mi, stream);    // k + 8 <= 64
-        launch_ukw<5, 1>(ctx, st, src, w.ws, 4, mi, stream);    // k + 8 <= 72
-        launch_ukw<5, 0>(ctx, st, src, w.ws, 5, mi, stream);    // k + 8 <= 80
-        launch_uk<7>(ctx, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: four-wave kernel)
-        launch_uk<8>(ctx, st, src, w.ws, 10, mi, stream);
-        launch_uk<9>(ctx, st, src, w.ws, 11, mi, stream);
-        launch_uk<10>(ctx, st, src, w.ws, 12, mi, stream);
+        launch_ukw<6, 1>(cnt, st, src, w.ws, 13, mi, stream);   // k + 8 <= 88
+        launch_ukw<6, 0>(cnt, st, src, w.ws, 14, mi, stream);   // k + 8 <= 96
+        launch_ukw<3, 1>(cnt, st, src, w.ws, 0, mi, stream);    // k + 8 <= 40
+        launch_ukw<3, 0>(cnt, st, src, w.ws, 1, mi, stream);    // k + 8 <= 48
+        launch_ukw<4, 1>(cnt, st, src, w.ws, 2, mi, stream);    // k + 8 <= 56
+        launch_ukw<4, 0>(cnt, st, src, w.ws, 3, mi, stream);    // k + 8 <= 64
+        launch_ukw<5, 1>(cnt, st, src, w.ws, 4, mi, stream);    // k + 8 <= 72
+        launch_ukw<5, 0>(cnt, st, src, w.ws, 5, mi, stream);    // k + 8 <= 80
+        launch_uk<7>(cnt, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: four-wave kernel)
+        launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);
+        launch_uk<9>(cnt, st, src, w.ws, 11, mi, stream);
+        launch_uk<10>(cnt, st, src, w.ws, 12, mi, stream);
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit

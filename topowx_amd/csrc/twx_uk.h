@@ -226,10 +226,11 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     // Which wave holds which four columns of a block is rotated per work-group: the work-groups resident on
     // a CU run in near lockstep, and without the rotation their panel factorisations (one wave each) would
     // all queue on the same SIMD while the other three idle.
-    // The item count of this matrix-size bucket lives in device memory (k_bucket_items): the host never reads it,
-    // the launch has a fixed grid and every work-group strides over the list.
-    const int nitems = *nitems_dev;
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    // The item count of this matrix-size bucket lives in device memory (k_bucket_items): the host never reads it.
+    // The launch covers the worst case (every system of the batch in this bucket); surplus work-groups leave at
+    // once.  (A fixed grid striding over the list keeps ~100 kernel-argument SGPRs live across the loop and spills.)
+    const int it = blockIdx.x;
+    if (it >= *nitems_dev) return;
     const int rot = (int)(((unsigned)it * 2654435761u) >> 13) & 3;
     const int wvp = (wv + rot) & 3;              // column group of this wave
     const int tc = 4 * wvp + tcl;
@@ -428,8 +429,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     }
     __syncthreads();
     if (t == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = s_err ? 1.0 : 0.0;
-    __syncthreads();                             // s_err / the LDS images are reused by the next item
-    }
 }
 
 // ---------------------------------------------------------------------------------

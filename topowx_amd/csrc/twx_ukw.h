@@ -42,9 +42,9 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     __shared__ double s_B[7][NP];
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
-    // fixed grid, device-side item count (see k_uk)
-    const int nitems = *nitems_dev;
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    // worst-case grid, device-side item count (see k_uk)
+    const int it = blockIdx.x;
+    if (it >= *nitems_dev) return;
     const int item = item_list[it];
     const int64_t lc = item / 12;
     const int m0 = item % 12;
@@ -224,6 +224,4 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         });
     }
     if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00) ? 0.0 : 1.0;   // singular / indefinite
-    __syncthreads();                             // the LDS images are reused by the next item
-    }
 }
