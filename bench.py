@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-daily", action="store_true", help="skip the daily (cell-days) record")
     ap.add_argument("--daily-years", type=int, default=10, help="years of days of the daily record (1981-...)")
+    ap.add_argument("--stream-tiles", type=int, default=4, help="tiles of the streamed (PCIe-inclusive) daily record; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
     return ap.parse_args()
 
@@ -261,7 +262,34 @@ def main():
                                                   "of the observation matrix read through L1/L2), DESIGN.md section 4"}},
             "mean_nnghs": float(kan[kan > 0].mean()),
         }
-        del d_dn, d_dx
+        del d_dn, d_dx, outs
+        torch.cuda.empty_cache()
+        # the same tile streamed: outputs of tile t travel to pinned host memory while tile t + 1 is computed
+        # (twx_stream_*); end to end = host wall clock from the first submit to the last tile in host memory
+        if args.stream_tiles > 0:
+            ts = ctx.stream(Y, X, daily=True, nslots=2)
+            ts.submit(0, grid); ts.wait(0)                       # warm-up: workspace, pinned pages
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dev_ms = 0.0
+            for i in range(args.stream_tiles):
+                ts.submit(i & 1, grid)
+                if i:
+                    dev_ms += ts.wait((i - 1) & 1)["device_ms"]
+            last = ts.wait((args.stream_tiles - 1) & 1)
+            dev_ms += last["device_ms"]
+            wall = time.perf_counter() - t1
+            okc = int((last["status"] == 0).sum())
+            out_bytes = sum(v.nbytes for k, v in last.items() if hasattr(v, "nbytes"))
+            ts.close()
+            e2e = okc * nd * 2 * args.stream_tiles / wall
+            res["daily"]["stream"] = {
+                "tiles": args.stream_tiles, "end_to_end_cell_days_per_s": e2e,
+                "device_only_cell_days_per_s": okc * nd * 2 * args.stream_tiles / (dev_ms * 1e-3),
+                "ratio": e2e / (okc * nd * 2 * args.stream_tiles / (dev_ms * 1e-3)),
+                "wall_s": wall, "device_ms_per_tile": dev_ms / args.stream_tiles,
+                "d2h_bytes_per_tile": out_bytes, "d2h_GBps_if_exposed": out_bytes * args.stream_tiles / wall / 1e9,
+                "note": "host pointers in, pinned host memory out (PCIe-inclusive; never the headline value)"}
 
     # ---- CPU baseline: the oracle on bounded samples of the headline workload ---------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
