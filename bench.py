@@ -253,13 +253,13 @@ def main():
                         "outputs + normals + SE + ninvalid" % (Y, X, args.nstns, nd, args.daily_years),
             "ms_per_step": el2 / args.steps * 1e3, "cell_days_per_step": cell_days, "cells_ok": ok2,
             "timing_ms": tm,
-            "daily_kernel": {"kernel": "k_row_offsets + k_daily_grid", "ms_per_step": tm["daily_ms"],
+            "daily_kernel": {"kernel": "k_tile_union + k_daily_tile (+ k_row_offsets, k_daily_ok, k_daily_tile_gather)", "ms_per_step": tm["daily_ms"],
                              "cell_days_per_s": cell_days / (tm["daily_ms"] * 1e-3),
                              "roofline": {"bound": "hbm", "achieved": dgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": dgbs / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_DAY * cell_days,
-                                          "note": "gather-bound (every cell-day is a ~80-term dot product over rows "
-                                                  "of the observation matrix read through L1/L2), DESIGN.md section 4"}},
+                                          "note": "every cell-day is a ~80-term dot product over observation rows; the rows "
+                                                  "of a tile-month are staged in LDS (VALU / LDS bound), DESIGN.md section 4"}},
             "mean_nnghs": float(kan[kan > 0].mean()),
         }
         del d_dn, d_dx, outs

@@ -76,6 +76,10 @@ typedef struct {
  * Default (flag clear): one 64-byte read-back of the matrix-size counts per (batch, variable), i.e. the host
  * waits for the selection kernels; everything after them -- kriging, GWR, daily values, fixer -- is asynchronous. */
 #define TWX_FLAG_NO_HOST_SYNC 2
+/* daily values: gather every (cell, neighbour) observation row from global memory instead of staging the rows of a
+ * tile-month in LDS (the path a tile-month with more than 224 distinct rows takes; results are bit-identical -- a
+ * test / diagnostic switch).  TWX_FLAG_OBS_ADDR64 implies it. */
+#define TWX_FLAG_DAILY_GATHER 4
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
  * StationSelect's isnan(bad) mask: station_data.py:126-183,609,

@@ -98,22 +98,25 @@ def test_all_stations_leave_one_out_normals(orc):
 
 
 def test_daily_64bit_obs_addressing_equals_32bit(golden_case):
-    """twx_daily.h daily_value2<false>: taken when stations x days >= 2^30; forced here by TWX_FLAG_OBS_ADDR64."""
+    """The three ways a daily value is formed give the same bits: rows of the tile-month staged in LDS (default),
+    gathered from global memory with 32-bit offsets (a tile-month with too many distinct rows; TWX_FLAG_DAILY_GATHER)
+    and with 64-bit offsets (stations x days >= 2^30; TWX_FLAG_OBS_ADDR64)."""
     from topowx_amd import _lib
     import make_golden
     grid, tmin, tmax = golden_case
     tmax = make_golden.lowered_tmax(tmax)                       # so that the fixer runs too
     outs = []
-    for flags in (0, _lib.FLAG_OBS_ADDR64):
+    for flags in (0, _lib.FLAG_DAILY_GATHER, _lib.FLAG_OBS_ADDR64):    # LDS table / 32-bit gather / 64-bit gather
         ctx = _lib.Context(flags=flags)
         ctx.set_stations(_lib.TMIN, tmin)
         ctx.set_stations(_lib.TMAX, tmax)
         outs.append(ctx.interp_grid(grid, daily=True, rows=slice(40, 75), cols=slice(3, 70)))
         ctx.close()
-    a, b = outs
+    a = outs[0]
     assert np.all(a["status"] == 0) and a["ninvalid"].max() > 0
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
+    for b in outs[1:]:
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
 
 
 def test_singular_gwr_abandons_the_cell(golden_case, orc):

@@ -18,11 +18,17 @@ struct DayAxis {
     const int32_t *ym_cnt;    // [norm_ny * 12] days of (year, month)
 };
 
+#define TWX_UROWS 224 // observation rows of a (tile, month) staged in LDS by k_daily_tile (x 64 days x 4 B = 56 KB)
+
 struct GwrWs {
     double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank
     double *zc;       // [ncell][12]          pt_norm - sum_j z_j norm_j
     int32_t *gstat;   // [ncell]
     uint32_t *noff;   // [ncell][ksel] byte offset of each ranked neighbour's observation row (k_row_offsets)
+    // k_tile_union -> k_daily_tile: the stations the cells of an 8x8 tile use in a month, as rows of an LDS table
+    uint32_t *soff;   // [ncell][12][TWX_KZ]  byte offset of the ranked neighbour's row in the tile's table
+    int32_t *urow;    // [ntile][12][TWX_UROWS] station index of table row u
+    int32_t *nurow;   // [ntile][12] rows in the table; -1 = more than TWX_UROWS (the tile-month gathers from global memory)
 };
 
 // ---------------------------------------------------------------------------------
@@ -291,6 +297,322 @@ __global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
     if (i >= ws.ncell * ws.ksel) return;
     const int j = ws.near_idx[i];
     gw.noff[i] = j < 0 ? 0u : (uint32_t)j * (uint32_t)ndays * 4u;
+}
+
+// ---------------------------------------------------------------------------------
+// k_tile_union: one work-group per (8x8-cell tile, month).  The GWR neighbourhoods of a tile's cells overlap
+// almost completely: mark the candidates (positions in the tile's candidate list, k_select) that any cell of
+// the tile uses this month, number them, and give every (cell, rank) the byte offset of its station's row in a
+// table of 64-day f4 rows -- k_daily_tile stages that table in LDS once per 64 days instead of gathering every
+// (cell, neighbour) row through the vector L1.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs gw)
+{
+    __shared__ uint16_t s_slot[TWX_CAND_MAX];
+    __shared__ int s_cnt[4], s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t tl = blockIdx.x / 12;                  // local tile
+    const int m0 = blockIdx.x % 12;
+    const int64_t tile = ws.tile0 + tl;
+    const int ty = (int)(tile / src.ntx), tx = (int)(tile % src.ntx);
+    const int r0 = ty * src.ts, q0 = tx * src.ts;
+    const int ncand = min(ws.ncand[tl], ws.cmax);
+    for (int p = t; p < ncand; p += 256) s_slot[p] = 0;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    // mark: thread pairs (cell, rank)
+    const int ncl = src.ts * src.ts;                     // cells per tile (<= 64)
+    for (int ci = wv; ci < ncl; ci += 4) {
+        const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
+        if (rr >= src.Y || qq >= src.X) continue;
+        const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
+        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
+        const int ka = ws.ka[lc * 12 + m0];
+        for (int r = lane; r < ka; r += 64) s_slot[ws.near_pos[lc * ws.ksel + r]] = 1;
+    }
+    __syncthreads();
+    // number the used candidates in list order (= ascending station index)
+    int nu = 0;
+    for (int p0 = 0; p0 < ncand; p0 += 256) {
+        const int p = p0 + t;
+        const bool f = p < ncand && s_slot[p] != 0;
+        const unsigned long long b = __ballot(f);
+        const int pre = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_cnt[w];
+        if (f) {
+            const int u = off + pre;
+            s_slot[p] = (uint16_t)u;
+            if (u < TWX_UROWS) gw.urow[(tl * 12 + m0) * TWX_UROWS + u] = ws.cand[tl * ws.cmax + p];
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    nu = s_base;
+    if (t == 0) gw.nurow[tl * 12 + m0] = nu <= TWX_UROWS ? nu : -1;
+    if (nu > TWX_UROWS) return;
+    for (int ci = wv; ci < ncl; ci += 4) {
+        const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
+        if (rr >= src.Y || qq >= src.X) continue;
+        const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
+        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
+        const int ka = ws.ka[lc * 12 + m0];
+        for (int r = lane; r < ka; r += 64)
+            gw.soff[(lc * 12 + m0) * TWX_KZ + r] = 256u * (uint32_t)s_slot[ws.near_pos[lc * ws.ksel + r]];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_daily_tile: (8x8-cell tile) x (month) x (64 month-major days), both variables.  Per variable: the tile-month's
+// station rows (k_tile_union) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave
+// walks 16 cells, lane = day: sum_r z_r * row(soff_r)[day] in rank order -- the same fma chain, bit for bit, as
+// daily_value / k_fix_cells -- with the hat row and the row offsets coming through scalar loads and the
+// observations through conflict-free ds_read_b32 (lanes = consecutive days).  Tmin values wait in registers while
+// the table is re-staged for Tmax; cells with any tmin >= tmax are flagged for k_fix_cells; results are transposed
+// through LDS and written as 16-byte runs (8 cells of a tile row) of the [ndays][Y][X] int16 output.
+// A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2), same arithmetic.
+// ---------------------------------------------------------------------------------
+#define TWX_DT_WAVES 16                          // waves per work-group of k_daily_tile (2 work-groups fit a CU: LDS)
+#define TWX_DT_CPW (64 / TWX_DT_WAVES)             // cells per wave
+
+// lean argument block of k_daily_tile (the full workspaces would not fit the scalar registers: 97 spilled SGPRs)
+struct DtVar {
+    const float *obs;         // [n][ndays] month-major
+    const int32_t *ka;        // [ncell][12]
+    const double *z, *zc;     // hat rows / constants
+    const uint32_t *soff;     // [ncell][12][TWX_KZ]
+    const int32_t *urow;      // [ntile][12][TWX_UROWS]
+    const int32_t *nurow;     // [ntile][12]
+};
+struct DtArgs {
+    DtVar n, x;
+    const int32_t *okc;       // [ncell] 1 = both variables of the cell are fine (k_daily_ok)
+    const int32_t *mm2chron;
+    int16_t *out_n, *out_x;   // [ndays][Y][X]
+    int32_t *flag;
+    int64_t cell0, ncell, tile0;
+    int Y, X, ts, ntx, ndays, nblk_max, gather;
+    int moff[13];
+};
+
+// cells whose two variables both came through selection, kriging and the GWR hat rows
+__global__ void k_daily_ok(SelWs wn, SelWs wx, GwrWs gn, GwrWs gx, int32_t *okc)
+{
+    const int64_t lc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= wn.ncell) return;
+    okc[lc] = wn.cstat[lc] == 0 && wn.uk_stat[lc] == 0 && gn.gstat[lc] == 0 && wx.cstat[lc] == 0 && wx.uk_stat[lc] == 0 &&
+              gx.gstat[lc] == 0;
+}
+
+__device__ __forceinline__ int64_t dt_cell(const DtArgs &a, int r0, int q0, int cl)
+{
+    const int rr = r0 + cl / a.ts, qq = q0 + cl % a.ts;
+    if (cl >= a.ts * a.ts || rr >= a.Y || qq >= a.X) return -1;
+    const int64_t lc = (int64_t)rr * a.X + qq - a.cell0;
+    if (lc < 0 || lc >= a.ncell || !a.okc[lc]) return -1;
+    return lc;
+}
+
+// acc += bcast(z, lane N of this lane's 16-lane row) * x   (v_fmac_f64 with a DPP row_newbcast source, see twx_uk.h)
+template <int N>
+__device__ __forceinline__ void dt_fmac(double &acc, double z, double x)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(z), "v"(x), "n"(N));
+}
+
+// bcast(off, lane N of the row) + base: the LDS byte address of this lane's day in the row of the N-th neighbour
+template <int N>
+__device__ __forceinline__ uint32_t dt_addr(uint32_t off, uint32_t base)
+{
+    uint32_t r;
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(off), "v"(base), "n"(N));
+    return r;
+}
+
+// sum_r z_r * table_row(soff_r)[lane] + zc in rank order: the fma chain of daily_value, bit for bit.  The hat row
+// and the row offsets are wave-uniform; scalar loads of them put a scalar-cache miss (they share the counter of the
+// LDS reads, so they cannot be prefetched past them) in front of every eight steps -- measured: 75 % of the wave
+// cycles waiting.  Instead lane l of every 16-lane row holds entry 16 c + (l & 15) of the current chunk (two vector
+// loads per 16 steps, prefetched one chunk ahead on the vector-memory counter) and each step picks its entry with a
+// DPP row broadcast inside the address add and inside the fmac: no extra instruction per step.
+__device__ __forceinline__ double dt_value(const DtVar &v, int64_t lc, int m0, const char *tab, uint32_t lane4, int lane)
+{
+    const int ka = v.ka[lc * 12 + m0];
+    const double *z = v.z + (lc * 12 + m0) * TWX_KZ;
+    const uint32_t *so = v.soff + (lc * 12 + m0) * TWX_KZ;
+    const int l16 = lane & 15;
+    double acc = 0.0;
+    double zv = l16 < ka ? z[l16] : 0.0;
+    uint32_t sv = l16 < ka ? so[l16] : 0u;
+    for (int r0 = 0; r0 < ka; r0 += 16) {
+        const int nx = r0 + 16 + l16;
+        double zn = 0.0;
+        uint32_t sn = 0u;
+        if (nx < ka) { zn = z[nx]; sn = so[nx]; }              // next chunk, in flight during this one
+        const int rem = ka - r0;
+        if (rem >= 16) {
+            sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
+                constexpr int N = decltype(n_)::value;
+                const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
+                dt_fmac<N>(acc, zv, (double)x);
+            });
+        } else {
+            sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
+                constexpr int N = decltype(n_)::value;
+                if (N < rem) {                                 // wave-uniform
+                    const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
+                    dt_fmac<N>(acc, zv, (double)x);
+                }
+            });
+        }
+        zv = zn; sv = sn;
+    }
+    return acc + v.zc[lc * 12 + m0];
+}
+
+#define TWX_DT_RPW ((TWX_UROWS + TWX_DT_WAVES - 1) / TWX_DT_WAVES)   // table rows staged per wave
+
+__global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
+{
+    __shared__ float s_tab[TWX_UROWS * 64];
+    __shared__ int16_t s_v[2][64][66];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tl = blockIdx.x;                      // local tile (same tiling for both variables)
+    const int m0 = blockIdx.y / a.nblk_max;
+    const int blk = blockIdx.y % a.nblk_max;
+    const int dm0 = a.moff[m0] + blk * 64, dm1 = a.moff[m0 + 1];
+    if (dm0 >= dm1) return;
+    const int nun = a.n.nurow[tl * 12 + m0], nux = a.x.nurow[tl * 12 + m0];
+    if (nun < 0 || nux < 0 || a.gather) return;         // this tile-month gathers from global memory (k_daily_tile_gather)
+    const int dm = dm0 + lane;
+    const bool day_ok = dm < dm1;
+    const int dmc = day_ok ? dm : dm1 - 1;              // clamped: staging loads stay inside the month
+    const int64_t tile = a.tile0 + tl;
+    const int r0 = (int)(tile / a.ntx) * a.ts, q0 = (int)(tile % a.ntx) * a.ts;
+    const char *tab = reinterpret_cast<const char *>(s_tab);
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+
+    // stage rows u = wv + TWX_DT_WAVES j of a variable's table: all of this wave's row loads in flight at once (the
+    // row indices come through one vector load per row: lanes read the same word)
+    float pre[TWX_DT_RPW];
+    auto fetch = [&](const DtVar &v, int nu) __attribute__((always_inline)) {
+        const int32_t *rows = v.urow + (tl * 12 + m0) * TWX_UROWS;
+#pragma unroll
+        for (int j = 0; j < TWX_DT_RPW; ++j) {
+            const int u = wv + TWX_DT_WAVES * j;
+            pre[j] = u < nu ? v.obs[(size_t)rows[u] * a.ndays + dmc] : 0.f;
+        }
+    };
+    auto store = [&](int nu) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TWX_DT_RPW; ++j) {
+            const int u = wv + TWX_DT_WAVES * j;
+            if (u < nu) s_tab[u * 64 + lane] = pre[j];
+        }
+    };
+
+    // ---- Tmin: stage the tile-month's rows, then walk this wave's cells.  (Issuing the Tmax row loads before the Tmin
+    // sums does not help: the hat-row loads of the sums queue behind them on the same in-order counter.)
+    fetch(a.n, nun);
+    store(nun);
+    __syncthreads();
+    double vn[TWX_DT_CPW];
+#pragma unroll
+    for (int i = 0; i < TWX_DT_CPW; ++i) {
+        const int64_t lc = dt_cell(a, r0, q0, wv * TWX_DT_CPW + i);
+        vn[i] = lc >= 0 ? dt_value(a.n, lc, m0, tab, lane4, lane) : 0.0;
+    }
+    __syncthreads();
+    // ---- Tmax: re-stage the table, walk the cells, flag, pack
+    fetch(a.x, nux);
+    store(nux);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TWX_DT_CPW; ++i) {
+        const int cl = wv * TWX_DT_CPW + i;
+        const int64_t lc = dt_cell(a, r0, q0, cl);
+        double vx = 0.0;
+        if (lc >= 0) {
+            vx = dt_value(a.x, lc, m0, tab, lane4, lane);
+            if (day_ok && vn[i] >= vx) a.flag[lc] = 1;
+        }
+        const bool okd = lc >= 0 && day_ok;
+        s_v[0][lane][cl] = okd ? pack_i16(vn[i]) : TWX_FILL_I2;
+        s_v[1][lane][cl] = okd ? pack_i16(vx) : TWX_FILL_I2;
+    }
+    __syncthreads();
+    // write: each wave takes 64 / TWX_DT_WAVES days; lane = cell of the tile
+    const int64_t lcw = dt_cell(a, r0, q0, lane);
+    if (lcw < 0) return;
+    const int64_t c = a.cell0 + lcw, yx = (int64_t)a.Y * a.X;
+    for (int i = 0; i < TWX_DT_CPW; ++i) {
+        const int dl = wv * TWX_DT_CPW + i;
+        if (dm0 + dl >= dm1) break;
+        const int64_t d = a.mm2chron[dm0 + dl];
+        a.out_n[d * yx + c] = s_v[0][dl][lane];
+        a.out_x[d * yx + c] = s_v[1][dl][lane];
+    }
+}
+
+// the same tile-month blocks gathered from global memory (daily_value2): tile-months whose union exceeds TWX_UROWS
+// rows, or all of them with TWX_FLAG_DAILY_GATHER / TWX_FLAG_OBS_ADDR64
+__global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
+                                                           GwrWs gn, GwrWs gx, DayAxis da, twx_grid_out out,
+                                                           int32_t *flag, const int32_t *okc, int nblk_max, int addr64,
+                                                           int gather)
+{
+    __shared__ int16_t s_v[2][64][66];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool off32 = !addr64 && (uint64_t)max(stn.n, stx.n) * (uint64_t)da.ndays < (1ull << 30) &&
+                       max(stn.n, stx.n) < (1 << 24) && da.ndays < (1 << 22);
+    const int64_t tl = blockIdx.x;
+    const int m0 = blockIdx.y / nblk_max;
+    const int blk = blockIdx.y % nblk_max;
+    const int dm0 = da.moff[m0] + blk * 64;
+    if (dm0 >= da.moff[m0 + 1]) return;
+    if (!gather && gn.nurow[tl * 12 + m0] >= 0 && gx.nurow[tl * 12 + m0] >= 0) return;   // done by k_daily_tile
+    const int dm = dm0 + lane;
+    const bool day_ok = dm < da.moff[m0 + 1];
+    const int64_t tile = wn.tile0 + tl;
+    const int r0 = (int)(tile / src.ntx) * src.ts, q0 = (int)(tile % src.ntx) * src.ts;
+    const int64_t yx = (int64_t)src.Y * src.X;
+    auto cell_lc = [&](int cl) -> int64_t {
+        const int rr = r0 + cl / src.ts, qq = q0 + cl % src.ts;
+        if (cl >= src.ts * src.ts || rr >= src.Y || qq >= src.X) return -1;
+        const int64_t lc = (int64_t)rr * src.X + qq - wn.cell0;
+        if (lc < 0 || lc >= wn.ncell || !okc[lc]) return -1;
+        return lc;
+    };
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const int cl = wv * 16 + i;
+        const int64_t lc = cell_lc(cl);
+        double va = 0.0, vb = 0.0;
+        if (lc >= 0 && day_ok) {
+            if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
+            else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
+            if (va >= vb) flag[lc] = 1;
+        }
+        const bool okd = lc >= 0 && day_ok;
+        s_v[0][lane][cl] = okd ? pack_i16(va) : TWX_FILL_I2;
+        s_v[1][lane][cl] = okd ? pack_i16(vb) : TWX_FILL_I2;
+    }
+    __syncthreads();
+    const int64_t lcw = cell_lc(lane);
+    if (lcw < 0) return;
+    const int64_t c = wn.cell0 + lcw;
+    for (int i = 0; i < 16; ++i) {
+        const int dl = wv * 16 + i;
+        if (dm0 + dl >= da.moff[m0 + 1]) break;
+        const int64_t d = da.mm2chron[dm0 + dl];
+        if (out.daily_tmin) out.daily_tmin[d * yx + c] = s_v[0][dl][lane];
+        if (out.daily_tmax) out.daily_tmax[d * yx + c] = s_v[1][dl][lane];
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "twx.h"
 
 #define TWX_KSEL_MAX 160            // nearest-list slots per cell (>= TWX_MAX_NNGHS + 1)
@@ -159,3 +161,25 @@ __device__ __forceinline__ int wave_sum_i(int v)
 }
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= 1.79769313486231570e308; }
+
+// compile-time loop: the body gets the index as an integral_constant, so every
+// register-array subscript is a constant by construction (a "#pragma unroll" on the
+// outer block-column loop is refused by the optimizer for the larger NB)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor2(F &&f)       // step 2
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor2<I + 2, N>(f);
+    }
+}
+

@@ -50,14 +50,16 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff;
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, soff, urow,
+        nurow;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff})
+                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
+                          &near_pos, &soff, &urow, &nurow})
             b->release();
     }
 };
@@ -144,7 +146,7 @@ template <class T> T *carve(char *&cur, size_t count)
 
 // ---- workspace of one (batch, variable) ---------------------------------------------
 int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile0, int64_t ntile, int ksel,
-                 int nblocks_tile, bool need_gwr, bool fit_vario = false)
+                 int nblocks_tile, bool need_gwr, bool fit_vario = false, bool tile_tab = false)
 {
     Work &w = ctx->work[v];
     const int n = ctx->var[v].n;
@@ -174,6 +176,12 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
     }
+    if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
+        HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));
+        HIPCHK(w.soff.ensure((size_t)ncell * 12 * TWX_KZ * 4));
+        HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
+        HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
+    }
     if (fit_vario) {
         HIPCHK(w.uk_beta.ensure((size_t)ncell * 12 * 5 * 8));
         HIPCHK(w.vfit.ensure((size_t)ncell * 12 * 3 * 8));
@@ -197,6 +205,10 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
+    s.near_pos = tile_tab ? w.near_pos.as<uint16_t>() : nullptr;
+    w.gw.soff = tile_tab ? w.soff.as<uint32_t>() : nullptr;
+    w.gw.urow = tile_tab ? w.urow.as<int32_t>() : nullptr;
+    w.gw.nurow = tile_tab ? w.nurow.as<int32_t>() : nullptr;
     return 0;
 }
 
@@ -257,7 +269,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_RANGE): the host
     // never looks at them.  The bucket counts are read back once (exact kriging grids) unless TWX_FLAG_NO_HOST_SYNC.
     w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
-    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario)) return -1;
+    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0)) return -1;
     HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
     {
         EvScope ev(ctx, stream, EV_TILE);
@@ -1052,10 +1064,37 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                         hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((wsv.ncell * wsv.ksel + 255) / 256)), dim3(256), 0,
                                            stream, wsv, ctx->work[v].gw, (int)ctx->ndays);
                     }
-                hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
-                                   stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
-                                   ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk,
-                                   (ctx->p.flags & TWX_FLAG_OBS_ADDR64) ? 1 : 0);
+                const int addr64 = (ctx->p.flags & TWX_FLAG_OBS_ADDR64) ? 1 : 0;
+                if (has_n && has_x && ts * ts <= 64) {
+                    // both variables: the tile kernel (observation rows of a tile-month staged in LDS)
+                    for (int v = 0; v < 2; ++v)
+                        hipLaunchKernelGGL(k_tile_union, dim3((unsigned)(ntile * 12)), dim3(256), 0, stream, s0, ctx->work[v].ws,
+                                           ctx->work[v].gw);
+                    int32_t *d_okc = ctx->flag_list.as<int32_t>();      // free until k_compact_flags (which runs after)
+                    hipLaunchKernelGGL(k_daily_ok, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, ctx->work[0].ws,
+                                       ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, d_okc);
+                    const int gather = (addr64 || (ctx->p.flags & TWX_FLAG_DAILY_GATHER)) ? 1 : 0;
+                    DtArgs da{};
+                    for (int v = 0; v < 2; ++v) {
+                        DtVar &dv = v == 0 ? da.n : da.x;
+                        const Work &wk = ctx->work[v];
+                        dv.obs = ctx->var[v].dev.obs; dv.ka = wk.ws.ka; dv.z = wk.gw.z; dv.zc = wk.gw.zc; dv.soff = wk.gw.soff;
+                        dv.urow = wk.gw.urow; dv.nurow = wk.gw.nurow;
+                    }
+                    da.okc = d_okc; da.mm2chron = ctx->da.mm2chron; da.out_n = o->daily_tmin; da.out_x = o->daily_tmax;
+                    da.flag = d_flag; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0;
+                    da.Y = Y; da.X = X; da.ts = ts; da.ntx = ntx; da.ndays = (int)ctx->ndays; da.nblk_max = nblk; da.gather = gather;
+                    for (int m = 0; m < 13; ++m) da.moff[m] = ctx->da.moff[m];
+                    if (!gather)
+                        hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
+                    hipLaunchKernelGGL(k_daily_tile_gather, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(256), 0, stream,
+                                       ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw,
+                                       ctx->work[1].gw, ctx->da, *o, d_flag, d_okc, nblk, addr64, gather);
+                } else {
+                    hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
+                                       stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
+                                       ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk, addr64);
+                }
             }
             if (has_n && has_x) {
                 hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_flag,

@@ -31,6 +31,7 @@ struct SelWs {
     float *dscratch;     // [gridDim][n] centre distances
     int32_t *near_idx;   // [ncell][ksel] by rank (nearest first), -1 padded
     double *near_dist;   // [ncell][ksel]
+    uint16_t *near_pos;  // [ncell][ksel] position of the ranked neighbour in its tile's candidate list (grid mode, daily) or null
     int32_t *nnear;      // [ncell]
     int32_t *kk;         // [ncell][12] kriging bandwidth (0 = month not requested)
     int32_t *ka;         // [ncell][12] GWR bandwidth
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
         if (valid && r < ws.ksel) {
             ws.near_idx[lc * ws.ksel + r] = s;
             ws.near_dist[lc * ws.ksel + r] = d;
+            if (ws.near_pos) ws.near_pos[lc * ws.ksel + r] = (uint16_t)(p >= 0 ? p : 0);
         }
     }
     __syncthreads();

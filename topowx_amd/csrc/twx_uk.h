@@ -36,27 +36,6 @@
 
 __device__ __forceinline__ constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
-// compile-time loop: the body gets the index as an integral_constant, so every
-// register-array subscript is a constant by construction (a "#pragma unroll" on the
-// outer block-column loop is refused by the optimizer for the larger NB)
-template <int I, int N, class F>
-__device__ __forceinline__ void sfor(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, N>(f);
-    }
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void sfor2(F &&f)       // step 2
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor2<I + 2, N>(f);
-    }
-}
-
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
     // v_rsq_f64 seed (~2^-23) + Newton steps; the second step only polishes the
