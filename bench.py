@@ -316,6 +316,32 @@ def main():
                             "sample": "%dx%d cell window, all 12 months (%.1f s)" % (n_one, n_one, dt_one)}}
         got = d_norm[:, :n_all, :n_all].cpu().numpy()
         res["parity_max_abs_degC"] = float(np.abs(got.astype(np.float64) - ref["norm_tmin"]).max())
+        # the same kernels against the 40-digit arbiter of the kriging system (oracle/arbiter.py): two cells of the
+        # tile, their own smoothed bandwidth and variogram
+        try:
+            from oracle import arbiter
+            cdb = db.cols
+            worst = 0.0
+            for (r, q, m) in ((17, 200, 1), (120, 40, 7)):
+                pts = ctx.make_pts(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
+                mean, var, used, st, ngh = ctx.krig_points(_lib.TMIN, pts, m, want_idx=True)
+                pt = orc.make_pt(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
+                vp = np.zeros(3)
+                import ctypes as C
+                rc, idx, _, wgt = orc.select(db, grid["lat"][r], grid["lon"][q], int(used[0]))
+                orc.lib().orc_smooth_vario(cdb["vario_nug"][m - 1].ctypes.data_as(C.POINTER(C.c_double)),
+                                           cdb["vario_psill"][m - 1].ctypes.data_as(C.POINTER(C.c_double)),
+                                           cdb["vario_rng"][m - 1].ctypes.data_as(C.POINTER(C.c_double)),
+                                           idx.ctypes.data_as(C.POINTER(C.c_int32)), wgt.ctypes.data_as(C.POINTER(C.c_double)),
+                                           C.c_int(int(used[0])), vp.ctypes.data_as(C.POINTER(C.c_double)))
+                ix = ngh[0, :used[0]]
+                am, av = arbiter.uk(cdb["lon"][ix], cdb["lat"][ix], cdb["elev"][ix], cdb["lst"][m - 1, ix], cdb["norm"][m - 1, ix],
+                                    (grid["lon"][q], grid["lat"][r], float(grid["elev"][r, q]), float(grid["lst_night"][m - 1, r, q])),
+                                    *vp)
+                worst = max(worst, abs(mean[0] - am), abs(var[0] - av))
+            res["parity_vs_arbiter_max_abs_degC"] = worst
+        except ImportError:
+            pass
     if rank == 0:
         print(json.dumps(res), flush=True)
     ctx.close()

@@ -346,3 +346,24 @@ def test_grid_many_small_batches_equal_one_batch(env, golden_case):
         assert np.array_equal(a[k], b[k]), k
     m = mask[rs, cs] != 0
     assert np.all(a["status"][m] == 0) and np.all(a["status"][~m] == -1)
+
+
+def test_krig_against_40_digit_arbiter(env, orc):
+    """The GPU kriging kernels (fp32 pair distances and exponentials, fp64 bordered Cholesky) against the augmented
+    system solved in 40-digit arithmetic (oracle/arbiter.py): one-wave kernel, four-wave kernel and the largest
+    bandwidth of the ladder; the residual is the fp32 distance / exponent rounding, far inside 1e-4 degC."""
+    from oracle import arbiter
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    c = env["dbn"].cols
+    r, q, m = 37, 61, 7
+    cell = np.array([[r, q]])
+    worst = 0.0
+    for k, vario in ((35, (0.3, 0.9, 35.0)), (101, (0.05, 2.0, 900.0)), (147, (0.25, 1.4, 60.0))):
+        mean, var, used, st, ngh = ctx.krig_points(lib.TMIN, _pts(ctx, grid, cell, "tmin"), m, nnghs=k, vario=[vario],
+                                                   want_idx=True)
+        assert st[0] == 0 and used[0] == k
+        idx = ngh[0, :k]
+        pt = (grid["lon"][q], grid["lat"][r], float(grid["elev"][r, q]), float(grid["lst_night"][m - 1, r, q]))
+        am, av = arbiter.uk(c["lon"][idx], c["lat"][idx], c["elev"][idx], c["lst"][m - 1, idx], c["norm"][m - 1, idx], pt, *vario)
+        worst = max(worst, abs(mean[0] - am), abs(var[0] - av))
+    assert worst < 1e-5, worst

@@ -88,3 +88,43 @@ def test_singular_system_reports_numeric(orc):
     lon[1], lat[1] = lon[0], lat[0]          # duplicate location, no nugget on the off-diagonal
     rc, _, _ = orc.uk(lon, lat, elev, lst, y, pt, 0.0, 1.0, 40.0)
     assert rc == 4
+
+
+# ---- known answers that do not come from this repository's algebra -----------------------------------------------
+def test_ellip_dist_published_values(orc):
+    """sp's documented spDistsN1 example, Meeus' worked example (the book sp's gcdist.c cites) and the textbook
+    WGS84 arc lengths of one degree: the restated formula (orc_ellip_dist) reproduces them."""
+    d = orc.lib().orc_ellip_dist
+    assert abs(d(5.0, 60.0, 6.0, 60.0) - 55.79918) < 5e-6              # ?spDistsN1: "0.00000 55.79918"
+    paris = (2 + 20 / 60 + 14 / 3600, 48 + 50 / 60 + 11 / 3600)
+    wash = (-(77 + 3 / 60 + 56 / 3600), 38 + 55 / 60 + 17 / 3600)
+    assert abs(d(paris[0], paris[1], wash[0], wash[1]) - 6181.63) < 0.01  # Meeus, Astronomical Algorithms, ex. 11.c
+    for got, want in ((d(0, -0.5, 0, 0.5), 110.574), (d(0, 44.5, 0, 45.5), 111.132), (d(0, 89.0, 0, 90.0), 111.694),
+                      (d(-0.5, 0, 0.5, 0), 111.320), (d(-0.5, 45.0, 0.5, 45.0), 78.847)):
+        assert abs(got - want) < 2e-3 * 1.0 + 1.5e-5 * want, (got, want)   # the tables' three decimals (+ formula error < 2 m / deg)
+    # the branches of sp's gcdist.c: identical points, the antimeridian, symmetry
+    assert d(-110.2, 45.1, -110.2, 45.1) == 0.0
+    assert abs(d(179.5, 10, -179.5, 10) - d(-0.5, 10, 0.5, 10)) < 1e-9
+    assert d(-111.0, 44.0, -109.5, 46.25) == d(-109.5, 46.25, -111.0, 44.0)
+    # and it is NOT the haversine of the selection stage (util_geo.py:24-40)
+    assert abs(orc.lib().orc_grt_circle_dist(5.0, 60.0, 6.0, 60.0) - 55.597) < 1e-3
+
+
+@pytest.mark.parametrize("k", [35, 101, 147])
+def test_uk_against_40_digit_arbiter(orc, golden_case, k):
+    """orc_uk (fp64, GLS form on centred / scaled trend columns) against the augmented system solved in 40-digit
+    arithmetic (oracle/arbiter.py) on real neighbourhoods of the golden database: the difference is fp64 rounding."""
+    from oracle import arbiter
+    from topowx_amd import stationdb as sdb
+    grid, tmin, _ = golden_case
+    db = orc.Db(tmin)
+    c = db.cols
+    r, q = 37, 61
+    pt = (grid["lon"][q], grid["lat"][r], float(grid["elev"][r, q]), float(grid["lst_night"][6, r, q]))
+    rc, idx, _, _ = orc.select(db, pt[1], pt[0], k)
+    assert rc == 0
+    args = (c["lon"][idx], c["lat"][idx], c["elev"][idx], c["lst"][6, idx], c["norm"][6, idx])
+    for nug, psill, rng in ((0.3, 0.9, 35.0), (0.05, 2.0, 900.0), (0.8, 0.0, 0.0)):
+        rc, mean, var = orc.uk(*args, pt, nug, psill, rng)
+        am, av = arbiter.uk(*args, pt, nug, psill, rng)
+        assert rc == 0 and abs(mean - am) < 1e-8 and abs(var - av) < 1e-8, (k, rng, mean - am, var - av)
