@@ -1,5 +1,5 @@
 """Reduce the rocprofv3 outputs of tests/tools/collect_profiles.sh to the small files kept under profiles/:
-the kernel-stats table, per-kernel sums of the PMC passes, and the HBM bytes per launch of the kriging kernels
+the kernel-stats tables, per-kernel sums of the PMC passes, and the HBM bytes per launch of the kriging kernels
 (quoted by bench.py as roofline.traffic) and of the daily kernels."""
 import collections
 import csv
@@ -10,50 +10,68 @@ import sys
 
 out = sys.argv[1]
 KRIG = ("k_uk<", "k_ukw<", "k_cell_dist")          # the kernels behind bench.py's uk_ms
-DAILY = ("k_daily_grid", "k_row_offsets")          # ... daily_ms
-OTHER = ("k_gwr_z", "k_fix_cells", "k_select", "k_tile_cand")
+DAILY = ("k_daily_tile", "k_tile_union", "k_row_offsets", "k_daily_ok", "k_daily_grid")   # ... daily_ms
+DAILY_ONLY = DAILY + ("k_gwr_z", "k_fix_cells", "k_compact_flags")
 
 
 def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
-res = {}
-for key, sub, pre in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
+def pmc(sub, pre, key):
     paths = glob.glob(os.path.join(out, sub, "**", pre + "_counter_collection.csv"), recursive=True)
-    if not paths:
-        continue
     per = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(paths[0])):
-        if r["Counter_Name"] != key:
-            continue
-        k = short(r["Kernel_Name"])
-        per[k][0] += 1
-        per[k][1] += float(r["Counter_Value"])
+    if paths:
+        for r in csv.DictReader(open(paths[0])):
+            if r["Counter_Name"] == key:
+                k = short(r["Kernel_Name"])
+                per[k][0] += 1
+                per[k][1] += float(r["Counter_Value"])
+    return per
+
+
+def group(per, prefixes):
+    n = sum(c for k, (c, v) in per.items() if k.startswith(prefixes))
+    kb = sum(v for k, (c, v) in per.items() if k.startswith(prefixes))
+    return n, kb
+
+
+res = {}
+for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE", "write", "dwrite", "w")):
+    per = pmc(sub, pre, key)
     with open(os.path.join(out, "pmc_%s.csv" % key), "w") as fh:
         fh.write("kernel,dispatches,%s_sum_KB\n" % key)
         for k, (n, v) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             fh.write('"%s",%d,%.1f\n' % (k, n, v))
-
-    def group(prefixes):
-        n = sum(c for k, (c, v) in per.items() if k.startswith(prefixes))
-        kb = sum(v for k, (c, v) in per.items() if k.startswith(prefixes))
-        return n, kb
-    n, kb = group(KRIG)
+    n, kb = group(per, KRIG)
     res[key] = {"k_uk_launches": n, "k_uk_total_KB": kb, "k_uk_per_launch_bytes": kb * 1024.0 / max(n, 1),
-                "kernels": "k_cell_dist + k_ukw<..> + k_uk<..>"}
-    n, kb = group(DAILY)
-    res[key]["daily"] = {"launches": n, "total_KB": kb, "per_launch_bytes": kb * 1024.0 / max(n, 1),
-                         "kernels": "k_daily_grid + k_row_offsets"}
-    for o in OTHER:
-        n, kb = group((o,))
-        res[key][o] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
+                "kernels": "k_cell_dist + k_ukw<..> + k_uk<..> (headline workload only)"}
+    dper = pmc(dsub, pre, key)
+    if dper:
+        with open(os.path.join(out, "pmc_daily_%s.csv" % key), "w") as fh:
+            fh.write("kernel,dispatches,%s_sum_KB\n" % key)
+            for k, (n, v) in sorted(dper.items(), key=lambda kv: -kv[1][1]):
+                if k.startswith(DAILY_ONLY):
+                    fh.write('"%s",%d,%.1f\n' % (k, n, v))
+        n, kb = group(dper, ("k_daily_tile",))
+        res[key]["k_daily_tile"] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
+        for o in ("k_tile_union", "k_gwr_z", "k_fix_cells"):
+            n, kb = group(dper, (o,))
+            res[key][o] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
-# kernel stats table (rocprofv3 --stats)
-for p in glob.glob(os.path.join(out, "stats", "**", "s_kernel_stats.csv"), recursive=True):
-    rows = list(csv.DictReader(open(p)))
-    with open(os.path.join(out, "kernel_stats.csv"), "w") as fh:
-        fh.write("kernel,calls,total_ns,avg_ns,pct\n")
-        for r in rows:
-            fh.write('"%s",%s,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+
+
+def stats(sub, name, only=None):
+    for p in glob.glob(os.path.join(out, sub, "**", "s_kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(p)))
+        with open(os.path.join(out, name), "w") as fh:
+            fh.write("kernel,calls,total_ns,avg_ns,pct\n")
+            for r in rows:
+                k = short(r["Name"])
+                if only is None or k.startswith(only):
+                    fh.write('"%s",%s,%s,%s,%s\n' % (k, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+
+
+stats("stats", "kernel_stats.csv")
+stats("dstats", "kernel_stats_daily.csv", DAILY_ONLY)
 print(json.dumps(res))
