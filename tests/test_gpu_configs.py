@@ -165,3 +165,21 @@ def test_destroy_returns_all_device_memory():
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
     assert free[-1] >= free[0] - (8 << 20), free                # no growth from cycle to cycle
+
+
+def test_single_variable_daily_equals_two_variable_run(golden_case):
+    """A one-variable daily request runs the strip kernel (k_daily_grid), the two-variable request the tile kernel
+    (k_daily_tile): same values, bit for bit, where the fixer has nothing to do."""
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    rs, cs = slice(13, 40), slice(61, 99)
+    both = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    one_n = ctx.interp_grid(grid, variables=("tmin",), daily=True, rows=rs, cols=cs)
+    one_x = ctx.interp_grid(grid, variables=("tmax",), daily=True, rows=rs, cols=cs)
+    ctx.close()
+    assert np.all(both["status"] == 0) and both["ninvalid"].max() == 0
+    assert np.array_equal(one_n["daily_tmin"], both["daily_tmin"]) and np.array_equal(one_x["daily_tmax"], both["daily_tmax"])
+    assert np.array_equal(one_n["norm_tmin"], both["norm_tmin"]) and np.array_equal(one_x["se_tmax"], both["se_tmax"])

@@ -453,16 +453,18 @@ __device__ __forceinline__ double dt_value(const DtVar &v, int64_t lc, int m0, c
         uint32_t sn = 0u;
         if (nx < ka) { zn = z[nx]; sn = so[nx]; }              // next chunk, in flight during this one
         const int rem = ka - r0;
-        if (rem >= 16) {
+        if (rem >= 16) {                                       // eight LDS reads in flight at a time
             sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
                 constexpr int N = decltype(n_)::value;
                 const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
                 dt_fmac<N>(acc, zv, (double)x);
             });
         } else {
+            // the last, partial chunk step by step (wave-uniform branches).  Padding it to 16 steps with zero
+            // weights on a row of zeros (fma(0, 0, acc) = acc) measured SLOWER: 11.1 vs 7.9 ms on the 10-year tile
             sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
                 constexpr int N = decltype(n_)::value;
-                if (N < rem) {                                 // wave-uniform
+                if (N < rem) {
                     const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
                     dt_fmac<N>(acc, zv, (double)x);
                 }
