@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             M[a][b] = wave_sum(s);
         }
     }
+    // Cholesky with one reciprocal per pivot (33 fp64 divisions -> 6: the kernel is VALU bound and a division is
+    // a dozen instructions; the hat row changes in the last bit only, all consumers use the same stored z)
+    double inv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -106,8 +109,8 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             double s = M[i][j];
 #pragma unroll
             for (int p = 0; p < j; ++p) s -= M[i][p] * M[j][p];
-            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); }
-            else M[i][j] = s / M[j][j];
+            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); inv[i] = 1.0 / M[i][i]; }
+            else M[i][j] = s * inv[j];
         }
     }
     // a = M^-1 e1
@@ -117,14 +120,14 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
         double s = (i == 0) ? 1.0 : 0.0;
 #pragma unroll
         for (int p = 0; p < i; ++p) s -= M[i][p] * a[p];
-        a[i] = s / M[i][i];
+        a[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = a[i];
 #pragma unroll
         for (int p = i + 1; p < 6; ++p) s -= M[p][i] * a[p];
-        a[i] = s / M[i][i];
+        a[i] = s * inv[i];
     }
     double zn = 0.0;
 #pragma unroll
