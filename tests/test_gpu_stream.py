@@ -115,3 +115,26 @@ def test_no_host_sync_mode_equals_default(golden_case):
         ctx.close()
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_driver_streamed_tiles_equal_synchronous(golden_case, tmp_path):
+    """driver.interp_tiles_streamed (three pinned slots, writer thread) == driver.interp_tiles on the same tiles."""
+    from topowx_amd import _lib, driver
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    tiles = driver.tile_list(grid["mask"], 25, 25)[:7]
+    want = driver.interp_tiles(grid, driver.gpu_compute(ctx, daily=True), tiles, 25, 25)
+    seen = []
+
+    def sink(k, arrays):
+        np.savez(str(tmp_path / ("t%d.npz" % k)), **{n: v for n, v in arrays.items() if hasattr(v, "shape")})
+        seen.append(k)
+    res, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, tiles, 25, 25, daily=True, sink=sink)
+    ctx.close()
+    assert res is None and seen == [t[0] for t in tiles] and dev_ms > 0 and secs > 0
+    for k, _, _, _ in tiles:
+        got = np.load(str(tmp_path / ("t%d.npz" % k)))
+        for name in want[k]:
+            assert np.array_equal(got[name], want[k][name]), (k, name)

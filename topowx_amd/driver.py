@@ -86,6 +86,69 @@ def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, d
     return mosaic
 
 
+def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
+                          writer_threads=1):
+    """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
+    tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
+    workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
+    returns (they are views of a pinned slot that is reused two tiles later); default: collect copies.
+    All tiles must have the shape tile_y x tile_x.  Returns (results or None, seconds, device_ms)."""
+    import queue
+    import threading
+    import time
+    collected = {}
+    if sink is None:
+        def sink(k, arrays):
+            collected[k] = {n: np.array(v) for n, v in arrays.items() if hasattr(v, "shape")}
+    nslots = 3                                  # one computing, one copying out, one at the writer
+    st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots)
+    q = queue.Queue(maxsize=1)
+    free = [threading.Semaphore(1) for _ in range(nslots)]
+    err = []
+
+    def writer():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            k, slot, arrays = item
+            try:
+                sink(k, arrays)
+            except Exception as e:              # noqa: BLE001 -- reported to the caller below
+                err.append(e)
+            finally:
+                free[slot].release()
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    pending = None
+    try:
+        for n, (k, i, j, _) in enumerate(tiles):
+            slot = n % nslots
+            free[slot].acquire()                # the writer is done with this slot's previous tile
+            st.submit(slot, grid, slice(i, i + tile_y), slice(j, j + tile_x))
+            if pending is not None:
+                pk, pslot = pending
+                out = st.wait(pslot)            # tile t is on the host; tile t + 1 is already running
+                dev_ms += out.pop("device_ms")
+                q.put((pk, pslot, out))
+            pending = (k, slot)
+        if pending is not None:
+            pk, pslot = pending
+            out = st.wait(pslot)
+            dev_ms += out.pop("device_ms")
+            q.put((pk, pslot, out))
+    finally:
+        q.put(None)
+        th.join()
+        st.close()
+    if err:
+        raise err[0]
+    return (collected if collected else None), time.perf_counter() - t0, dev_ms
+
+
 def gpu_compute(ctx, variables=("tmin", "tmax"), daily=False):
     """compute() backed by libtwxhip (the product path)."""
     def compute(grid, rows, cols):
@@ -100,6 +163,7 @@ def main():
     ap.add_argument("--daily", action="store_true")
     ap.add_argument("--gather", action="store_true", help="assemble the normals mosaic on rank 0 (RCCL gather)")
     ap.add_argument("--out", default=None, help=".npz for rank 0's mosaic")
+    ap.add_argument("--tile-dir", default=None, help="write every tile of this rank as <dir>/tileNNNNN.npz while the next one runs")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -117,11 +181,22 @@ def main():
     tiles = tile_list(grid["mask"], args.tile, args.tile)
     assignment = assign_tiles(tiles, world)
     t0 = time.perf_counter()
-    mine = interp_tiles(grid, gpu_compute(ctx, daily=args.daily), assignment[rank], args.tile, args.tile)
+    even = grid["mask"].shape[0] % args.tile == 0 and grid["mask"].shape[1] % args.tile == 0
+    if args.tile_dir and even:
+        # streamed: outputs of tile t travel to the host and to disk while tile t + 1 is computed
+        os.makedirs(args.tile_dir, exist_ok=True)
+
+        def sink(k, arrays):
+            np.savez(os.path.join(args.tile_dir, "tile%05d.npz" % k), **{n: v for n, v in arrays.items() if hasattr(v, "shape")})
+        mine, dt, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=args.daily, sink=sink)
+        mine = mine or {}
+    else:
+        mine = interp_tiles(grid, gpu_compute(ctx, daily=args.daily), assignment[rank], args.tile, args.tile)
+        dev_ms = None
     dt = time.perf_counter() - t0
     ncell = sum(t[3] for t in assignment[rank])
-    print(json.dumps({"rank": rank, "tiles": len(assignment[rank]), "cells": ncell, "seconds": dt}), flush=True)
-    if args.gather:
+    print(json.dumps({"rank": rank, "tiles": len(assignment[rank]), "cells": ncell, "seconds": dt, "device_ms": dev_ms}), flush=True)
+    if args.gather and not args.tile_dir:
         keys = ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")
         mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, keys, rank, world,
                                device="cuda:%d" % local)
