@@ -61,6 +61,21 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     const float chi = (float)c2;
     const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
 
+    // the pair distances of this lane's elements (k_cell_dist's cache; 16x16 blocks, element order [column][row]):
+    // every load is issued here, before the staging, so that their latency hides behind it (entries outside the
+    // neighbourhood are never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
+    float hd[NT];
+    {
+        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                hd[widx(a, b)] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
+            });
+        });
+    }
+
     // ---- staging: neighbours t = lane, lane + 64 (NP <= 96) -----------------------------------
     double xs[2][4], yv[2], c0v[2];
     double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
@@ -99,24 +114,17 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     // ---- build this lane's elements (negated: the registers hold N = -M): covariance of the cached pair
     //      distance (k_cell_dist; 16x16 blocks, element order [column][row]) -------------------------------------
     double A[NT];
-    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
-        // all loads of the block row in flight before the first use (entries outside the neighbourhood are
-        // never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
-        float h[4 * a + 4];
-        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
-            constexpr int b = decltype(b_)::value;
-            h[b] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
-        });
         sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 4 * b + tc;
+            const float hh = hd[widx(a, b)];
             // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0), so the panel step has no special cases
             double v = (i == j && i < RHS0) ? 1.0 : 0.0;
-            if (i < k && j <= i) v = (i == j || h[b] == 0.f) ? c00 : psill_e * (double)exp2_neg(h[b], chi);
+            if (i < k && j <= i) v = (i == j || hh == 0.f) ? c00 : psill_e * (double)exp2_neg(hh, chi);
             if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
             A[widx(a, b)] = -v;
         });
