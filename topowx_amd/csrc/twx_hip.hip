@@ -49,7 +49,7 @@ struct VarData {
 };
 
 struct Work {
-    DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, kmaxc,
+    DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, soff, urow,
         nurow;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
@@ -58,7 +58,7 @@ struct Work {
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &kmaxc, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
+                          &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
                           &near_pos, &soff, &urow, &nurow})
             b->release();
     }
@@ -161,7 +161,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.ka.ensure((size_t)ncell * 48));
     HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
     HIPCHK(w.cstat.ensure((size_t)ncell * 4));
-    HIPCHK(w.kmaxc.ensure((size_t)ncell * 4));
+    HIPCHK(w.cdup.ensure((size_t)ncell * 4));
     HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 15 * 4));
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
@@ -198,7 +198,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
     s.nnear = w.nnear.as<int32_t>(); s.kk = w.kk.as<int32_t>(); s.ka = w.ka.as<int32_t>();
-    s.vario = w.vario.as<double>(); s.cstat = w.cstat.as<int32_t>(); s.kmaxc = w.kmaxc.as<int32_t>();
+    s.vario = w.vario.as<double>(); s.cstat = w.cstat.as<int32_t>(); s.cdup = w.cdup.as<int32_t>();
     s.bucket_cells = w.bucket_cells.as<int32_t>();
     s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();

@@ -37,7 +37,7 @@ struct SelWs {
     int32_t *ka;         // [ncell][12] GWR bandwidth
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
-    int32_t *kmaxc;      // [ncell] largest kk / ka of the cell
+    int32_t *cdup;       // [ncell] lowest rank i whose neighbour coincides with an earlier one (k_cell_dist): systems with k > i are singular
     int32_t *bucket_cnt; // [16]: 0..5 and 13, 14 one-wave kernel (8-row units 5..10, 11, 12), 6..12 four-wave kernel NB = 4..10
     int32_t *bucket_cells; // [15][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
@@ -286,11 +286,11 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     __syncthreads();
     if (!in_range) return;
     if (!valid) {
-        if (lane == 0) { ws.cstat[lc] = TWX_CELL_MASKED; ws.kmaxc[lc] = 0; ws.nnear[lc] = 0; }
+        if (lane == 0) { ws.cstat[lc] = TWX_CELL_MASKED; ws.nnear[lc] = 0; }
         return;
     }
     // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
-    int status = too_many ? TWX_CELL_RANGE : TWX_CELL_OK, kkmax = 0;
+    int status = too_many ? TWX_CELL_RANGE : TWX_CELL_OK;
     const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;
@@ -338,7 +338,6 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
             }
         }
         if (status) { k = 0; kan = 0; }
-        kkmax = max(kkmax, k);
         if (lane == 0) {
             ws.kk[lc * 12 + m0] = k;
             ws.ka[lc * 12 + m0] = kan;
@@ -356,7 +355,6 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
             ws.ctrig[lc * 4 + 0] = sin(cv.lat * r / 2.0); ws.ctrig[lc * 4 + 1] = cos(cv.lat * r / 2.0);
             ws.ctrig[lc * 4 + 2] = sin(cv.lon * r / 2.0); ws.ctrig[lc * 4 + 3] = cos(cv.lon * r / 2.0);
         }
-        ws.kmaxc[lc] = status ? 0 : kkmax;
     }
 }
 

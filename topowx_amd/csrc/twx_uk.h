@@ -62,12 +62,16 @@ __device__ __forceinline__ void fmac_rowbcast(double &acc, double p, double u)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(u), "n"(N));
 }
 
-// exp(-h / range) = 2^(h * c), c = -log2(e) / range, in fp32: the product carries a relative error of 2^-24, i.e.
-// |t| * 6e-8 in the exponent and at most 2e-8 * psill absolute on the covariance (largest at t = -1.44);
-// v_exp_f32 itself is good to 1 ulp.  Far inside the 1e-4 degC bar (measured: DESIGN.md section 2).
-__device__ __forceinline__ float exp2_neg(float h, float c)
+// psill exp(-h / range) = 2^(h c + log2 psill), c = -log2(e) / range, in fp32: ONE fma and one v_exp_f32 per matrix
+// element.  The exponent carries a relative error of 2^-24 (|t| * 6e-8, plus the same on log2 psill, a common factor
+// of all off-diagonal elements), v_exp_f32 is good to 1 ulp: ~1e-7 relative on the covariance, far inside the
+// 1e-4 degC bar (measured against the 40-digit arbiter: DESIGN.md section 2).  The element masks of
+// the build ride on the operands: c = -inf for a row outside the neighbourhood and log2 psill = -inf for a pure
+// nugget both give 2^-inf = 0 (h > 0 always: k_cell_dist stores 1 for pairs outside the cell's largest neighbourhood
+// and a tiny distance for coincident neighbours, whose systems are singular and flagged through SelWs.cdup).
+__device__ __forceinline__ float cov_exp2(float h, float c, float lgp)
 {
-    return __builtin_amdgcn_exp2f(h * c);
+    return __builtin_amdgcn_exp2f(fmaf(h, c, lgp));
 }
 
 // far pairs (> ~1300 km): full fp64 formula; kept out of line so that the (never taken in practice)
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 {
     __shared__ double s_trig[TWX_KSEL_MAX * 4];
     __shared__ double s_cphi[TWX_KSEL_MAX];
+    __shared__ int s_dup;                                    // lowest rank whose neighbour coincides with an earlier one
     const int64_t lc = blockIdx.x;
     if (lc >= ws.ncell || ws.cstat[lc] != 0) return;
     const int t = threadIdx.x, tr = t & 15, tc = t >> 4;
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 #pragma unroll
     for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
     if (kmax <= 0) return;
+    if (t == 0) s_dup = 0x7fffffff;
     if (t < kmax) {
         const int j = ws.near_idx[lc * ws.ksel + t];
         const double sp = st.sph[j], cp = st.cph[j], sl = st.slh[j], cl = st.clh[j];
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
                                                   sp, cp, sl, cl, cph);
     }
     __syncthreads();
-    const int nbk = (kmax + 15) >> 4;
+    // block rows the kriging kernels read: their matrices span up to k + 8 rows (RHS rows included) rounded up to 16
+    const int nbk = min((int)TWX_DIST_NB, (kmax + 8 + 15) >> 4);
     float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
     for (int a = 0; a < nbk; ++a) {
         const int i = 16 * a + tr;
@@ -151,13 +158,20 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
         const double sli = iv ? s_trig[i * 4 + 2] : 0.0, cli = iv ? s_trig[i * 4 + 3] : 1.0, cphi = iv ? s_cphi[i] : 1.0;
         for (int b = 0; b <= a; ++b) {
             const int j = 16 * b + tc;
-            float h = 0.f;
-            if (iv && j < kmax && i != j)
+            float h = 1.f;                                   // diagonal / outside the neighbourhood: any h > 0 (masked by the build)
+            if (iv && j < kmax && i != j) {
                 h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1], s_trig[j * 4 + 2],
                                     s_trig[j * 4 + 3], s_cphi[j]);
+                // coincident neighbours: c(0) = full sill in both rows, i.e. every system holding both is singular
+                // (gstat fails there).  Such systems are flagged by rank (k > cdup) instead of through their pivots,
+                // and the cached distance stays positive so that the build's masks (-inf * h) never see 0.
+                if (h == 0.f) { atomicMin(&s_dup, max(i, j)); h = 1e-30f; }
+            }
             out[(a * (a + 1) / 2 + b) * 256 + t] = h;        // t = tc * 16 + tr
         }
     }
+    __syncthreads();
+    if (t == 0) ws.cdup[lc] = s_dup;
 }
 
 #ifndef TWX_UK_WV
@@ -228,18 +242,20 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
     const float chi = (float)c2;
     const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
+    const float lgp = __builtin_amdgcn_logf((float)psill_e);          // log2 psill (-inf for a pure nugget)
+    const int kdup = ws.cdup[lc];                                     // systems larger than this hold coincident neighbours: singular
 
     // the pair distances of this thread's elements (k_cell_dist's cache): every load is issued here, before the
     // staging, so that their latency hides behind it (measured: 13.3 -> 12.75 ms per C2 step) (entries outside the neighbourhood are never used; the slab of
     // a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
     float hd[NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     {
-        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
             constexpr int a = decltype(a_)::value;
             sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
                 constexpr int b = decltype(b_)::value;
-                hd[tri(a, b)] = (a < TWX_DIST_NB) ? __builtin_nontemporal_load(&dist[tri(a, b) * 256]) : 0.f;
+                hd[tri(a, b)] = (a < TWX_DIST_NB) ? __builtin_nontemporal_load(&dist[tri(a, b) * 256]) : 1.f;
             });
         });
     }
@@ -254,7 +270,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
         const float h0 = ws.h0[lc * ws.ksel + t];
         const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-        c0v = same ? c00 : psill_e * (double)exp2_neg(h0, chi);
+        c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
     }
     {
         double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
@@ -278,23 +294,27 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     __syncthreads();
 
     // ---- build this thread's elements: covariance of the cached pair distance (k_cell_dist) --------------
+    // Straight-line: fma, v_exp_f32, convert per element.  A row outside the neighbourhood has c = -inf (its
+    // elements come out 0); j <= i < k makes a column test unnecessary below the diagonal, and what lies above
+    // the diagonal inside the diagonal blocks is never read by the elimination.
     double A[NT];
+    const bool rhs_row = tr >= 9;                             // of the last block row: rows NP-7..NP-1
+    const double *rhs = &s_B[rhs_row ? tr - 9 : 0][tc];       // (s_B is 0 from column k on)
     sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
+        const float ca = i < k ? chi : -__builtin_inff();
         sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 16 * b + tc;
-            const float hh = hd[tri(a, b)];
+            double v = (double)cov_exp2(hd[tri(a, b)], ca, lgp);
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
-            double v = (a == b && tr == tc && !(a == NB - 1 && tr >= 9)) ? 1.0 : 0.0;
-            if (i < k && j < k) v = (i == j || hh == 0.f) ? c00 : psill_e * (double)exp2_neg(hh, chi);
-            if (a == NB - 1 && tr >= 9 && j < k) v = s_B[tr - 9][j];   // RHS rows NP-7..NP-1
+            if (a == b && tr == tc) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
+            if (a == NB - 1) v = rhs_row ? rhs[16 * b] : v;  // unconditional LDS read: no branch per element
             A[tri(a, b)] = -v;                               // the registers hold N = -M: updates are pure fmacs
         });
     });
-
     // ---- elimination: panels of four columns ------------------------------------------------------
     int pbuf = 0;
     double dmin = 1.0;                                       // smallest pivot this wave has factorised
@@ -407,7 +427,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             }
         }
     });
-    if (!(dmin > 1e-9 * c00)) s_err = 1;                     // singular / indefinite system (benign race: all write 1)
+    if (!(dmin > 1e-9 * c00) || k > kdup) s_err = 1;         // singular / indefinite system (benign race: all write 1)
 
     // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
     if (tr >= 9 && tc >= 9 && tr >= tc) {

@@ -60,13 +60,15 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
     const float chi = (float)c2;
     const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
+    const float lgp = __builtin_amdgcn_logf((float)psill_e);          // log2 psill (-inf for a pure nugget)
+    const int kdup = ws.cdup[lc];                                     // systems larger than this hold coincident neighbours: singular
 
     // the pair distances of this lane's elements (k_cell_dist's cache; 16x16 blocks, element order [column][row]):
     // every load is issued here, before the staging, so that their latency hides behind it (entries outside the
     // neighbourhood are never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
     float hd[NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     {
-        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
             constexpr int a = decltype(a_)::value;
             sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
@@ -91,7 +93,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             yv[u] = st.norm[m0 * n + j];
             const float h0 = ws.h0[lc * ws.ksel + t];          // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v[u] = same ? c00 : psill_e * (double)exp2_neg(h0, chi);
+            c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
             e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
             e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
         }
@@ -113,23 +115,27 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
 
     // ---- build this lane's elements (negated: the registers hold N = -M): covariance of the cached pair
     //      distance (k_cell_dist; 16x16 blocks, element order [column][row]) -------------------------------------
+    //      Straight-line: fma, v_exp_f32, convert per element (cov_exp2).  A row outside the neighbourhood has
+    //      c = -inf (its elements come out 0); j <= i < k makes a column test unnecessary below the diagonal, and
+    //      what lies above the diagonal is never read by the elimination.
     double A[NT];
+    const bool rhs_row = tr >= R0 && tr < R0 + 7;             // of the last block row: rows RHS0..RHS0+6
+    const double *rhs = &s_B[rhs_row ? tr - R0 : 0][tc];      // (s_B is 0 from column k on)
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
+        const float ca = i < k ? chi : -__builtin_inff();
         sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 4 * b + tc;
-            const float hh = hd[widx(a, b)];
+            double v = (double)cov_exp2(hd[widx(a, b)], ca, lgp);
             // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0), so the panel step has no special cases
-            double v = (i == j && i < RHS0) ? 1.0 : 0.0;
-            if (i < k && j <= i) v = (i == j || hh == 0.f) ? c00 : psill_e * (double)exp2_neg(hh, chi);
-            if (a == NBR - 1 && tr >= R0 && tr < R0 + 7 && j < k) v = s_B[tr - R0][j];   // RHS rows RHS0..RHS0+6
+            if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
+            if (a == NBR - 1) v = rhs_row ? rhs[4 * b] : v;  // unconditional LDS read: no branch per element
             A[widx(a, b)] = -v;
         });
     });
-
     // ---- elimination: one panel per block column ----------------------------------------------------------
     double dmin = 1.0;                                       // smallest pivot
     sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
@@ -231,5 +237,5 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
                 ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[widx(NBR - 1, bb)];
         });
     }
-    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00) ? 0.0 : 1.0;   // singular / indefinite
+    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
 }
