@@ -46,6 +46,14 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return y;
 }
 
+// plain v_max_f64 (fmax() canonicalises its operands first: one more instruction per call on the panel chain)
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double readlane_d(double v, int lane /*wave-uniform*/)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -148,8 +156,7 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
                                                   sp, cp, sl, cl, cph);
     }
     __syncthreads();
-    // block rows the kriging kernels read: their matrices span up to k + 8 rows (RHS rows included) rounded up to 16
-    const int nbk = min((int)TWX_DIST_NB, (kmax + 8 + 15) >> 4);
+    const int nbk = (kmax + 15) >> 4;   // (the kriging kernels may read one block row more: they mask it themselves)
     float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
     for (int a = 0; a < nbk; ++a) {
         const int i = 16 * a + tr;
@@ -307,7 +314,9 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 16 * b + tc;
-            double v = (double)cov_exp2(hd[tri(a, b)], ca, lgp);
+            // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
+            // not multiplied by -inf)
+            double v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[tri(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[tri(a, b)], ca, lgp));
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
             if (a == b && tr == tc) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
@@ -317,7 +326,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     });
     // ---- elimination: panels of four columns ------------------------------------------------------
     int pbuf = 0;
-    double dmin = 1.0;                                       // smallest pivot this wave has factorised
+    double nmax = -1.0;                                      // -(smallest pivot this wave has factorised)
     sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
         constexpr int bp = decltype(bp_)::value;
         const int ncb = k - 16 * bp;                         // C columns left
@@ -332,7 +341,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                 //     element as a column-by-column sweep.  One wave, not all four: the chain is ~30 instructions
                 //     and would otherwise be issued on every SIMD.  A non-positive pivot gives NaN factors that
                 //     reach the Schur block (k_uk_solve rejects non-finite results); too small a pivot is caught
-                //     through dmin at the end.
+                //     through nmax at the end.
                 if (wvp == s) {
                 TWX_STAMP(4 * bp + s, 2);
                 sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
@@ -351,9 +360,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                 const double2 g3b = double2{dg[2 * NP + 3], dg[3 * NP + 3]};
                 // the registers hold N = -M: pivot d = -n, l = n * (-1/sqrt(d)), updates n += l l
                 auto pivot = [&](double nd) __attribute__((always_inline)) {
-                    const double d = -nd;
-                    dmin = fmin(dmin, d);
-                    return -rsqrt_nr(d);
+                    nmax = max_raw(nmax, nd);                // (a NaN pivot is not caught here: it reaches the Schur block)
+                    return -rsqrt_nr(-nd);
                 };
                 const double r0 = pivot(g00);
                 const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
@@ -362,12 +370,12 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                 const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
                 const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
                 const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))));
-                constexpr int NROW = 16 * (NB - bp), RPR = 64;
+                constexpr int NROW = 16 * (NB - bp), RPR = 64, NU = (NROW + RPR - 1) / RPR;
 #pragma unroll
-                for (int u = 0; u < (NROW + RPR - 1) / RPR; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     // only the rows below the panel are needed (by the update of live elements); the finished rows
                     // keep whatever the slab held, which reaches finished elements only
-                    const int rr = 4 * s + 4 + lane + RPR * u;           // row within the block rows bp..
+                    const int rr = 4 * s + 4 + lane + RPR * u;
                     if (rr < NROW) {
                         const int myrow = 16 * bp + rr;
                         const double2 n01 = double2{s_raw[myrow], s_raw[NP + myrow]};
@@ -427,7 +435,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             }
         }
     });
-    if (!(dmin > 1e-9 * c00) || k > kdup) s_err = 1;         // singular / indefinite system (benign race: all write 1)
+    if (!(-nmax > 1e-9 * c00) || k > kdup) s_err = 1;         // singular / indefinite system (benign race: all write 1)
 
     // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
     if (tr >= 9 && tc >= 9 && tr >= tc) {

@@ -128,7 +128,9 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
             const int j = 4 * b + tc;
-            double v = (double)cov_exp2(hd[widx(a, b)], ca, lgp);
+            // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
+            // not multiplied by -inf)
+            double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
             // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0), so the panel step has no special cases
             if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
@@ -137,7 +139,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         });
     });
     // ---- elimination: one panel per block column ----------------------------------------------------------
-    double dmin = 1.0;                                       // smallest pivot
+    double nmax = -1.0;                                      // -(smallest pivot)
     sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
         constexpr int b = decltype(b_)::value;
         constexpr int a0 = b / 4;                            // first block row holding columns 4b..4b+3
@@ -151,7 +153,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             // (2) the 4x4 diagonal block (uniform addresses: broadcasts), its Cholesky factor, then one row
             //     solve per lane and round -- the same fma sequence per element as a column-by-column sweep.
             //     A non-positive pivot gives NaN factors that reach the Schur block (k_uk_solve rejects
-            //     non-finite results); too small a pivot is caught through dmin at the end.
+            //     non-finite results); too small a pivot is caught through nmax at the end.
             // column-major panel image: s_raw[column][row] (publishing lanes write consecutive rows, the row solve
             // reads consecutive rows: no bank conflicts); the diagonal block comes back as broadcasts
             const double *dg = &s_raw[4 * b];
@@ -162,9 +164,8 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             const double2 g3 = double2{dg[3], dg[NP + 3]};
             const double2 g3b = double2{dg[2 * NP + 3], dg[3 * NP + 3]};
             auto pivot = [&](double nd) __attribute__((always_inline)) {
-                const double d = -nd;
-                dmin = fmin(dmin, d);
-                return -rsqrt_nr(d);
+                nmax = max_raw(nmax, nd);
+                return -rsqrt_nr(-nd);
             };
             const double r0 = pivot(g00);
             const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
@@ -237,5 +238,5 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
                 ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[widx(NBR - 1, bb)];
         });
     }
-    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (dmin > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
+    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (-nmax > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
 }
