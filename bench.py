@@ -187,6 +187,9 @@ def main():
     # bandwidths actually used by the timed steps (diagnostic accessor, no extra launches)
     ks = ctx.last_bandwidths(_lib.TMIN).ravel()
     flops_per_solve = float(uk_flops(ks[ks > 0]).mean())
+    # systems per kriging launch: matrix rows (k + 8, rounded up to the kernel's size) -> count
+    edges = np.array([40, 48, 56, 64, 72, 80, 88, 96, 112, 128, 144, 160])
+    rows_hist = np.bincount(np.searchsorted(edges, ks[ks > 0] + 8), minlength=edges.size + 1)
     ach_tflops = flops_per_solve * solves / (uk_ms * 1e-3) / 1e12
     # PMC counters cannot be read from inside the process: the committed measurement of THIS workload is quoted
     traffic, traffic_src = (None, None)
@@ -213,7 +216,8 @@ def main():
                      "kernel_ms_per_step": uk_ms,
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},
         "fp64": {"achieved": ach_tflops, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": ach_tflops / FP64_VEC_PEAK_TFLOPS, "flops_per_solve": flops_per_solve},
+                 "frac": ach_tflops / FP64_VEC_PEAK_TFLOPS, "flops_per_solve": flops_per_solve,
+                 "systems_by_matrix_rows": {str(int(e)): int(c) for e, c in zip(edges, rows_hist) if c}},
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},
     }

@@ -238,7 +238,7 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
         (void)hipMemsetAsync(dbg, 0, nb, s);
         w2.dbg = dbg;
     }
-    hipLaunchKernelGGL((k_uk<NB>), dim3(grid), dim3(256), 0, s, st, src, w2, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB)>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, w2, cells, ws.bucket_cnt + bucket);
     if (NB == 7) {
         std::vector<unsigned long long> h(nb / 8);
         (void)hipStreamSynchronize(s);
@@ -246,7 +246,7 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
         if (FILE *f = fopen("gpurun_out/uk_stamps.bin", "wb")) { fwrite(h.data(), 1, nb, f); fclose(f); }
     }
 #else
-    hipLaunchKernelGGL((k_uk<NB>), dim3(grid), dim3(256), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB)>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 #endif
 }
 

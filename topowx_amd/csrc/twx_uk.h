@@ -1,21 +1,22 @@
 // twx_uk.h -- universal-kriging kernel.
 //
-// One 256-thread workgroup per (cell, month) item; items are bucketed by their own
-// neighbourhood size k so that every launch runs a kernel specialised (template NB)
-// for NP = 16*NB >= k + 7 rows.  The bordered matrix
+// One work-group of NW = 2 or 4 wavefronts per (cell, month) item; items are bucketed by their own
+// neighbourhood size k so that every launch runs a kernel specialised (template NB, NW)
+// for NP = 16*NB >= k + 8 rows.  The bordered matrix
 //
 //        M = [ C   B ]      C = k x k covariance, B = [1 x1 x2 x3 x4 | y | c0]
 //            [ B'  0 ]
 //
 // is held ENTIRELY IN REGISTERS (negated: the registers hold N = -M, so every update is a pure
-// fmac), distributed 2-D block-cyclically over the 16x16 thread grid: thread (tr, tc) owns element
-// (16a+tr, 16b+tc) of every 16x16 block (a >= b).  Right-looking Cholesky eliminates the C part in
+// fmac), distributed 2-D block-cyclically over the 16 x 4NW thread grid: thread (tr, tc) owns element
+// (16a+tr, 4NW b+tc) of every 16 x 4NW block that reaches the lower triangle.  Right-looking Cholesky eliminates
+// the C part in
 // PANELS of four columns with ONE work-group barrier per panel:
 //   (1) the one wavefront that holds the panel's four columns (lanes = 4 columns x 16 rows) writes them
 //       unfactorised to LDS, reads the 4x4 diagonal block back through LDS broadcasts, factorises it
 //       (the chain of four dependent rsqrt passes through neither LDS nor another wave) and solves the
 //       panel's rows, 64 per round (one row per lane) -- the same fma sequence per element as a column
-//       sweep -- into a double-buffered slab; the other three waves are still applying the previous
+//       sweep -- into a double-buffered slab; the other waves are still applying the previous
 //       panel meanwhile;
 //   (2) after the barrier every thread applies the rank-4 update to its own elements (all register
 //       indices compile-time).  The column factors are common to the 16 lanes of a DPP row, so each
@@ -181,15 +182,30 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
     if (t == 0) ws.cdup[lc] = s_dup;
 }
 
+// Waves per work-group (column groups of four) per matrix size.  Two waves hold 16 x 8 blocks: twice the elements
+// per thread, half the threads per system.  What it buys is resident SYSTEMS per CU at the same register file:
+// 112 rows: 6 (3 waves per SIMD x 166 VGPRs) instead of 4; 144 / 160 rows: 4 (2 waves per SIMD) instead of 3; and every
+// row factor read from LDS feeds twice as many fmacs.  Measured per launch on the C2 bench (four waves -> two):
+// 112 rows 3.30 -> 2.72 ms, 144 rows 1.03 -> 0.92, 160 rows 1.43 -> 1.38; 128 rows 1.85 -> 1.91 (4 systems either
+// way, and 6 only with spills): stays at four waves.
+#ifndef TWX_UK_NW
+#define TWX_UK_NW 2, 2, 4, 2          // NB = 10, 9, 8, 7
+#endif
+__host__ __device__ constexpr int twx_uk_nw(int nb)
+{
+    constexpr int w[4] = {TWX_UK_NW};
+    return w[10 - nb];
+}
+// waves per SIMD the register budget is sized for (min == max so that the compiler does not spill the
+// register-resident matrix to chase a higher occupancy; measured per bucket on the C2 bench)
 #ifndef TWX_UK_WV
-#define TWX_UK_WV 3, 3, 4, 4, 5, 6, 7   // NB = 10, 9, 8, 7, 6, 5, 4
+#define TWX_UK_WV 2, 2, 4, 3          // NB = 10, 9, 8, 7
 #endif
 __host__ __device__ constexpr int twx_uk_waves(int nb)
 {
-    constexpr int w[7] = {TWX_UK_WV};
+    constexpr int w[4] = {TWX_UK_WV};
     return w[10 - nb];
 }
-#define TWX_UK_WAVES(NB) twx_uk_waves(NB)
 
 #ifdef TWX_UK_STAMP
 #ifndef TWX_STAMP_WG0
@@ -207,32 +223,40 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 #define TWX_STAMP(P, SLOT) do { } while (0)
 #endif
 
-template <int NB>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(TWX_UK_WAVES(NB), TWX_UK_WAVES(NB))))
+// Thread (tr, tc) = (t & 15, 4 * wave + lane / 16) of the 16 x CB thread grid (CB = 4 NW columns) owns element
+// (16a + tr, CB b + tc) of every 16 x CB block that reaches the lower triangle: block columns b < 16 (a + 1) / CB of
+// block row a, stored at uk_eidx(a, b).
+template <int NW> __device__ __forceinline__ constexpr int uk_nbc(int a) { return 16 * (a + 1) / (4 * NW); }
+template <int NW> __device__ __forceinline__ constexpr int uk_eidx(int a, int b) { return (4 / NW) * (a * (a + 1) / 2) + b; }
+
+template <int NB, int NW>
+__global__ __launch_bounds__(64 * NW)
+__attribute__((amdgpu_waves_per_eu(twx_uk_waves(NB), twx_uk_waves(NB))))
 void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
-    constexpr int NP = NB * 16, NT = NB * (NB + 1) / 2;
+    constexpr int NP = NB * 16, CB = 4 * NW, NBC = NP / CB, NT = uk_eidx<NW>(NB, 0), NTH = 64 * NW;
     constexpr int PS = 6;   // slab row stride in doubles: 48 B rows make the 16-B x 16-row reads bank-conflict free
+    constexpr int RPT = (NP + NTH - 1) / NTH;               // matrix rows staged per thread
+    static_assert(RPT <= 2, "at most two neighbours per thread in the staging");
     __shared__ __attribute__((aligned(16))) double s_pan[2][NP * PS];         // four scaled columns of a panel, [row][4]; double-buffered:
                                                                               // the next panel is factorised while this one is still being applied
     __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
-    __shared__ double s_red[4][4];
+    __shared__ double s_red[NW][4];
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: branches on the wave's role are s_cbranch
     // Which wave holds which four columns of a block is rotated per work-group: the work-groups resident on
     // a CU run in near lockstep, and without the rotation their panel factorisations (one wave each) would
-    // all queue on the same SIMD while the other three idle.
+    // all queue on the same SIMD while the others idle.
     // The item count of this matrix-size bucket lives in device memory (k_bucket_items): the host never reads it.
     // The launch covers the worst case (every system of the batch in this bucket); surplus work-groups leave at
     // once.  (A fixed grid striding over the list keeps ~100 kernel-argument SGPRs live across the loop and spills.)
     const int it = blockIdx.x;
     if (it >= *nitems_dev) return;
-    const int rot = (int)(((unsigned)it * 2654435761u) >> 13) & 3;
-    const int wvp = (wv + rot) & 3;              // column group of this wave
+    const int rot = (int)(((unsigned)it * 2654435761u) >> 13) & (NW - 1);
+    const int wvp = (wv + rot) & (NW - 1);       // column group of this wave
     const int tc = 4 * wvp + tcl;
     const int item = item_list[it];
     const int64_t lc = item / 12;
@@ -252,51 +276,66 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     const float lgp = __builtin_amdgcn_logf((float)psill_e);          // log2 psill (-inf for a pure nugget)
     const int kdup = ws.cdup[lc];                                     // systems larger than this hold coincident neighbours: singular
 
-    // the pair distances of this thread's elements (k_cell_dist's cache): every load is issued here, before the
-    // staging, so that their latency hides behind it (measured: 13.3 -> 12.75 ms per C2 step) (entries outside the neighbourhood are never used; the slab of
-    // a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
+    // the pair distances of this thread's elements (k_cell_dist's cache, 16x16 blocks, element order [column][row]):
+    // every load is issued here, before the staging, so that their latency hides behind it (measured: 13.3 -> 12.75 ms
+    // per C2 step) (entries outside the neighbourhood are masked by the build; the slab of a cell always spans
+    // TWX_DIST_BLOCKS blocks, so the addresses are valid)
     float hd[NT];
-    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     {
+        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
             constexpr int a = decltype(a_)::value;
-            sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
+            sfor<0, uk_nbc<NW>(a)>([&](auto b_) __attribute__((always_inline)) {
                 constexpr int b = decltype(b_)::value;
-                hd[tri(a, b)] = (a < TWX_DIST_NB) ? __builtin_nontemporal_load(&dist[tri(a, b) * 256]) : 1.f;
+                constexpr int j0 = CB * b;                   // first column of the block
+                hd[uk_eidx<NW>(a, b)] = (a < TWX_DIST_NB) ? __builtin_nontemporal_load(&dist[tri(a, j0 / 16) * 256 + (j0 % 16) * 16]) : 1.f;
             });
         });
     }
 
-    // ---- staging: one neighbour per thread (NP <= 160 < 256) ------------------------------
-    double x0 = 0, x1 = 0, x2 = 0, x3 = 0, yv = 0, c0v = 0;
-    if (t < k) {
-        const int j = ws.near_idx[lc * ws.ksel + t];
-        const double lo = st.lon[j], la = st.lat[j];
-        x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
-        yv = st.norm[m0 * n + j];
-        // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
-        const float h0 = ws.h0[lc * ws.ksel + t];
-        const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-        c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+    // ---- staging: neighbours t, t + NTH (NP <= 2 NTH) ------------------------------------------
+    double xs[RPT][4], yv[RPT], c0v[RPT];
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int q = t + NTH * u;
+        xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
+        if (q < k) {
+            const int j = ws.near_idx[lc * ws.ksel + q];
+            const double lo = st.lon[j], la = st.lat[j];
+            xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev; xs[u][3] = st.lst[m0 * n + j] - plst;
+            yv[u] = st.norm[m0 * n + j];
+            // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
+            const float h0 = ws.h0[lc * ws.ksel + q];
+            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+            c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+            e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
+            e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
+        }
     }
-    {
-        double e0 = wave_max(fabs(x0)), e1 = wave_max(fabs(x1)), e2 = wave_max(fabs(x2)), e3 = wave_max(fabs(x3));
-        if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
-    }
+    e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
+    if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
     if (t == 0) s_err = 0;
-    for (int q = t; q < 2 * NP * PS; q += 256) (&s_pan[0][0])[q] = 0.0;   // finished rows are never written: keep them finite
+    for (int q = t; q < 2 * NP * PS; q += NTH) (&s_pan[0][0])[q] = 0.0;   // finished rows are never written: keep them finite
     __syncthreads();
-    if (t < NP) {
+    {
         double sc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            double s = fmax(fmax(s_red[0][q], s_red[1][q]), fmax(s_red[2][q], s_red[3][q]));
+            double s = s_red[0][q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s = fmax(s, s_red[w][q]);
             sc[q] = s > 0.0 ? 1.0 / s : 1.0;
         }
-        const bool in = t < k;
-        s_B[0][t] = in ? 1.0 : 0.0;
-        s_B[1][t] = x0 * sc[0]; s_B[2][t] = x1 * sc[1]; s_B[3][t] = x2 * sc[2]; s_B[4][t] = x3 * sc[3];
-        s_B[5][t] = yv; s_B[6][t] = c0v;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int q = t + NTH * u;
+            if (q < NP) {
+                s_B[0][q] = q < k ? 1.0 : 0.0;
+                s_B[1][q] = xs[u][0] * sc[0]; s_B[2][q] = xs[u][1] * sc[1]; s_B[3][q] = xs[u][2] * sc[2]; s_B[4][q] = xs[u][3] * sc[3];
+                s_B[5][q] = yv[u]; s_B[6][q] = c0v[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -311,47 +350,49 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
         const float ca = i < k ? chi : -__builtin_inff();
-        sfor<0, a + 1>([&](auto b_) __attribute__((always_inline)) {
+        sfor<0, uk_nbc<NW>(a)>([&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value;
-            const int j = 16 * b + tc;
+            constexpr int e = uk_eidx<NW>(a, b);
+            const int j = CB * b + tc;
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
-            double v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[tri(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[tri(a, b)], ca, lgp));
+            double v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
-            if (a == b && tr == tc) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
-            if (a == NB - 1) v = rhs_row ? rhs[16 * b] : v;  // unconditional LDS read: no branch per element
-            A[tri(a, b)] = -v;                               // the registers hold N = -M: updates are pure fmacs
+            if (CB * b / 16 == a && i == j) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
+            if (a == NB - 1) v = rhs_row ? rhs[CB * b] : v;  // unconditional LDS read: no branch per element
+            A[e] = -v;                                       // the registers hold N = -M: updates are pure fmacs
         });
     });
-    // ---- elimination: panels of four columns ------------------------------------------------------
+    // ---- elimination: panels of four columns, NW per block column --------------------------------------
     int pbuf = 0;
     double nmax = -1.0;                                      // -(smallest pivot this wave has factorised)
-    sfor<0, NB>([&](auto bp_) __attribute__((always_inline)) {
-        constexpr int bp = decltype(bp_)::value;
-        const int ncb = k - 16 * bp;                         // C columns left
+    sfor<0, NBC>([&](auto bc_) __attribute__((always_inline)) {
+        constexpr int bc = decltype(bc_)::value;
+        constexpr int a0 = CB * bc / 16;                     // first block row that reaches this block column
+        const int ncb = k - CB * bc;                         // C columns left
         if (ncb > 0) {
-            const int npan = min(4, (ncb + 3) >> 2);
+            const int npan = min(NW, (ncb + 3) >> 2);
 #pragma nounroll
             for (int s = 0; s < npan; ++s) {
                 // (1)+(2) the wave holding the panel's four columns: publish them as they are (LDS operations of
                 //     one wave execute in order: no barrier), read the 4x4 diagonal block back through LDS
                 //     broadcasts, factorise it (a chain of four dependent rsqrt that passes through neither LDS
                 //     nor another wave), then solve the panel's rows, 64 per round -- the same fma sequence per
-                //     element as a column-by-column sweep.  One wave, not all four: the chain is ~30 instructions
+                //     element as a column-by-column sweep.  One wave, not all: the chain is ~30 instructions
                 //     and would otherwise be issued on every SIMD.  A non-positive pivot gives NaN factors that
                 //     reach the Schur block (k_uk_solve rejects non-finite results); too small a pivot is caught
                 //     through nmax at the end.
                 if (wvp == s) {
-                TWX_STAMP(4 * bp + s, 2);
-                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                TWX_STAMP(NW * bc + s, 2);
+                sfor<a0, NB>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value;
-                    s_raw[tcl * NP + 16 * a + tr] = A[tri(a, bp)];
+                    s_raw[tcl * NP + 16 * a + tr] = A[uk_eidx<NW>(a, bc)];
                 });
                 __builtin_amdgcn_wave_barrier();
                 // column-major panel image: s_raw[column][row] (publishing lanes write consecutive rows, the row solve
                 // reads consecutive rows: no bank conflicts); the diagonal block comes back as broadcasts
-                const double *dg = &s_raw[16 * bp + 4 * s];
+                const double *dg = &s_raw[CB * bc + 4 * s];
                 const double g00 = dg[0];
                 const double2 g1 = double2{dg[1], dg[NP + 1]};
                 const double2 g2 = double2{dg[2], dg[NP + 2]};
@@ -370,14 +411,14 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                 const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
                 const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
                 const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))));
-                constexpr int NROW = 16 * (NB - bp), RPR = 64, NU = (NROW + RPR - 1) / RPR;
+                constexpr int NROW = NP - CB * bc, RPR = 64;
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
+                for (int u = 0; u < (NROW + RPR - 1) / RPR; ++u) {
                     // only the rows below the panel are needed (by the update of live elements); the finished rows
                     // keep whatever the slab held, which reaches finished elements only
-                    const int rr = 4 * s + 4 + lane + RPR * u;
+                    const int rr = 4 * s + 4 + lane + RPR * u;           // row counted from the block column's first
                     if (rr < NROW) {
-                        const int myrow = 16 * bp + rr;
+                        const int myrow = CB * bc + rr;
                         const double2 n01 = double2{s_raw[myrow], s_raw[NP + myrow]};
                         const double2 n23 = double2{s_raw[2 * NP + myrow], s_raw[3 * NP + myrow]};
                         const double L0 = n01.x * r0;
@@ -388,59 +429,60 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                         *reinterpret_cast<double2 *>(&s_pan[pbuf][myrow * PS + 2]) = double2{L2, L3};
                     }
                 }
-                TWX_STAMP(4 * bp + s, 3);
+                TWX_STAMP(NW * bc + s, 3);
                 }
                 __syncthreads();
-                TWX_STAMP(4 * bp + s, 0);
-                // (3) rank-4 update N(i,j) += l(i,:) . l(j,:).  The column factors l(16b+tc, 0..3) are common to
-                // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bp) + column) once
+                TWX_STAMP(NW * bc + s, 0);
+                // (3) rank-4 update N(i,j) += l(i,:) . l(j,:).  The column factors l(CB b + tc, 0..3) are common to
+                // the 16 lanes of a DPP row: lane n of the row loads entry e = 16r + n (e = 4(b-bc) + column) once
                 // per panel and every fmac picks its operand with row_newbcast; the row factors l(16a+tr, 0..3)
-                // are read once per block row.  LDS reads per panel: 2(NB-bp) b128 + 3 b64 per lane.
+                // are read once per block row.
                 // In the panel's own block column only the waves holding columns right of the panel (wvp > s)
                 // still have live elements: the others skip it (a scalar branch).
                 const double *pan = s_pan[pbuf];
                 pbuf ^= 1;
-                constexpr int NE = 4 * (NB - bp), NR = (NE + 15) / 16;
+                constexpr int NE = 4 * (NBC - bc), NR = (NE + 15) / 16;
                 const bool own_live = wvp > s;
                 double P[NR];
                 sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     const int e = min(16 * r + tr, NE - 1);
-                    P[r] = pan[(16 * (bp + (e >> 2)) + tc) * PS + (e & 3)];
+                    P[r] = pan[(CB * (bc + (e >> 2)) + tc) * PS + (e & 3)];
                 });
-                sfor<bp, NB>([&](auto a_) __attribute__((always_inline)) {
+                sfor<a0, NB>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value;
                     const double2 u0 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS]);
                     const double2 u1 = *reinterpret_cast<const double2 *>(&pan[(16 * a + tr) * PS + 2]);
                     if (own_live) {
-                        double acc = A[tri(a, bp)];
+                        double acc = A[uk_eidx<NW>(a, bc)];
                         fmac_rowbcast<0>(acc, P[0], u0.x);
                         fmac_rowbcast<1>(acc, P[0], u0.y);
                         fmac_rowbcast<2>(acc, P[0], u1.x);
                         fmac_rowbcast<3>(acc, P[0], u1.y);
-                        A[tri(a, bp)] = acc;
+                        A[uk_eidx<NW>(a, bc)] = acc;
                     }
-                    sfor<bp + 1, a + 1>([&](auto b_) __attribute__((always_inline)) {
+                    sfor<bc + 1, uk_nbc<NW>(a)>([&](auto b_) __attribute__((always_inline)) {
                         constexpr int b = decltype(b_)::value;
-                        constexpr int e = 4 * (b - bp);
-                        double acc = A[tri(a, b)];
+                        constexpr int e = 4 * (b - bc);
+                        double acc = A[uk_eidx<NW>(a, b)];
                         fmac_rowbcast<(e + 0) % 16>(acc, P[(e + 0) / 16], u0.x);
                         fmac_rowbcast<(e + 1) % 16>(acc, P[(e + 1) / 16], u0.y);
                         fmac_rowbcast<(e + 2) % 16>(acc, P[(e + 2) / 16], u1.x);
                         fmac_rowbcast<(e + 3) % 16>(acc, P[(e + 3) / 16], u1.y);
-                        A[tri(a, b)] = acc;
+                        A[uk_eidx<NW>(a, b)] = acc;
                     });
                 });
-                TWX_STAMP(4 * bp + s, 1);
+                TWX_STAMP(NW * bc + s, 1);
             }
         }
     });
-    if (!(-nmax > 1e-9 * c00) || k > kdup) s_err = 1;         // singular / indefinite system (benign race: all write 1)
+    if (!(-nmax > 1e-9 * c00) || k > kdup) s_err = 1;        // singular / indefinite system (benign race: all write 1)
 
     // ---- Schur complement out: the 7x7 GLS epilogue runs one thread per system in k_uk_solve -------
-    if (tr >= 9 && tc >= 9 && tr >= tc) {
-        const int r = tr - 9, cq = tc - 9;
-        ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[tri(NB - 1, NB - 1)];
+    {
+        const int r = tr - 9, cq = CB * (NBC - 1) + tc - (NP - 7);   // RHS rows / columns NP-7..NP-1 (last block column)
+        if (r >= 0 && cq >= 0 && r >= cq)
+            ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + cq] = A[uk_eidx<NW>(NB - 1, NBC - 1)];
     }
     __syncthreads();
     if (t == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = s_err ? 1.0 : 0.0;
