@@ -146,10 +146,40 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Wave-wide sum through DPP row shifts / row broadcasts (no LDS crossbar traffic: a __shfl_xor butterfly costs two
+// ds_bpermute per step and double).  All lanes return the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);       // lanes without a source (or in a masked row) add +0
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v = dpp_add_step<0x111, 0xf>(v);           // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);           // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);           // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);           // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_step<0x142, 0xa>(v);           // row_bcast:15 into rows 1 and 3
+    v = dpp_add_step<0x143, 0xc>(v);           // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 

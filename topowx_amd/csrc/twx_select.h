@@ -175,6 +175,13 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
 // them (clo < ncand <= chi; masked cells belong to the first).  Dynamic LDS: WPB * chi doubles.
 // ---------------------------------------------------------------------------------
 #define TWX_CAND_SMALL 512
+// months whose gathers are in flight together in k_select's smoothing: bandwidths (GA) / variogram parameters (GB).
+// Measured on the C2 bench (select_ms): 4/1 1.08, 6/2 1.11, 12/3 1.13, 12/4 1.25 (144 VGPRs), month by month 1.26:
+// past a few months per round the registers cost more occupancy than the shorter dependency chain wins.
+#ifndef TWX_SEL_GA
+#define TWX_SEL_GA 4
+#define TWX_SEL_GB 1
+#endif
 #define TWX_CAND_MAX 2048    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS)
 struct SmoothOut { int status; int k; };
 
@@ -195,18 +202,21 @@ __device__ __forceinline__ int smooth3(const double *snd, const int *sidx, int n
     const double dbw = snd[k];
     if (!(dbw > 0.0)) return TWX_CELL_NUMERIC;
     double n0 = 0, n1 = 0, n2 = 0, den = 0;
-    int cnt = 0;
-    for (int r = lane; r < k; r += 64) {
-        int j = sidx[r];
-        double v0 = f0[j];
-        if (finite_d(v0)) {
+    int cnt = 0;                                             // neighbours with a finite field value (scalar: ballot + popcount)
+    for (int r0 = 0; r0 < k; r0 += 64) {
+        const int r = r0 + lane;
+        const int j = r < k ? sidx[r] : -1;
+        const double v0 = j >= 0 ? f0[j] : NAN;
+        const bool fin = finite_d(v0);
+        cnt += __popcll(__ballot(fin));
+        if (fin) {
             double w = bisq(snd[r], dbw);
-            n0 += v0 * w; den += w; ++cnt;
+            n0 += v0 * w; den += w;
             if (f1) { n1 += f1[j] * w; n2 += f2[j] * w; }
         }
     }
-    n0 = wave_sum(n0); den = wave_sum(den); cnt = wave_sum_i(cnt);
-    if (f1) { n1 = wave_sum(n1); n2 = wave_sum(n2); }
+    n0 = wave_sum_dpp(n0); den = wave_sum_dpp(den);
+    if (f1) { n1 = wave_sum_dpp(n1); n2 = wave_sum_dpp(n2); }
     if (cnt == 0) return -1; // caller maps to NNGHS / VARIO
     if (!(den != 0.0)) return TWX_CELL_NUMERIC;
     out[0] = n0 / den; out[1] = n1 / den; out[2] = n2 / den;
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     const int64_t c = ws.cell0 + (in_range ? lc : 0);       // global cell id
     bool valid = in_range && cell_valid(src, c);
     double *sd = s_dyn + (size_t)wv * chi;
+    uint16_t *scj = reinterpret_cast<uint16_t *>(s_dyn + (size_t)WPB * chi) + (size_t)wv * chi;   // list position of a compacted candidate
     double *snd = s_nd[wv];
     int *sni = s_ni[wv];
     int *snp = s_np[wv];
@@ -258,32 +269,66 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     }
     for (int r = lane; r < TWX_KSEL_MAX; r += 64) snp[r] = -1;
     nv = wave_sum_i(nv);
-    __syncthreads();
-    // phase 2: rank by counting
-    for (int j = lane; j < ncand; j += 64) {
-        double dj = sd[j];
-        if (dj == INFINITY) continue;
-        int rank = 0;
-        for (int i = 0; i < ncand; ++i) {
-            double di = sd[i];
-            rank += (di < dj) || (di == dj && i < j);
+    __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
+    // phase 2: the ksel nearest, ranked.  Ranking by counting costs (candidates)^2 / 64 compares per lane, and a tile's
+    // list is 2-3 x ksel long: first a distance bound T with at least ksel candidates inside (bisection on the fp32
+    // distance: a monotone key; every step is one compare per candidate and a population count), then the candidates
+    // inside the bound are compacted in list order and only they are ranked.  Whatever lies outside is strictly
+    // farther than everything inside, so the ranks < ksel are the ranks of the full list (ties: list order, as before).
+    float T = __builtin_inff();
+    if (nv > ws.ksel) {
+        float lo = 0.f, hi = 0.f;
+        for (int j = lane; j < ncand; j += 64) { const double d = sd[j]; if (d != INFINITY) hi = fmaxf(hi, (float)d); }
+        hi = wave_max_f(hi);
+        int chi_cnt = nv;
+        for (int itr = 0; itr < 12 && chi_cnt > ws.ksel + 8; ++itr) {
+            const float mid = 0.5f * (lo + hi);
+            int cnt = 0;                                     // scalar: ballot + population count per chunk of 64
+            for (int j0 = 0; j0 < ncand; j0 += 64) {
+                const int j = j0 + lane;
+                cnt += __popcll(__ballot(j < ncand && (float)sd[j] <= mid));
+            }
+            if (cnt >= ws.ksel) { hi = mid; chi_cnt = cnt; } else lo = mid;
         }
-        if (rank < ws.ksel) snp[rank] = j;
+        T = hi;
     }
-    __syncthreads();
+    int m = 0;                                               // candidates inside the bound (wave-uniform)
+    for (int j0 = 0; j0 < ncand; j0 += 64) {
+        const int j = j0 + lane;
+        const double d = j < ncand ? sd[j] : INFINITY;
+        const bool keep = d != INFINITY && (float)d <= T;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {                                          // in place: position <= j, and this chunk has been read
+            const int pos = m + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            sd[pos] = d; scj[pos] = (uint16_t)j;
+        }
+        m += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
+    for (int p = lane; p < m; p += 64) {
+        const double dj = sd[p];
+        int rank = 0;
+        for (int i = 0; i < m; ++i) {
+            const double di = sd[i];
+            rank += (di < dj) || (di == dj && i < p);
+        }
+        if (rank < ws.ksel) snp[rank] = p;
+    }
+    __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
     const int nnear = min(nv, ws.ksel);
     for (int r = lane; r < TWX_KSEL_MAX; r += 64) {
-        int p = (r < nnear) ? snp[r] : -1;
-        int s = p >= 0 ? cand[p] : -1;
-        double d = p >= 0 ? sd[p] : INFINITY;
+        const int p = (r < nnear) ? snp[r] : -1;
+        const int j = p >= 0 ? (int)scj[p] : 0;
+        const int s = p >= 0 ? cand[j] : -1;
+        const double d = p >= 0 ? sd[p] : INFINITY;
         snd[r] = d; sni[r] = s;
         if (valid && r < ws.ksel) {
             ws.near_idx[lc * ws.ksel + r] = s;
             ws.near_dist[lc * ws.ksel + r] = d;
-            if (ws.near_pos) ws.near_pos[lc * ws.ksel + r] = (uint16_t)(p >= 0 ? p : 0);
+            if (ws.near_pos) ws.near_pos[lc * ws.ksel + r] = (uint16_t)j;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
     if (!in_range) return;
     if (!valid) {
         if (lane == 0) { ws.cstat[lc] = TWX_CELL_MASKED; ws.nnear[lc] = 0; }
@@ -294,6 +339,130 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;
+    const bool given_vario = src.mode == 1 && src.vario_in && finite_d(src.vario_in[c * 3]);
+    if (only == 0 && k_in <= 0 && !given_vario) {
+        // All twelve months at once (the grid path and whole-year point requests).  The month-by-month form below
+        // runs 24-36 dependent rounds of gathers + wave reductions per cell; here the bandwidth smoothing of all
+        // months shares its weights (Select(init_nnghs)) and its 12 (24) gathers are in flight together, and the
+        // variogram smoothing runs several months per round.  Same sums per month; the statuses are then resolved
+        // month by month in the reference's order (krig, then gwr).
+        constexpr int NS = (TWX_MAX_NNGHS + 63) / 64;        // neighbour slots per lane
+        constexpr int GA = TWX_SEL_GA, GB = TWX_SEL_GB;      // months per round (registers <-> rounds of gather latency)
+        const int kinit = ws.init_nnghs;
+        int rc_init = TWX_CELL_OK;                           // smooth3's checks of Select(init_nnghs): the same for every month
+        if (kinit >= nnear) rc_init = TWX_CELL_FEW_STATIONS;
+        else if (!(snd[kinit] > 0.0)) rc_init = TWX_CELL_NUMERIC;
+        int jn[NS];
+        double dn[NS], wi[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int r = lane + 64 * u;
+            jn[u] = r < nnear ? sni[r] : -1;
+            dn[u] = r < nnear ? snd[r] : INFINITY;
+            wi[u] = (rc_init == TWX_CELL_OK && r < kinit) ? bisq(dn[u], snd[kinit]) : 0.0;
+        }
+        // weighted mean of one field per month over Select(init_nnghs) -> rounded bandwidth, smooth3's status
+        auto bandwidths = [&](const double *field, int (&kq)[12], int (&rq)[12]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 12; g += GA) {               // GA months of gathers in flight
+                double v[GA][NS];
+#pragma unroll
+                for (int q = 0; q < GA; ++q)
+#pragma unroll
+                    for (int u = 0; u < NS; ++u)
+                        v[q][u] = (jn[u] >= 0 && lane + 64 * u < kinit) ? field[(g + q) * n + jn[u]] : NAN;
+#pragma unroll
+                for (int q = 0; q < GA; ++q) {
+                    double n0 = 0, den = 0;
+                    int cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        const bool fin = finite_d(v[q][u]);
+                        cnt += __popcll(__ballot(fin));
+                        if (fin) { n0 += v[q][u] * wi[u]; den += wi[u]; }
+                    }
+                    n0 = wave_sum_dpp(n0); den = wave_sum_dpp(den);
+                    int rc = rc_init, kk = 0;
+                    if (!rc && cnt == 0) rc = TWX_CELL_NNGHS;
+                    if (!rc && !(den != 0.0)) rc = TWX_CELL_NUMERIC;
+                    if (!rc) { kk = (int)rint(n0 / den); if (kk < 1 || kk > TWX_MAX_NNGHS) rc = TWX_CELL_RANGE; }
+                    kq[g + q] = __builtin_amdgcn_readfirstlane(kk); rq[g + q] = __builtin_amdgcn_readfirstlane(rc);   // scalars: SGPRs
+                }
+            }
+        };
+        int kq[12], rq[12], kaq[12], raq[12], rvq[12];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) { kq[m] = kaq[m] = 0; rq[m] = raq[m] = rvq[m] = TWX_CELL_OK; }
+        if (!(src.do_krig && src.do_vario) && lane < 36) ws.vario[lc * 36 + lane] = 0.0;
+        if (src.do_krig) bandwidths(st.optim, kq, rq);
+        if (src.do_anom) {
+            bandwidths(st.optim_anom, kaq, raq);
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {                   // GwrTairAnom.__get_nnghs (interp_tair.py:245-259)
+                if (!raq[m] && kaq[m] >= nnear) raq[m] = TWX_CELL_FEW_STATIONS;
+                if (!raq[m] && !(snd[kaq[m]] > 0.0)) raq[m] = TWX_CELL_NUMERIC;
+                raq[m] = __builtin_amdgcn_readfirstlane(raq[m]);
+            }
+        }
+        if (src.do_krig) {
+            // KrigTair.__get_vario_params (interp_tair.py:837-851): weights of Select(k_m), GB months per round
+#pragma unroll
+            for (int g = 0; g < 12; g += GB) {
+                double w[GB][NS], f[GB][3][NS];
+                int rc[GB];
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int m = g + q, k = rq[m] ? 0 : kq[m];
+                    rc[q] = rq[m];
+                    if (!rc[q] && k >= nnear) rc[q] = TWX_CELL_FEW_STATIONS;
+                    if (!rc[q] && !(snd[k] > 0.0)) rc[q] = TWX_CELL_NUMERIC;
+                    const double dbw = rc[q] ? 1.0 : snd[k];
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        const bool act = !rc[q] && src.do_vario && lane + 64 * u < k;
+                        w[q][u] = act ? bisq(dn[u], dbw) : 0.0;
+                        f[q][0][u] = act ? st.nug[m * n + jn[u]] : NAN;
+                        f[q][1][u] = act ? st.psill[m * n + jn[u]] : 0.0;
+                        f[q][2][u] = act ? st.rng[m * n + jn[u]] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int m = g + q;
+                    if (src.do_vario) {
+                        double n0 = 0, n1 = 0, n2 = 0, den = 0;
+                        int cnt = 0;
+#pragma unroll
+                        for (int u = 0; u < NS; ++u) {
+                            const bool fin = finite_d(f[q][0][u]);
+                            cnt += __popcll(__ballot(fin));
+                            if (fin) { n0 += f[q][0][u] * w[q][u]; n1 += f[q][1][u] * w[q][u]; n2 += f[q][2][u] * w[q][u]; den += w[q][u]; }
+                        }
+                        n0 = wave_sum_dpp(n0); n1 = wave_sum_dpp(n1); n2 = wave_sum_dpp(n2); den = wave_sum_dpp(den);
+                        if (!rc[q] && cnt == 0) rc[q] = TWX_CELL_VARIO;
+                        if (!rc[q] && !(den != 0.0)) rc[q] = TWX_CELL_NUMERIC;
+                        if (rc[q]) n0 = n1 = n2 = 0.0, den = 1.0;
+                        if (lane == 0) {
+                            ws.vario[(lc * 12 + m) * 3 + 0] = n0 / den;
+                            ws.vario[(lc * 12 + m) * 3 + 1] = n1 / den;
+                            ws.vario[(lc * 12 + m) * 3 + 2] = n2 / den;
+                        }
+                    }
+                    rvq[m] = __builtin_amdgcn_readfirstlane(rc[q]);   // (without do_vario: only Select(k) must exist)
+                }
+            }
+        }
+        // resolve month by month: the first failure sticks (the reference abandons the point)
+#pragma unroll
+        for (int m0 = 0; m0 < 12; ++m0) {
+            if (status == TWX_CELL_OK && src.do_krig) status = rq[m0] ? rq[m0] : rvq[m0];
+            if (status == TWX_CELL_OK && src.do_anom) status = raq[m0];
+            if (lane == 0) {
+                ws.kk[lc * 12 + m0] = status ? 0 : kq[m0];
+                ws.ka[lc * 12 + m0] = status ? 0 : kaq[m0];
+            }
+        }
+    } else
     for (int m0 = 0; m0 < 12; ++m0) {
         int k = 0, kan = 0;
         double vp[3] = {0, 0, 0};

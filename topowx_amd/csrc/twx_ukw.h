@@ -17,7 +17,7 @@
 
 // waves per SIMD the register budget is sized for (min == max, see twx_uk.h)
 #ifndef TWX_UKW_WV
-#define TWX_UKW_WV 2, 3, 3, 5   // NBR = 6, 5, 4, 3 (measured on the C2 bench; NBR = 4 at three waves: 128 -> 168 VGPRs, no spills, -0.3 ms)
+#define TWX_UKW_WV 2, 3, 4, 5   // NBR = 6, 5, 4, 3 (measured on the C2 bench; NBR = 4: 122 VGPRs since the straight-line build, four waves: -8 %; NBR = 3 at six waves spills: +9 %)
 #endif
 __host__ __device__ constexpr int twx_ukw_waves(int nbr)
 {
