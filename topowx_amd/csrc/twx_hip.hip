@@ -146,7 +146,7 @@ template <class T> T *carve(char *&cur, size_t count)
 
 // ---- workspace of one (batch, variable) ---------------------------------------------
 int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile0, int64_t ntile, int ksel,
-                 int nblocks_tile, bool need_gwr, bool fit_vario = false, bool tile_tab = false)
+                 int nblocks_tile, bool need_gwr, bool fit_vario = false, bool tile_tab = false, bool grid = false)
 {
     Work &w = ctx->work[v];
     const int n = ctx->var[v].n;
@@ -176,8 +176,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
     }
+    if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_union)
     if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
-        HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));
         HIPCHK(w.soff.ensure((size_t)ncell * 12 * TWX_KZ * 4));
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
@@ -205,7 +205,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>();
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
-    s.near_pos = tile_tab ? w.near_pos.as<uint16_t>() : nullptr;
+    s.near_pos = grid ? w.near_pos.as<uint16_t>() : nullptr;
     w.gw.soff = tile_tab ? w.soff.as<uint32_t>() : nullptr;
     w.gw.urow = tile_tab ? w.urow.as<int32_t>() : nullptr;
     w.gw.nurow = tile_tab ? w.nurow.as<int32_t>() : nullptr;
@@ -269,7 +269,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_RANGE): the host
     // never looks at them.  The bucket counts are read back once (exact kriging grids) unless TWX_FLAG_NO_HOST_SYNC.
     w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
-    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0)) return -1;
+    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0, src.mode == 0)) return -1;
     HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
     {
         EvScope ev(ctx, stream, EV_TILE);
@@ -299,7 +299,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     {
         EvScope ev(ctx, stream, EV_UK);
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
-        hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
+        if (w.ws.near_pos)       // grid mode: per tile, from a table of the tile's station pairs
+            hipLaunchKernelGGL(k_tile_dist, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
+        else
+            hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
         const int64_t mi = ncell * 12;
         launch_ukw<6, 1>(cnt, st, src, w.ws, 13, mi, stream);   // k + 8 <= 88
         launch_ukw<6, 0>(cnt, st, src, w.ws, 14, mi, stream);   // k + 8 <= 96

@@ -182,6 +182,148 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
     if (t == 0) ws.cdup[lc] = s_dup;
 }
 
+// ---------------------------------------------------------------------------------
+// k_tile_dist (grid mode): the same cache as k_cell_dist, one work-group per 8x8-cell tile.  The kriging
+// neighbourhoods of a tile's cells draw on the same ~200 stations, so the pair distances of that UNION are evaluated
+// once per tile into an LDS table (lower triangle, fp32, <= TWX_TD_U stations: 129 KB of gfx950's 160 KB) and every
+// cell's rank-ordered blocks are gathered from it: ~15 x fewer evaluations of the distance formula than per cell.
+// A tile whose union is larger evaluates the formula per element from the union's trigonometry staged in the same
+// LDS space.  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
+// ---------------------------------------------------------------------------------
+#define TWX_TD_U 256
+#define TWX_TD_WAVES 16
+#ifndef TWX_TD_PARTS
+#define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
+#endif
+__global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, CellSrc src, SelWs ws)
+{
+    constexpr int NTH = 64 * TWX_TD_WAVES;
+    __shared__ __attribute__((aligned(16))) float s_T[TWX_TD_U * (TWX_TD_U + 1) / 2];
+    __shared__ uint16_t s_slot[TWX_CAND_MAX];                // candidate position -> 1 + number in the union (0: not used)
+    __shared__ double s_trig[TWX_TD_U * 5];                  // sin / cos of half latitude and longitude, cos(latitude)
+    __shared__ uint16_t s_ur[TWX_TD_WAVES][TWX_KSEL_MAX];    // per wave: union number by rank, of the wave's current cell
+    __shared__ int s_cnt[TWX_TD_WAVES], s_base, s_dup[TWX_TD_WAVES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t tl = blockIdx.x / TWX_TD_PARTS;            // local tile; this work-group takes one part of its cells
+    const int part = blockIdx.x % TWX_TD_PARTS;
+    const int64_t tile = ws.tile0 + tl;
+    const int ty = (int)(tile / src.ntx), tx = (int)(tile % src.ntx);
+    const int r0 = ty * src.ts, q0 = tx * src.ts;
+    const int ncl = src.ts * src.ts;                         // cells per tile (<= 64)
+    const int ci0 = ncl * part / TWX_TD_PARTS, ci1 = ncl * (part + 1) / TWX_TD_PARTS;
+    const int ncand = min(ws.ncand[tl], ws.cmax);
+    for (int p = t; p < ncand; p += NTH) s_slot[p] = 0;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    // local cell of the tile's ci-th cell and its largest monthly neighbourhood (wave-uniform; -1 / 0: nothing to do)
+    auto cell_of = [&](int ci, int &kmax) __attribute__((always_inline)) -> int64_t {
+        kmax = 0;
+        const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
+        if (rr >= src.Y || qq >= src.X) return -1;
+        const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
+        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0) return -1;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
+        return lc;
+    };
+    // (1) mark the candidates any cell of the tile kriges with
+    for (int ci = ci0 + wv; ci < ci1; ci += TWX_TD_WAVES) {
+        int kmax;
+        const int64_t lc = cell_of(ci, kmax);
+        for (int r = lane; r < kmax; r += 64) s_slot[ws.near_pos[lc * ws.ksel + r]] = 1;
+    }
+    __syncthreads();
+    // (2) number them in list order, (3) stage their trigonometry (beside the table, or in its place when the union is
+    //     too large for one: the space holds 3 289 stations)
+    for (int p0 = 0; p0 < ncand; p0 += NTH) {
+        const int p = p0 + t;
+        const bool f = p < ncand && s_slot[p] != 0;
+        const unsigned long long b = __ballot(f);
+        const int pre = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_cnt[w];
+        if (f) s_slot[p] = (uint16_t)(off + pre + 1);
+        __syncthreads();
+        if (t == 0) { int a = 0; for (int w = 0; w < TWX_TD_WAVES; ++w) a += s_cnt[w]; s_base += a; }
+        __syncthreads();
+    }
+    const int nu = s_base;
+    if (nu == 0) return;
+    const bool table = nu <= TWX_TD_U;
+    double *trig = table ? s_trig : reinterpret_cast<double *>(s_T);
+    for (int p = t; p < ncand; p += NTH) {
+        const int u = (int)s_slot[p] - 1;
+        if (u >= 0) {
+            const int j = ws.cand[tl * ws.cmax + p];
+            const double sp = st.sph[j], cp = st.cph[j];
+            trig[u * 5 + 0] = sp; trig[u * 5 + 1] = cp; trig[u * 5 + 2] = st.slh[j]; trig[u * 5 + 3] = st.clh[j];
+            trig[u * 5 + 4] = fma(cp, cp, -(sp * sp));
+        }
+    }
+    __syncthreads();
+    // (4) the pair table: row u1 per wave, lanes over u2 < u1
+    if (table) {
+        for (int u1 = wv; u1 < nu; u1 += TWX_TD_WAVES) {
+            const double *a = &trig[u1 * 5];
+            for (int u2 = lane; u2 < u1; u2 += 64) {
+                const double *bq = &trig[u2 * 5];
+                s_T[u1 * (u1 + 1) / 2 + u2] = ellip_pair_fast(a[0], a[1], a[2], a[3], a[4], bq[0], bq[1], bq[2], bq[3], bq[4]);
+            }
+        }
+        __syncthreads();
+    }
+    // (5) every cell's blocks, one cell per wave at a time: rank -> union number, then 64 elements per pass
+    for (int ci = ci0 + wv; ci < ci1; ci += TWX_TD_WAVES) {
+        int kmax;
+        const int64_t lc = cell_of(ci, kmax);
+        if (kmax <= 0) continue;
+        uint16_t *ur = s_ur[wv];
+        if (lane == 0) s_dup[wv] = 0x7fffffff;
+        const double *ct = ws.ctrig + lc * 4;
+        const double ccph = fma(ct[1], ct[1], -(ct[0] * ct[0]));
+        for (int r = lane; r < kmax; r += 64) {
+            const int u = (int)s_slot[ws.near_pos[lc * ws.ksel + r]] - 1;
+            ur[r] = (uint16_t)u;
+            const double *bq = &trig[u * 5];
+            ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nbk = (kmax + 15) >> 4;
+        float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
+        const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
+        for (int a = 0; a < nbk; ++a) {
+            const int i = 16 * a + tr;
+            const bool iv = i < kmax;
+            const int ui = iv ? ur[i] : 0, ti = ui * (ui + 1) / 2;
+            const double *pa = &trig[ui * 5];
+            for (int b = 0; b <= a; ++b) {
+                float *ob = out + (a * (a + 1) / 2 + b) * 256 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 16 * b + 4 * q + tq;
+                    float h = 1.f;                           // diagonal / outside the neighbourhood: any h > 0 (masked by the build)
+                    if (iv && j < kmax && i != j) {
+                        const int uj = ur[j];
+                        if (table) h = s_T[ui > uj ? ti + uj : uj * (uj + 1) / 2 + ui];
+                        else {
+                            const double *pb = &trig[uj * 5];
+                            h = ellip_pair_fast(pa[0], pa[1], pa[2], pa[3], pa[4], pb[0], pb[1], pb[2], pb[3], pb[4]);
+                        }
+                        // coincident neighbours: see k_cell_dist
+                        if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
+                    }
+                    ob[64 * q] = h;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ws.cdup[lc] = s_dup[wv];
+    }
+}
+
 // Waves per work-group (column groups of four) per matrix size.  Two waves hold 16 x 8 blocks: twice the elements
 // per thread, half the threads per system.  What it buys is resident SYSTEMS per CU at the same register file:
 // 112 rows: 6 (3 waves per SIMD x 166 VGPRs) instead of 4; 144 / 160 rows: 4 (2 waves per SIMD) instead of 3; and every
