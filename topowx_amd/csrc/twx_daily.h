@@ -29,6 +29,7 @@ struct GwrWs {
     uint32_t *soff;   // [ncell][12][TWX_KZ]  byte offset of the ranked neighbour's row in the tile's table
     int32_t *urow;    // [ntile][12][TWX_UROWS] station index of table row u
     int32_t *nurow;   // [ntile][12] rows in the table; -1 = more than TWX_UROWS (the tile-month gathers from global memory)
+    double *zd;       // [ncell][12][TWX_UROWS] the hat row scattered to table-row order (0 for rows the cell does not use)
 };
 
 // ---------------------------------------------------------------------------------
@@ -363,20 +364,30 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
         const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
         if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
         const int ka = ws.ka[lc * 12 + m0];
-        for (int r = lane; r < ka; r += 64)
-            gw.soff[(lc * 12 + m0) * TWX_KZ + r] = 256u * (uint32_t)s_slot[ws.near_pos[lc * ws.ksel + r]];
+        // the hat row in table-row order, zero where the cell does not use the row (k_daily_tile walks the TABLE, four
+        // cells at a time): rows up to the next multiple of 16
+        double *zd = gw.zd + (lc * 12 + m0) * TWX_UROWS;
+        for (int u = lane; u < ((nu + 15) & ~15); u += 64) zd[u] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros are out (s_waitcnt vmcnt(0)) before the scatter
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < ka; r += 64) {
+            const uint32_t u = s_slot[ws.near_pos[lc * ws.ksel + r]];
+            gw.soff[(lc * 12 + m0) * TWX_KZ + r] = 256u * u;
+            zd[u] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------
 // k_daily_tile: (8x8-cell tile) x (month) x (64 month-major days), both variables.  Per variable: the tile-month's
-// station rows (k_tile_union) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave
-// walks 16 cells, lane = day: sum_r z_r * row(soff_r)[day] in rank order -- the same fma chain, bit for bit, as
-// daily_value / k_fix_cells -- with the hat row and the row offsets coming through scalar loads and the
-// observations through conflict-free ds_read_b32 (lanes = consecutive days).  Tmin values wait in registers while
-// the table is re-staged for Tmax; cells with any tmin >= tmax are flagged for k_fix_cells; results are transposed
-// through LDS and written as 16-byte runs (8 cells of a tile row) of the [ndays][Y][X] int16 output.
-// A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2), same arithmetic.
+// station rows (k_tile_union) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave takes
+// four cells, lane = day, and walks the TABLE: each row is read from LDS (conflict-free ds_read_b32 with immediate
+// offsets, lanes = consecutive days) and converted once and feeds one fmac per cell, weighted with the cell's hat row in
+// table order (zero where the cell does not use the row; a DPP row broadcast) -- dt_value4.  Tmin values wait in
+// registers while the table is re-staged for Tmax (whose rows are fetched while the Tmin sums run); cells with any
+// tmin >= tmax are flagged for k_fix_cells; results are transposed through LDS and written as 16-byte runs (8 cells
+// of a tile row) of the [ndays][Y][X] int16 output.
+// A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2: rank-order sums).
 // ---------------------------------------------------------------------------------
 #define TWX_DT_WAVES 16                          // waves per work-group of k_daily_tile (2 work-groups fit a CU: LDS)
 #define TWX_DT_CPW (64 / TWX_DT_WAVES)             // cells per wave
@@ -387,6 +398,7 @@ struct DtVar {
     const int32_t *ka;        // [ncell][12]
     const double *z, *zc;     // hat rows / constants
     const uint32_t *soff;     // [ncell][12][TWX_KZ]
+    const double *zd;         // [ncell][12][TWX_UROWS] hat row in table-row order
     const int32_t *urow;      // [ntile][12][TWX_UROWS]
     const int32_t *nurow;     // [ntile][12]
 };
@@ -396,7 +408,7 @@ struct DtArgs {
     const int32_t *mm2chron;
     int16_t *out_n, *out_x;   // [ndays][Y][X]
     int32_t *flag;
-    int64_t cell0, ncell, tile0;
+    int64_t cell0, ncell, tile0, ntile;
     int Y, X, ts, ntx, ndays, nblk_max, gather;
     int moff[13];
 };
@@ -426,56 +438,39 @@ __device__ __forceinline__ void dt_fmac(double &acc, double z, double x)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(z), "v"(x), "n"(N));
 }
 
-// bcast(off, lane N of the row) + base: the LDS byte address of this lane's day in the row of the N-th neighbour
-template <int N>
-__device__ __forceinline__ uint32_t dt_addr(uint32_t off, uint32_t base)
+// The same sums for the FOUR cells of a wave at once, walking the table's rows instead of each cell's own list:
+// every row is read from LDS and converted once per wave (immediate offsets: no address arithmetic) and feeds one
+// fmac per cell, whose weight -- the cell's hat row scattered to table order by k_tile_union, zero where the cell does
+// not use the row -- is again a DPP row broadcast.  ~2 VALU instructions per useful term instead of 3.9; the terms are
+// added in table order, not in rank order (the sum differs from daily_value's in the last bits, far below the int16
+// rounding step; observations are finite by construction of the infilled station matrix).
+__device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TWX_DT_CPW], int m0, const char *tab, uint32_t lane4,
+                                          int lane, int nu, double (&acc)[TWX_DT_CPW])
 {
-    uint32_t r;
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(off), "v"(base), "n"(N));
-    return r;
-}
-
-// sum_r z_r * table_row(soff_r)[lane] + zc in rank order: the fma chain of daily_value, bit for bit.  The hat row
-// and the row offsets are wave-uniform; scalar loads of them put a scalar-cache miss (they share the counter of the
-// LDS reads, so they cannot be prefetched past them) in front of every eight steps -- measured: 75 % of the wave
-// cycles waiting.  Instead lane l of every 16-lane row holds entry 16 c + (l & 15) of the current chunk (two vector
-// loads per 16 steps, prefetched one chunk ahead on the vector-memory counter) and each step picks its entry with a
-// DPP row broadcast inside the address add and inside the fmac: no extra instruction per step.
-__device__ __forceinline__ double dt_value(const DtVar &v, int64_t lc, int m0, const char *tab, uint32_t lane4, int lane)
-{
-    const int ka = v.ka[lc * 12 + m0];
-    const double *z = v.z + (lc * 12 + m0) * TWX_KZ;
-    const uint32_t *so = v.soff + (lc * 12 + m0) * TWX_KZ;
     const int l16 = lane & 15;
-    double acc = 0.0;
-    double zv = l16 < ka ? z[l16] : 0.0;
-    uint32_t sv = l16 < ka ? so[l16] : 0u;
-    for (int r0 = 0; r0 < ka; r0 += 16) {
-        const int nx = r0 + 16 + l16;
-        double zn = 0.0;
-        uint32_t sn = 0u;
-        if (nx < ka) { zn = z[nx]; sn = so[nx]; }              // next chunk, in flight during this one
-        const int rem = ka - r0;
-        if (rem >= 16) {                                       // eight LDS reads in flight at a time
-            sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
-                constexpr int N = decltype(n_)::value;
-                const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
-                dt_fmac<N>(acc, zv, (double)x);
-            });
-        } else {
-            // the last, partial chunk step by step (wave-uniform branches).  Padding it to 16 steps with zero
-            // weights on a row of zeros (fma(0, 0, acc) = acc) measured SLOWER: 11.1 vs 7.9 ms on the 10-year tile
-            sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
-                constexpr int N = decltype(n_)::value;
-                if (N < rem) {
-                    const float x = *reinterpret_cast<const float *>(tab + dt_addr<N>(sv, lane4));
-                    dt_fmac<N>(acc, zv, (double)x);
-                }
-            });
-        }
-        zv = zn; sv = sn;
+    const double *zp[TWX_DT_CPW];
+    double zv[TWX_DT_CPW], zn[TWX_DT_CPW];
+#pragma unroll
+    for (int i = 0; i < TWX_DT_CPW; ++i) {
+        acc[i] = 0.0;
+        zp[i] = lc[i] >= 0 ? v.zd + (lc[i] * 12 + m0) * TWX_UROWS + l16 : nullptr;
+        zv[i] = zp[i] ? zp[i][0] : 0.0;
     }
-    return acc + v.zc[lc * 12 + m0];
+    for (int u0 = 0; u0 < nu; u0 += 16) {
+#pragma unroll
+        for (int i = 0; i < TWX_DT_CPW; ++i) zn[i] = (zp[i] && u0 + 16 < nu) ? zp[i][u0 + 16] : 0.0;   // next chunk, in flight during this one
+        const char *row = tab + (uint32_t)u0 * 256u + lane4;
+        sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
+            constexpr int N = decltype(n_)::value;
+            const double x = (double)*reinterpret_cast<const float *>(row + 256 * N);
+#pragma unroll
+            for (int i = 0; i < TWX_DT_CPW; ++i) dt_fmac<N>(acc[i], zv[i], x);
+        });
+#pragma unroll
+        for (int i = 0; i < TWX_DT_CPW; ++i) zv[i] = zn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TWX_DT_CPW; ++i) acc[i] += lc[i] >= 0 ? v.zc[lc[i] * 12 + m0] : 0.0;
 }
 
 #define TWX_DT_RPW ((TWX_UROWS + TWX_DT_WAVES - 1) / TWX_DT_WAVES)   // table rows staged per wave
@@ -486,9 +481,15 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
     __shared__ int16_t s_v[2][64][66];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tl = blockIdx.x;                      // local tile (same tiling for both variables)
-    const int m0 = blockIdx.y / a.nblk_max;
-    const int blk = blockIdx.y % a.nblk_max;
+    // Work-groups are dealt round-robin to the 8 XCDs (one L2 each): all 64-day blocks of a (tile, month) go to ONE
+    // XCD, back to back, so that the tile-month's hat rows (133 KB for both variables) come from HBM once and from
+    // that L2 for the other blocks, and consecutive blocks read consecutive 256-byte pieces of the observation rows.
+    const int64_t seq = blockIdx.x >> 3;
+    const int64_t tm = (seq / a.nblk_max) * 8 + (blockIdx.x & 7);
+    if (tm >= a.ntile * 12) return;
+    const int64_t tl = tm / 12;                         // local tile (same tiling for both variables)
+    const int m0 = (int)(tm % 12);
+    const int blk = (int)(seq % a.nblk_max);
     const int dm0 = a.moff[m0] + blk * 64, dm1 = a.moff[m0 + 1];
     if (dm0 >= dm1) return;
     const int nun = a.n.nurow[tl * 12 + m0], nux = a.x.nurow[tl * 12 + m0];
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
 #pragma unroll
         for (int j = 0; j < TWX_DT_RPW; ++j) {
             const int u = wv + TWX_DT_WAVES * j;
-            if (u < nu) s_tab[u * 64 + lane] = pre[j];
+            if (u < ((nu + 15) & ~15)) s_tab[u * 64 + lane] = pre[j];   // (rows up to the next multiple of 16: zeros)
         }
     };
 
@@ -525,26 +526,24 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
     fetch(a.n, nun);
     store(nun);
     __syncthreads();
-    double vn[TWX_DT_CPW];
+    int64_t lcs[TWX_DT_CPW];
 #pragma unroll
-    for (int i = 0; i < TWX_DT_CPW; ++i) {
-        const int64_t lc = dt_cell(a, r0, q0, wv * TWX_DT_CPW + i);
-        vn[i] = lc >= 0 ? dt_value(a.n, lc, m0, tab, lane4, lane) : 0.0;
-    }
+    for (int i = 0; i < TWX_DT_CPW; ++i) lcs[i] = dt_cell(a, r0, q0, wv * TWX_DT_CPW + i);
+    double vn[TWX_DT_CPW], vxs[TWX_DT_CPW];
+    fetch(a.x, nux);     // the Tmax rows travel while the Tmin sums run (the sums' hat-row loads are prefetched a chunk ahead,
+                         // so only their first wait sits behind these loads on the in-order counter: 42.6 -> 41.4 ms per C4 tile)
+    dt_value4(a.n, lcs, m0, tab, lane4, lane, nun, vn);
     __syncthreads();
     // ---- Tmax: re-stage the table, walk the cells, flag, pack
-    fetch(a.x, nux);
     store(nux);
     __syncthreads();
+    dt_value4(a.x, lcs, m0, tab, lane4, lane, nux, vxs);
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         const int cl = wv * TWX_DT_CPW + i;
-        const int64_t lc = dt_cell(a, r0, q0, cl);
-        double vx = 0.0;
-        if (lc >= 0) {
-            vx = dt_value(a.x, lc, m0, tab, lane4, lane);
-            if (day_ok && vn[i] >= vx) a.flag[lc] = 1;
-        }
+        const int64_t lc = lcs[i];
+        const double vx = vxs[i];
+        if (lc >= 0 && day_ok && vn[i] >= vx) a.flag[lc] = 1;
         const bool okd = lc >= 0 && day_ok;
         s_v[0][lane][cl] = okd ? pack_i16(vn[i]) : TWX_FILL_I2;
         s_v[1][lane][cl] = okd ? pack_i16(vx) : TWX_FILL_I2;

@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, soff, urow,
-        nurow;
+        nurow, zd;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
@@ -59,7 +59,7 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
-                          &near_pos, &soff, &urow, &nurow})
+                          &near_pos, &soff, &urow, &nurow, &zd})
             b->release();
     }
 };
@@ -179,6 +179,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_union)
     if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
         HIPCHK(w.soff.ensure((size_t)ncell * 12 * TWX_KZ * 4));
+        HIPCHK(w.zd.ensure((size_t)ncell * 12 * TWX_UROWS * 8));
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
     }
@@ -207,6 +208,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     w.gw.noff = w.noff.as<uint32_t>();
     s.near_pos = grid ? w.near_pos.as<uint16_t>() : nullptr;
     w.gw.soff = tile_tab ? w.soff.as<uint32_t>() : nullptr;
+    w.gw.zd = tile_tab ? w.zd.as<double>() : nullptr;
     w.gw.urow = tile_tab ? w.urow.as<int32_t>() : nullptr;
     w.gw.nurow = tile_tab ? w.nurow.as<int32_t>() : nullptr;
     return 0;
@@ -1081,15 +1083,15 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                     for (int v = 0; v < 2; ++v) {
                         DtVar &dv = v == 0 ? da.n : da.x;
                         const Work &wk = ctx->work[v];
-                        dv.obs = ctx->var[v].dev.obs; dv.ka = wk.ws.ka; dv.z = wk.gw.z; dv.zc = wk.gw.zc; dv.soff = wk.gw.soff;
+                        dv.obs = ctx->var[v].dev.obs; dv.ka = wk.ws.ka; dv.z = wk.gw.z; dv.zc = wk.gw.zc; dv.soff = wk.gw.soff; dv.zd = wk.gw.zd;
                         dv.urow = wk.gw.urow; dv.nurow = wk.gw.nurow;
                     }
                     da.okc = d_okc; da.mm2chron = ctx->da.mm2chron; da.out_n = o->daily_tmin; da.out_x = o->daily_tmax;
-                    da.flag = d_flag; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0;
+                    da.flag = d_flag; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0; da.ntile = ntile;
                     da.Y = Y; da.X = X; da.ts = ts; da.ntx = ntx; da.ndays = (int)ctx->ndays; da.nblk_max = nblk; da.gather = gather;
                     for (int m = 0; m < 13; ++m) da.moff[m] = ctx->da.moff[m];
                     if (!gather)
-                        hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
+                        hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)((ntile * 12 + 7) / 8 * 8 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
                     hipLaunchKernelGGL(k_daily_tile_gather, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(256), 0, stream,
                                        ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw,
                                        ctx->work[1].gw, ctx->da, *o, d_flag, d_okc, nblk, addr64, gather);
