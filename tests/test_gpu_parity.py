@@ -367,3 +367,37 @@ def test_krig_against_40_digit_arbiter(env, orc):
         am, av = arbiter.uk(c["lon"][idx], c["lat"][idx], c["elev"][idx], c["lst"][m - 1, idx], c["norm"][m - 1, idx], pt, *vario)
         worst = max(worst, abs(mean[0] - am), abs(var[0] - av))
     assert worst < 1e-5, worst
+
+
+def test_grid_tile_table_equals_point_path(env, golden_case, orc):
+    """Grid mode gathers the pair-distance cache per tile from an LDS table of the tile's station pairs (k_tile_dist),
+    point mode evaluates it per cell (k_cell_dist): same normals and SE, bit for bit in fp64 terms -- the f4 grid outputs
+    are the rounded point outputs -- also where two stations coincide (systems flagged singular by rank, not by pivot)."""
+    from topowx_amd import _lib, stationdb as sdb
+    ctx, grid = env["ctx"], env["grid"]
+    rs, cs = slice(21, 39), slice(58, 77)                         # straddles tile edges
+    got = ctx.interp_grid(grid, variables=("tmin",), daily=False, rows=rs, cols=cs)
+    cells = np.array([(r, c) for r in range(rs.start, rs.stop) for c in range(cs.start, cs.stop)])
+    _, norms, se, st = ctx.interp_points(_lib.TMIN, _pts(ctx, grid, cells, "tmin"), daily=False)
+    assert np.all(st == 0) and np.all(got["status"] == 0)
+    shp = (rs.stop - rs.start, cs.stop - cs.start)
+    assert np.array_equal(got["norm_tmin"], norms.T.reshape(12, *shp).astype(np.float32))
+    assert np.array_equal(got["se_tmin"], se.T.reshape(12, *shp).astype(np.float32))
+    # a duplicated station location near the window: both paths fail exactly the same cells
+    grid0, tmin, _ = golden_case
+    dup = sdb.StationDataWrkChk(tmin.stns.copy(), "tmin", tmin.days, tmin.var)
+    lo, la = grid["lon"][cs.start + 9], grid["lat"][rs.start + 9]
+    j = np.argmin((dup.stns[sdb.LON] - lo) ** 2 + (dup.stns[sdb.LAT] - la) ** 2)
+    i = np.argsort((dup.stns[sdb.LON] - lo) ** 2 + (dup.stns[sdb.LAT] - la) ** 2)[40]
+    dup.stns[sdb.LON][i], dup.stns[sdb.LAT][i] = dup.stns[sdb.LON][j], dup.stns[sdb.LAT][j]
+    c2 = _lib.Context()
+    c2.set_stations(_lib.TMIN, dup, with_obs=False)
+    g2 = c2.interp_grid(grid, variables=("tmin",), daily=False, rows=rs, cols=cs)
+    _, n2, _, s2 = c2.interp_points(_lib.TMIN, _pts(c2, grid, cells, "tmin"), daily=False)
+    c2.close()
+    assert np.array_equal(g2["status"].ravel(), s2) and (s2 == 4).any()
+    # ... and the oracle fails the same cells (coincident stations share the full sill: singular, as gstat reports)
+    want = orc.interp_grid(orc.Db(dup), None, env["prm"], grid, daily=False, nthreads=8, rows=rs, cols=cs)
+    assert np.array_equal(g2["status"], want["status"])
+    ok = s2 == 0
+    assert np.array_equal(g2["norm_tmin"].reshape(12, -1)[:, ok], n2[ok].T.astype(np.float32))

@@ -104,6 +104,9 @@ __device__ __attribute__((noinline)) float ellip_pair_far(double Sd, double cc, 
 __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double sl1, double cl1, double cph1,
                                                  double sp2, double cp2, double sl2, double cl2, double cph2)
 {
+    // same location: exactly 0, as sp / gstat and the oracle return (the products below leave a rounding residue of
+    // ~1e-13 km, which would hide a coincident pair -- full sill, singular system -- behind a plain psill entry)
+    if (sp1 == sp2 && cp1 == cp2 && sl1 == sl2 && cl1 == cl2) return 0.f;
     const double sG = fma(sp1, cp2, -(cp1 * sp2));
     const double sL = fma(sl1, cl2, -(cl1 * sl2));
     const double cc = cph1 * cph2;
