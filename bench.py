@@ -212,7 +212,7 @@ def main():
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_MONTH * solves / launches,
-                     "kernel": "universal kriging: k_cell_dist + k_ukw<..> + k_uk<..> (%d launches per step)" % launches,
+                     "kernel": "universal kriging: k_tile_dist + k_ukw<..> + k_uk<..> (%d launches per step)" % launches,
                      "kernel_ms_per_step": uk_ms,
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},
         "fp64": {"achieved": ach_tflops, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",

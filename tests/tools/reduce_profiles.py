@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KRIG = ("k_uk<", "k_ukw<", "k_cell_dist")          # the kernels behind bench.py's uk_ms
+KRIG = ("k_uk<", "k_ukw<", "k_cell_dist", "k_tile_dist")   # the kernels behind bench.py's uk_ms
 DAILY = ("k_daily_tile", "k_tile_union", "k_row_offsets", "k_daily_ok", "k_daily_grid")   # ... daily_ms
 DAILY_ONLY = DAILY + ("k_gwr_z", "k_fix_cells", "k_compact_flags")
 
@@ -45,7 +45,7 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
             fh.write('"%s",%d,%.1f\n' % (k, n, v))
     n, kb = group(per, KRIG)
     res[key] = {"k_uk_launches": n, "k_uk_total_KB": kb, "k_uk_per_launch_bytes": kb * 1024.0 / max(n, 1),
-                "kernels": "k_cell_dist + k_ukw<..> + k_uk<..> (headline workload only)"}
+                "kernels": "k_tile_dist + k_ukw<..> + k_uk<..> (headline workload only)"}
     dper = pmc(dsub, pre, key)
     if dper:
         with open(os.path.join(out, "pmc_daily_%s.csv" % key), "w") as fh:

@@ -481,15 +481,18 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
     __shared__ int16_t s_v[2][64][66];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Work-groups are dealt round-robin to the 8 XCDs (one L2 each): all 64-day blocks of a (tile, month) go to ONE
-    // XCD, back to back, so that the tile-month's hat rows (133 KB for both variables) come from HBM once and from
-    // that L2 for the other blocks, and consecutive blocks read consecutive 256-byte pieces of the observation rows.
+    // Work-groups are dealt round-robin to the 8 XCDs (one L2 each).  A unit = 8 consecutive tiles (neighbours in x) x
+    // one month goes to ONE XCD, walked block by block with the 8 tiles side by side: the tiles' 16-byte output runs
+    // of a day meet in that L2 and leave as whole 128-byte lines (measured write amplification of the int16 output
+    // 2.1 x when neighbouring tiles ran on different XCDs), and a tile-month's hat rows (133 KB for both variables)
+    // come from HBM once and from the L2 for its other blocks.
     const int64_t seq = blockIdx.x >> 3;
-    const int64_t tm = (seq / a.nblk_max) * 8 + (blockIdx.x & 7);
-    if (tm >= a.ntile * 12) return;
-    const int64_t tl = tm / 12;                         // local tile (same tiling for both variables)
-    const int m0 = (int)(tm % 12);
-    const int blk = (int)(seq % a.nblk_max);
+    const int64_t unit = (seq / (8 * a.nblk_max)) * 8 + (blockIdx.x & 7);
+    const int rem = (int)(seq % (8 * a.nblk_max));
+    const int64_t tl = (unit / 12) * 8 + (rem & 7);     // local tile (same tiling for both variables)
+    if (tl >= a.ntile) return;
+    const int m0 = (int)(unit % 12);
+    const int blk = rem >> 3;
     const int dm0 = a.moff[m0] + blk * 64, dm1 = a.moff[m0 + 1];
     if (dm0 >= dm1) return;
     const int nun = a.n.nurow[tl * 12 + m0], nux = a.x.nurow[tl * 12 + m0];

@@ -1091,7 +1091,8 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                     da.Y = Y; da.X = X; da.ts = ts; da.ntx = ntx; da.ndays = (int)ctx->ndays; da.nblk_max = nblk; da.gather = gather;
                     for (int m = 0; m < 13; ++m) da.moff[m] = ctx->da.moff[m];
                     if (!gather)
-                        hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)((ntile * 12 + 7) / 8 * 8 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
+                        // units of (8 tiles, month), rounded up to a multiple of the 8 XCDs, x 8 tiles x nblk blocks each
+                        hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)((((ntile + 7) / 8) * 12 + 7) / 8 * 8 * 8 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
                     hipLaunchKernelGGL(k_daily_tile_gather, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(256), 0, stream,
                                        ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw,
                                        ctx->work[1].gw, ctx->da, *o, d_flag, d_okc, nblk, addr64, gather);
