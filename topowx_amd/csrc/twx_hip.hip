@@ -221,7 +221,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
 // work-groups per step = +1.2 ms = +9 % kriging time, which is why it is not the default).
 inline unsigned krig_grid(const int32_t *cnt, int bucket, int64_t max_items)
 {
-    return (unsigned)std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items);
+    // (a multiple of 8: the kernels deal the item list to the 8 XCDs in contiguous eighths, uk_item())
+    return (unsigned)((std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items) + 7) / 8 * 8);
 }
 
 template <int NB>
