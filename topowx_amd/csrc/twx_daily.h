@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
                                                const double *pt_norm_in)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wv;
+    const int wgi = xcd_contig(blockIdx.x, (int)((ws.ncell * 12 + 3) / 4));
+    if (wgi < 0) return;
+    const int64_t item = (int64_t)wgi * 4 + wv;
     if (item >= ws.ncell * 12) return;
     const int64_t lc = item / 12;
     const int m0 = (int)(item % 12);

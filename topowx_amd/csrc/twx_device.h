@@ -139,6 +139,21 @@ __device__ __forceinline__ double ellip_pair(double sp1, double cp1, double sl1,
     return ellip_core(sG * sG, cG * cG, sF * sF, cF * cF, sL * sL, cL * cL);
 }
 
+// Work-group -> position in a list of n units of work.  Work-groups are dealt round-robin to the 8 XCDs (one L2
+// each); with this map every XCD takes a contiguous eighth of the list, in order, so that neighbouring units (the
+// months of a cell, the cells of a tile row) meet in one L2.  The launch needs a multiple of 8 work-groups >= n;
+// -1 = nothing to do.
+__device__ __forceinline__ int xcd_contig(unsigned wg, int n)
+{
+#ifdef TWX_NO_XCD_ORDER
+    return (int)wg < n ? (int)wg : -1;
+#else
+    const int per = (n + 7) >> 3;
+    const int it = (int)(wg & 7u) * per + (int)(wg >> 3);
+    return ((int)(wg >> 3) < per && it < n) ? it : -1;
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

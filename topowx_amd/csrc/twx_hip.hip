@@ -280,10 +280,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     }
     {
         EvScope ev(ctx, stream, EV_SELECT);
-        hipLaunchKernelGGL((k_select<4>), dim3((unsigned)((ncell + 3) / 4)), dim3(256), (size_t)4 * TWX_CAND_SMALL * (sizeof(double) + 2),
+        hipLaunchKernelGGL((k_select<4>), dim3((unsigned)(((ncell + 3) / 4 + 7) / 8 * 8)), dim3(256), (size_t)4 * TWX_CAND_SMALL * (sizeof(double) + 2),
                            stream, st, src, w.ws, 0, TWX_CAND_SMALL);
         if (w.cmax > TWX_CAND_SMALL)      // cells of tiles with long candidate lists (dense station clusters)
-            hipLaunchKernelGGL((k_select<1>), dim3((unsigned)ncell), dim3(64), (size_t)w.cmax * (sizeof(double) + 2), stream, st, src,
+            hipLaunchKernelGGL((k_select<1>), dim3((unsigned)((ncell + 7) / 8 * 8)), dim3(64), (size_t)w.cmax * (sizeof(double) + 2), stream, st, src,
                                w.ws, TWX_CAND_SMALL, w.cmax);
     }
     if (!src.do_krig) return 0;
@@ -340,7 +340,7 @@ int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, 
     HIPCHK(hipMemsetAsync(w.gstat.p, 0, (size_t)w.ws.ncell * 4, stream));
     EvScope ev(ctx, stream, EV_GWR);
     int64_t items = w.ws.ncell * 12;
-    hipLaunchKernelGGL(k_gwr_z, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, ctx->var[v].dev, src, w.ws,
+    hipLaunchKernelGGL(k_gwr_z, dim3((unsigned)(((items + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, stream, ctx->var[v].dev, src, w.ws,
                        w.gw, pt_norm_dev);
     return 0;
 }

@@ -231,7 +231,9 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     __shared__ int s_ni[WPB][TWX_KSEL_MAX];
     __shared__ int s_np[WPB][TWX_KSEL_MAX];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t lc = (int64_t)blockIdx.x * WPB + wv;      // local cell
+    const int wgi = xcd_contig(blockIdx.x, (int)((ws.ncell + WPB - 1) / WPB));   // row-major cells: a tile's rows meet in one L2
+    if (wgi < 0) return;
+    const int64_t lc = (int64_t)wgi * WPB + wv;             // local cell
     bool in_range = lc < ws.ncell;
     const int64_t c = ws.cell0 + (in_range ? lc : 0);       // global cell id
     bool valid = in_range && cell_valid(src, c);

@@ -65,20 +65,6 @@ __device__ __forceinline__ double readlane_d(double v, int lane /*wave-uniform*/
 // acc += bcast(p, lane N of this lane's 16-lane row) * u in ONE instruction: v_fmac_f64 with a DPP
 // row_newbcast source (gfx90a+; full fp64 rate on gfx950: tests/tools/micro/fmac_dpp.hip).  The column
 // operand of the rank-4 update is common to the 16 lanes of a row, so it never has to be re-read from LDS.
-// Work-group -> position in the bucket's item list.  Work-groups are dealt round-robin to the 8 XCDs (one L2 each);
-// every XCD takes a contiguous eighth of the list, in order.  The list keeps the months of a cell next to each other
-// (k_bucket_items), so the systems that share a cell's pair-distance cache, neighbour list and predictors meet in one L2.
-__device__ __forceinline__ int uk_item(unsigned wg, int n)
-{
-#ifdef TWX_UK_NO_XCD_ORDER
-    return (int)wg < n ? (int)wg : -1;
-#else
-    const int per = (n + 7) >> 3;
-    const int it = (int)(wg & 7u) * per + (int)(wg >> 3);
-    return ((int)(wg >> 3) < per && it < n) ? it : -1;
-#endif
-}
-
 template <int N>
 __device__ __forceinline__ void fmac_rowbcast(double &acc, double p, double u)
 {
@@ -412,7 +398,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     // The item count of this matrix-size bucket lives in device memory (k_bucket_items): the host never reads it.
     // The launch covers the worst case (every system of the batch in this bucket); surplus work-groups leave at
     // once.  (A fixed grid striding over the list keeps ~100 kernel-argument SGPRs live across the loop and spills.)
-    const int it = uk_item(blockIdx.x, *nitems_dev);
+    const int it = xcd_contig(blockIdx.x, *nitems_dev);   // the months of a cell sit next to each other in the list (k_bucket_items): one L2
     if (it < 0) return;
     const int rot = (int)(((unsigned)it * 2654435761u) >> 13) & (NW - 1);
     const int wvp = (wv + rot) & (NW - 1);       // column group of this wave

@@ -43,7 +43,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
     // worst-case grid, device-side item count (see k_uk)
-    const int it = uk_item(blockIdx.x, *nitems_dev);
+    const int it = xcd_contig(blockIdx.x, *nitems_dev);
     if (it < 0) return;
     const int item = item_list[it];
     const int64_t lc = item / 12;
