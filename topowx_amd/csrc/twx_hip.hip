@@ -276,7 +276,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
     {
         EvScope ev(ctx, stream, EV_TILE);
-        hipLaunchKernelGGL(k_tile_cand, dim3(nblk), dim3(256), 0, stream, st, src, w.ws);
+        // grid mode has few tiles per batch (512 ... 2 048: at most a few work-groups per CU): 16 waves each; point mode one
+        // "tile" per point and many of them: 4 waves each
+        hipLaunchKernelGGL(k_tile_cand, dim3(nblk), dim3(src.mode == 0 ? 1024 : 256), st.n <= TWX_TC_LDS_STNS ? (size_t)st.n * 4 : 0, stream,
+                           st, src, w.ws);
     }
     {
         EvScope ev(ctx, stream, EV_SELECT);

@@ -16,6 +16,8 @@
 #define TWX_DIST_BLOCKS (TWX_DIST_NB * (TWX_DIST_NB + 1) / 2)
 
 // Workspace of one (batch, variable)
+#define TWX_TC_LDS_STNS 16384  // k_tile_cand keeps its distance row in LDS up to this many stations (64 KB)
+
 struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
     int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_RANGE)
@@ -60,13 +62,16 @@ struct SelWs {
 // centre to every station (a1), bisection for a radius T holding >= KSEL stations,
 // candidates = stations within T + 2 * (centre -> farthest cell) (+ margin).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs ws)
+__global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelWs ws)
 {
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[16];                                // per wave (work-groups of 4 ... 16 waves)
     __shared__ int s_any;
     __shared__ int s_base;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    float *dsc = ws.dscratch + (int64_t)blockIdx.x * st.n;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nth = blockDim.x, nwv = nth >> 6;
+    // tile-centre -> station distances of the current tile: in LDS when the station table fits (the bisection reads
+    // them ~20 times), else in a global scratch row of this work-group
+    extern __shared__ float s_dsc[];
+    float *dsc = st.n <= TWX_TC_LDS_STNS ? s_dsc : ws.dscratch + (int64_t)blockIdx.x * st.n;
 
     for (int64_t tl = blockIdx.x; tl < ws.ntile; tl += gridDim.x) {
         const int64_t tile = ws.tile0 + tl;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
             __syncthreads();
             int mine = 0;
             int nr = r1 - r0 + 1, nq = q1 - q0 + 1;
-            for (int i = t; i < nr * nq; i += 256)
+            for (int i = t; i < nr * nq; i += nth)
                 mine |= src.mask[(int64_t)(r0 + i / nq) * src.X + (q0 + i % nq)] != 0;
             if (mine) s_any = 1;
             __syncthreads();
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
         // distances (float is enough for a conservative bound; margin below)
         float dmax = 0.f;
         int nvalid = 0;
-        for (int j = t; j < st.n; j += 256) {
+        for (int j = t; j < st.n; j += nth) {
             double d = hav_km(clon, clat, st.lon[j], st.lat[j]);
             float f = (float)d;
             if (j == excl || (src.rm_zero && d == 0.0)) f = -1.f; // dropped (point mode)
@@ -112,11 +117,11 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
         }
         dmax = (float)wave_max((double)dmax);
         nvalid = wave_sum_i(nvalid);
-        __shared__ float s_dmax[4];
+        __shared__ float s_dmax[16];
         if (lane == 0) { s_dmax[wv] = dmax; s_cnt[wv] = nvalid; }
         __syncthreads();
-        dmax = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
-        nvalid = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        dmax = 0.f; nvalid = 0;
+        for (int w = 0; w < nwv; ++w) { dmax = fmaxf(dmax, s_dmax[w]); nvalid += s_cnt[w]; }
         __syncthreads();
         float T;
         if (nvalid <= ws.ksel) {
@@ -125,14 +130,19 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
             float lo = 0.f, hi = dmax;
             for (int it = 0; it < 24; ++it) {
                 float mid = 0.5f * (lo + hi);
-                int c = 0;
-                for (int j = t; j < st.n; j += 256) { float f = dsc[j]; c += (f >= 0.f && f <= mid); }
-                c = wave_sum_i(c);
+                int c = 0;                                   // per wave, scalar: ballot + population count
+                for (int j0 = 0; j0 < st.n; j0 += nth) {
+                    const int j = j0 + t;
+                    const float f = j < st.n ? dsc[j] : -1.f;
+                    c += __popcll(__ballot(f >= 0.f && f <= mid));
+                }
                 if (lane == 0) s_cnt[wv] = c;
                 __syncthreads();
-                c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                c = 0;
+                for (int w = 0; w < nwv; ++w) c += s_cnt[w];
                 __syncthreads();
                 if (c >= ws.ksel) hi = mid; else lo = mid;
+                if (c >= ws.ksel && c <= ws.ksel + 8) break;     // (uniform) tight enough: any radius holding >= ksel stations is valid
             }
             T = hi;
         }
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
         // ordered compaction
         if (t == 0) s_base = 0;
         __syncthreads();
-        for (int j0 = 0; j0 < st.n; j0 += 256) {
+        for (int j0 = 0; j0 < st.n; j0 += nth) {
             int j = j0 + t;
             bool f = false;
             if (j < st.n) { float d = dsc[j]; f = (d >= 0.f && d <= R); }
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void k_tile_cand(StnDev st, CellSrc src, SelWs
             for (int w = 0; w < wv; ++w) off += s_cnt[w];
             if (f && off + pre < ws.cmax) ws.cand[tl * ws.cmax + off + pre] = j;
             __syncthreads();
-            if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (t == 0) { int a = 0; for (int w = 0; w < nwv; ++w) a += s_cnt[w]; s_base += a; }
             __syncthreads();
         }
         if (t == 0) {
