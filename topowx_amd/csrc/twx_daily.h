@@ -81,14 +81,14 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
     bool bad = false;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-        double s = wave_max(mx[q]);
+        double s = wave_max_dpp(mx[q]);       // (32 wave reductions per item: DPP row shifts, not the LDS crossbar)
         s = s > 0.0 ? 1.0 / s : 1.0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) row[u][1 + q] *= s;
         // a predictor that is exactly zero at every neighbour (e.g. TDI on flat terrain) gives X'WX an exactly
         // zero row: np.linalg.inv raises (interp_tair.py:1139) -- with the columns shifted to the cell that case
         // would otherwise only be collinear, which rounding can hide from the Cholesky pivots below
-        if (wave_max(rawmx[q]) == 0.0) bad = true;
+        if (wave_max_dpp(rawmx[q]) == 0.0) bad = true;
     }
     // M = X'WX (lower triangle, 21 sums)
     double M[6][6];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             double s = 0.0;
 #pragma unroll
             for (int u = 0; u < 3; ++u) s += w[u] * row[u][a] * row[u][b];
-            M[a][b] = wave_sum(s);
+            M[a][b] = wave_sum_dpp(s);
         }
     }
     // Cholesky with one reciprocal per pivot (33 fp64 divisions -> 6: the kernel is VALU bound and a division is
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             if (!finite_d(z)) bad = true;
         }
     }
-    zn = wave_sum(zn);
+    zn = wave_sum_dpp(zn);
     bad = __any(bad);
     if (lane == 0) {
         double pn = pt_norm_in ? pt_norm_in[c] : ws.uk_mean[lc * 12 + m0];

@@ -184,6 +184,28 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     return __hiloint2double(hi, lo);
 }
 
+// wave-wide maximum of NON-NEGATIVE values the same way (lanes without a source contribute +0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return fmax(v, __hiloint2double(hi, lo));
+}
+
+__device__ __forceinline__ double wave_max_dpp(double v)
+{
+    v = dpp_max_step<0x111, 0xf>(v);
+    v = dpp_max_step<0x112, 0xf>(v);
+    v = dpp_max_step<0x114, 0xf>(v);
+    v = dpp_max_step<0x118, 0xf>(v);
+    v = dpp_max_step<0x142, 0xa>(v);
+    v = dpp_max_step<0x143, 0xc>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll

@@ -458,7 +458,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
         }
     }
-    e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
+    e0 = wave_max_dpp(e0); e1 = wave_max_dpp(e1); e2 = wave_max_dpp(e2); e3 = wave_max_dpp(e3);   // (non-negative: DPP row shifts, no LDS crossbar)
     if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
     if (t == 0) s_err = 0;
     for (int q = t; q < 2 * NP * PS; q += NTH) (&s_pan[0][0])[q] = 0.0;   // finished rows are never written: keep them finite

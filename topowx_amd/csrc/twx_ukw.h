@@ -98,7 +98,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
         }
     }
-    e0 = wave_max(e0); e1 = wave_max(e1); e2 = wave_max(e2); e3 = wave_max(e3);
+    e0 = wave_max_dpp(e0); e1 = wave_max_dpp(e1); e2 = wave_max_dpp(e2); e3 = wave_max_dpp(e3);   // (non-negative: DPP row shifts, no LDS crossbar)
     const double sc0 = e0 > 0.0 ? 1.0 / e0 : 1.0, sc1 = e1 > 0.0 ? 1.0 / e1 : 1.0;
     const double sc2 = e2 > 0.0 ? 1.0 / e2 : 1.0, sc3 = e3 > 0.0 ? 1.0 / e3 : 1.0;
 #pragma unroll
