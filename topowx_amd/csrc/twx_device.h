@@ -154,15 +154,8 @@ __device__ __forceinline__ int xcd_contig(unsigned wg, int n)
 #endif
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Wave-wide sum through DPP row shifts / row broadcasts (no LDS crossbar traffic: a __shfl_xor butterfly costs two
-// ds_bpermute per step and double).  All lanes return the total.
+// Wave-wide sum / maximum through DPP row shifts and row broadcasts (no LDS crossbar traffic: a __shfl_xor butterfly
+// costs two ds_bpermute per step and double).  All lanes return the result.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_step(double v)
 {
@@ -171,7 +164,23 @@ __device__ __forceinline__ double dpp_add_step(double v)
     return v + __hiloint2double(hi, lo);       // lanes without a source (or in a masked row) add +0
 }
 
-__device__ __forceinline__ double wave_sum_dpp(double v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v)
+{
+    const int l = __double2loint(v), h = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep their own value
+    const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi, lo));
+}
+
+__device__ __forceinline__ double readlane63(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
 {
     v = dpp_add_step<0x111, 0xf>(v);           // row_shr:1
     v = dpp_add_step<0x112, 0xf>(v);           // row_shr:2
@@ -179,21 +188,10 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     v = dpp_add_step<0x118, 0xf>(v);           // row_shr:8   -> lane 15 of every row holds the row's sum
     v = dpp_add_step<0x142, 0xa>(v);           // row_bcast:15 into rows 1 and 3
     v = dpp_add_step<0x143, 0xc>(v);           // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
+    return readlane63(v);
 }
 
-// wave-wide maximum of NON-NEGATIVE values the same way (lanes without a source contribute +0)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_max_step(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-    return fmax(v, __hiloint2double(hi, lo));
-}
-
-__device__ __forceinline__ double wave_max_dpp(double v)
+__device__ __forceinline__ double wave_max(double v)
 {
     v = dpp_max_step<0x111, 0xf>(v);
     v = dpp_max_step<0x112, 0xf>(v);
@@ -201,17 +199,11 @@ __device__ __forceinline__ double wave_max_dpp(double v)
     v = dpp_max_step<0x118, 0xf>(v);
     v = dpp_max_step<0x142, 0xa>(v);
     v = dpp_max_step<0x143, 0xc>(v);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
+    return readlane63(v);
 }
 
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ double wave_sum_dpp(double v) { return wave_sum(v); }
+__device__ __forceinline__ double wave_max_dpp(double v) { return wave_max(v); }
 
 __device__ __forceinline__ float wave_max_f(float v)
 {
