@@ -39,6 +39,9 @@ struct CellSrc {
     const int32_t *mth;  // per point month 1..12 (0 / null = all twelve)
     const int32_t *nnghs_in;   // per point explicit bandwidth (<= 0 smooth) or null
     const double *vario_in;    // per point [3] explicit variogram (NaN nugget = smooth) or null
+    // point mode: runs of consecutive points at one location with one excluded station (a cross-validated station x its
+    // bandwidths x months) share ONE candidate list: ptile = list ("tile") of a point, ptfirst = first point of a list
+    const int32_t *ptile, *ptfirst;
     int rm_zero;
     int do_krig;         // derive kriging bandwidth + variogram (a3, a4)
     int do_vario;        // smooth the variogram from the neighbours' (0: it is fitted afterwards, 8f-1)
@@ -74,7 +77,7 @@ __device__ __forceinline__ double cell_lst(const CellSrc &s, int64_t c, int m0)
 
 __device__ __forceinline__ int64_t cell_tile(const CellSrc &s, int64_t c)
 {
-    if (s.mode == 1) return c;
+    if (s.mode == 1) return s.ptile ? s.ptile[c] : c;
     int r = (int)(c / s.X), q = (int)(c % s.X);
     return (int64_t)(r / s.ts) * s.ntx + (q / s.ts);
 }

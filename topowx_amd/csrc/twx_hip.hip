@@ -547,8 +547,9 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
 namespace {
 struct PtDev {
     twx_pt *pts = nullptr;
-    int32_t *mth = nullptr, *nnghs = nullptr, *excl = nullptr;
+    int32_t *mth = nullptr, *nnghs = nullptr, *excl = nullptr, *ptile = nullptr, *ptfirst = nullptr;
     double *vario = nullptr, *pt_norm = nullptr;
+    int64_t nlists = 0;       // candidate lists: runs of consecutive points with the same location and excluded station
 };
 
 int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *lon, const double *lat,
@@ -557,7 +558,7 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
 {
     ctx->ev_used = 0;   // point entries do not report kernel timing: recycle the event pool
     ctx->have_total = false;
-    size_t bytes = (size_t)npts * (sizeof(twx_pt) + 3 * 4 + 4 * 8) + 4096;
+    size_t bytes = (size_t)npts * (sizeof(twx_pt) + 5 * 4 + 4 * 8) + 8192;
     HIPCHK(ctx->pt_in.ensure(bytes));
     char *cur = ctx->pt_in.as<char>();
     pd.pts = carve<twx_pt>(cur, npts);
@@ -574,6 +575,18 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
     if (excl) { pd.excl = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.excl, excl, npts * 4, hipMemcpyHostToDevice)); }
     if (vario) { pd.vario = carve<double>(cur, npts * 3); HIPCHK(hipMemcpy(pd.vario, vario, npts * 24, hipMemcpyHostToDevice)); }
     if (pt_norm) { pd.pt_norm = carve<double>(cur, npts); HIPCHK(hipMemcpy(pd.pt_norm, pt_norm, npts * 8, hipMemcpyHostToDevice)); }
+    // one candidate list per run of points that share location and excluded station (cross-validation asks for a
+    // station x 16 bandwidths x 12 months: 192 points, one search through the station table instead of 192)
+    std::vector<int32_t> ptile(npts), ptfirst;
+    for (int64_t i = 0; i < npts; ++i) {
+        const bool same = i > 0 && pts[i].lon == pts[i - 1].lon && pts[i].lat == pts[i - 1].lat &&
+                          (excl ? excl[i] == excl[i - 1] : true);
+        if (!same) ptfirst.push_back((int32_t)i);
+        ptile[i] = (int32_t)ptfirst.size() - 1;
+    }
+    pd.nlists = (int64_t)ptfirst.size();
+    pd.ptile = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.ptile, ptile.data(), npts * 4, hipMemcpyHostToDevice));
+    pd.ptfirst = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.ptfirst, ptfirst.data(), ptfirst.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -581,6 +594,7 @@ CellSrc point_src(const PtDev &pd, int rm_zero, int do_krig, int do_anom)
 {
     CellSrc s{};
     s.mode = 1; s.pts = pd.pts; s.excl = pd.excl; s.mth = pd.mth; s.nnghs_in = pd.nnghs; s.vario_in = pd.vario;
+    s.ptile = pd.ptile; s.ptfirst = pd.ptfirst;
     s.rm_zero = rm_zero; s.do_krig = do_krig; s.do_anom = do_anom; s.do_vario = 1;
     return s;
 }
@@ -604,7 +618,7 @@ int twx_knn(twx_ctx *ctx, int var, int64_t npts, const double *lon, const double
     PtDev pd;
     if (upload_points(ctx, npts, nullptr, lon, lat, nullptr, nullptr, nullptr, excl, nullptr, pd)) return -1;
     CellSrc src = point_src(pd, rm_zero_dist, 0, 0);
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, k + 1, false, nullptr)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, k + 1, false, nullptr)) return -1;
     size_t ob = (size_t)npts * k * (4 + 8 + 8) + (size_t)npts * 4 + 4096;
     HIPCHK(ctx->pt_out.ensure(ob));
     char *cur = ctx->pt_out.as<char>();
@@ -635,7 +649,7 @@ int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, cons
     if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, vario, excl, nullptr, pd)) return -1;
     CellSrc src = point_src(pd, rm_zero_dist, 1, 0);
     const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, false, nullptr)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, ksel, false, nullptr)) return -1;
     const int ld = TWX_MAX_NNGHS;
     size_t ob = (size_t)npts * (8 + 8 + 4 + 4) + (size_t)npts * ld * 4 + 4096;
     HIPCHK(ctx->pt_out.ensure(ob));
@@ -676,7 +690,7 @@ int twx_fit_vario_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,
     CellSrc src = point_src(pd, rm_zero_dist, 1, 0);
     src.do_vario = 0;
     const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, false, nullptr, true)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, ksel, false, nullptr, true)) return -1;
     HIPCHK(hipDeviceSynchronize());
     Work &w = ctx->work[var];
     std::vector<int32_t> cs(npts), us(npts), kk((size_t)npts * 12);
@@ -713,7 +727,7 @@ int twx_gwr_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const
     if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, pt_norm, pd)) return -1;
     CellSrc src = point_src(pd, rm_zero_dist, 0, 1);
     const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, true, nullptr)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, ksel, true, nullptr)) return -1;
     if (run_gwr(ctx, var, src, pd.pt_norm, nullptr)) return -1;
     Work &w = ctx->work[var];
     HIPCHK(ctx->pt_out.ensure((size_t)npts * ld * 8 + 4096));
@@ -754,7 +768,7 @@ int twx_gwr_xval_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, 
     if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, pt_norm, pd)) return -1;
     CellSrc src = point_src(pd, rm_zero_dist, 0, 1);
     const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, ksel, true, nullptr)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, ksel, true, nullptr)) return -1;
     if (run_gwr(ctx, var, src, pd.pt_norm, nullptr)) return -1;
     Work &w = ctx->work[var];
     HIPCHK(ctx->pt_out.ensure((size_t)npts * (3 * 8 + 4) + 4096));
@@ -794,7 +808,7 @@ int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, co
     PtDev pd;
     if (upload_points(ctx, npts, pts, nullptr, nullptr, nullptr, nullptr, nullptr, excl, nullptr, pd)) return -1;
     CellSrc src = point_src(pd, rm_zero_dist, 1, daily ? 1 : 0);
-    if (run_select_uk(ctx, var, src, 0, npts, 0, npts, pick_ksel(ctx, var, 0), daily != nullptr, nullptr)) return -1;
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, pick_ksel(ctx, var, 0), daily != nullptr, nullptr)) return -1;
     Work &w = ctx->work[var];
     const int64_t nd = ctx->ndays;
     size_t ob = (size_t)npts * (96 * 2 + 4) + (daily ? (size_t)npts * nd * 8 : 0) + 4096;

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
         int excl = -1;
         int any = 1;
         if (src.mode == 1) {
-            clon = src.pts[tile].lon; clat = src.pts[tile].lat;
-            excl = src.excl ? src.excl[tile] : -1;
+            const int64_t p = src.ptfirst ? src.ptfirst[tile] : tile;     // the list's first point stands for all of them
+            clon = src.pts[p].lon; clat = src.pts[p].lat;
+            excl = src.excl ? src.excl[p] : -1;
         } else {
             int ty = (int)(tile / src.ntx), tx = (int)(tile % src.ntx);
             int r0 = ty * src.ts, r1 = min(r0 + src.ts, src.Y) - 1;
