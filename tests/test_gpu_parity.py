@@ -401,3 +401,23 @@ def test_grid_tile_table_equals_point_path(env, golden_case, orc):
     assert np.array_equal(g2["status"], want["status"])
     ok = s2 == 0
     assert np.array_equal(g2["norm_tmin"].reshape(12, -1)[:, ok], n2[ok].T.astype(np.float32))
+
+
+def test_point_runs_share_candidate_lists(env):
+    """Consecutive points at one location with one excluded station share a candidate list (one search of the station
+    table per run): the same requests in an order without runs give the same bits, point for point."""
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    rng = np.random.default_rng(3)
+    cells = np.column_stack([rng.integers(0, grid["lat"].size, 24), rng.integers(0, grid["lon"].size, 24)])
+    base = _pts(ctx, grid, cells, "tmin")
+    # station-major: 24 locations x (12 months x 3 bandwidths), excluded station varies inside a location for a third
+    pts = np.repeat(base, 36)
+    mth = np.tile(np.repeat(np.arange(1, 13), 3), 24)
+    nn = np.tile(np.array([35, 60, 0]), 24 * 12)
+    excl = np.where(np.arange(pts.size) % 3 == 2, 17, -1).astype(np.int32)
+    a = ctx.krig_points(lib.TMIN, pts, mth, nnghs=nn, excl=excl)
+    perm = rng.permutation(pts.size)                              # no two neighbours alike (almost surely)
+    b = ctx.krig_points(lib.TMIN, pts[perm], mth[perm], nnghs=nn[perm], excl=excl[perm])
+    assert np.all(a[3] == 0)
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x[perm], y, equal_nan=True)

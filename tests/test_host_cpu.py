@@ -77,3 +77,25 @@ def test_synth_is_deterministic():
     assert np.array_equal(g1["elev"], g2["elev"]) and a1.stns.tobytes() == a2.stns.tobytes()
     assert g1["lat"][0] > g1["lat"][-1]                      # north-up (step25:113-116)
     assert a1.stns.size == 500
+
+
+def test_xcd_contiguous_order_is_a_bijection():
+    """topowx_amd/csrc/twx_device.h::xcd_contig -- work-group -> list position such that each of the 8 XCDs (work-groups
+    are dealt round-robin) takes a contiguous eighth of the list: every position exactly once, -1 for the surplus
+    work-groups of a launch rounded up to a multiple of 8, and XCD x's positions form the range [x*per, (x+1)*per)."""
+    src = open(os.path.join(ROOT, "topowx_amd", "csrc", "twx_device.h")).read()
+    assert "const int per = (n + 7) >> 3;" in src and "(int)(wg & 7u) * per + (int)(wg >> 3)" in src   # the map restated below
+
+    def xcd_contig(wg, n):
+        per = (n + 7) >> 3
+        it = (wg & 7) * per + (wg >> 3)
+        return it if (wg >> 3) < per and it < n else -1
+
+    for n in (1, 7, 8, 9, 63, 64, 65, 1000, 128375):
+        grid = (n + 7) // 8 * 8
+        got = [xcd_contig(w, n) for w in range(grid)]
+        assert sorted(g for g in got if g >= 0) == list(range(n))
+        per = (n + 7) >> 3
+        for x in range(8):
+            mine = [g for w, g in enumerate(got) if w % 8 == x and g >= 0]
+            assert mine == list(range(x * per, min(n, (x + 1) * per)))
