@@ -1,0 +1,20 @@
+#!/bin/bash
+# Copy what tests/tools/collect_round.sh left under gpurun_out/ into profiles/ under this round's names.
+# usage: bash tests/tools/install_profiles.sh r2
+set -eu
+R=${1:?round tag, e.g. r2}
+P=gpurun_out/prof_round
+cp $P/bench.json profiles/${R}_bench.json
+cp $P/bench_profiled.json profiles/${R}_bench_profiled.json
+cp $P/bench_daily_profiled.json profiles/${R}_bench_daily_profiled.json
+cp $P/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
+cp $P/kernel_stats_daily.csv profiles/${R}_daily_kernel_stats.csv
+cp $P/pmc_FETCH_SIZE.csv profiles/${R}_bench_pmc_FETCH_SIZE.csv
+cp $P/pmc_WRITE_SIZE.csv profiles/${R}_bench_pmc_WRITE_SIZE.csv
+cp $P/pmc_daily_FETCH_SIZE.csv profiles/${R}_daily_pmc_FETCH_SIZE.csv
+cp $P/pmc_daily_WRITE_SIZE.csv profiles/${R}_daily_pmc_WRITE_SIZE.csv
+cp $P/hbm_traffic.json profiles/${R}_bench_hbm_traffic.json
+cp $P/c4_stream_daily.json profiles/${R}_c4_stream_daily.json
+cp $P/xval_10k.json profiles/${R}_xval_10k.json
+cp gpurun_out/sq_krig/sq_table.txt profiles/${R}_sq_counters_kriging.txt
+cp gpurun_out/sq_daily/sq_table.txt profiles/${R}_sq_counters_daily.txt

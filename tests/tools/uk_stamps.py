@@ -8,7 +8,9 @@ import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2048, 40, 4, 4).astype(np.int64)
 used = a[:, :, :, 0].max(axis=(1, 2)) > 0
 a = a[used]
-print("work-groups with stamps:", a.shape[0])
+nw = int((a[:, :, :, 0].max(axis=(0, 1)) > 0).sum())      # waves per work-group of the stamped kernel (2 or 4)
+a = a[:, :, :nw]
+print("work-groups with stamps:", a.shape[0], " waves per work-group:", nw)
 t0 = a[:, :, :, 0]            # barrier passed
 t1 = a[:, :, :, 1]            # update done
 t2 = a[:, :, :, 2].max(axis=2)   # holder: chain begins (only the holder's entry is non-zero)
