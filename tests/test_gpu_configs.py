@@ -98,7 +98,8 @@ def test_all_stations_leave_one_out_normals(orc):
 
 
 def test_daily_64bit_obs_addressing_equals_32bit(golden_case):
-    """The three ways a daily value is formed give the same bits: rows of the tile-month staged in LDS (default),
+    """The three ways a daily value is formed give the same packed values (the two gathers sum in rank order and agree in
+    fp64, the LDS-table kernel sums in table order: last-bit differences far below the int16 step): rows of the tile-month staged in LDS (default),
     gathered from global memory with 32-bit offsets (a tile-month with too many distinct rows; TWX_FLAG_DAILY_GATHER)
     and with 64-bit offsets (stations x days >= 2^30; TWX_FLAG_OBS_ADDR64)."""
     from topowx_amd import _lib
@@ -183,3 +184,39 @@ def test_single_variable_daily_equals_two_variable_run(golden_case):
     assert np.all(both["status"] == 0) and both["ninvalid"].max() == 0
     assert np.array_equal(one_n["daily_tmin"], both["daily_tmin"]) and np.array_equal(one_x["daily_tmax"], both["daily_tmax"])
     assert np.array_equal(one_n["norm_tmin"], both["norm_tmin"]) and np.array_equal(one_x["se_tmax"], both["se_tmax"])
+
+
+def test_dense_stations_large_tile_unions(golden_case, orc):
+    """k_tile_dist's second path: a tile whose cells krige with more than 256 distinct stations does not fit the LDS pair
+    table and evaluates the distance formula per element instead.  30 000 stations around the 100 x 100 grid (1.4 per
+    cell; more than k_tile_cand keeps in LDS, too) with 148 neighbours everywhere give unions of ~400 per 8x8 tile.
+    Grid path == point path (per-cell k_cell_dist) bit for bit, sampled cells vs the oracle."""
+    from topowx_amd import _lib, stationdb as sdb, synth
+    grid, _, _ = golden_case
+    stn = synth.make_stations(grid["bbox"], 30000, 11, "tmin", expand_deg=0.3)
+    for m in range(1, 13):
+        stn.stns[sdb.get_optim_varname(m)] = 148.0
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, stn, with_obs=False)
+    rs, cs = slice(30, 50), slice(40, 64)
+    got = ctx.interp_grid(grid, variables=("tmin",), daily=False, rows=rs, cols=cs)
+    kk = ctx.last_bandwidths(_lib.TMIN)
+    assert np.all(got["status"] == 0) and np.all(kk[kk > 0] == 148)
+    cells = np.array([(r, c) for r in range(rs.start, rs.stop) for c in range(cs.start, cs.stop)])
+    pts = ctx.make_pts(grid["lon"][cells[:, 1]], grid["lat"][cells[:, 0]], grid["elev"][cells[:, 0], cells[:, 1]],
+                       grid["tdi"][cells[:, 0], cells[:, 1]], grid["lst_night"][:, cells[:, 0], cells[:, 1]].T)
+    _, norms, se, st = ctx.interp_points(_lib.TMIN, pts, daily=False)
+    ctx.close()
+    shp = (rs.stop - rs.start, cs.stop - cs.start)
+    assert np.all(st == 0)
+    assert np.array_equal(got["norm_tmin"], norms.T.reshape(12, *shp).astype(np.float32))
+    assert np.array_equal(got["se_tmin"], se.T.reshape(12, *shp).astype(np.float32))
+    db, prm = orc.Db(stn), orc.params()
+    worst = 0.0
+    for r, c in cells[np.random.default_rng(2).choice(len(cells), 12, replace=False)]:
+        pt = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_night"][:, r, c])
+        rc, _, wn, ws = orc.interp(db, prm, pt, daily=False)
+        assert rc == 0
+        worst = max(worst, np.abs(got["norm_tmin"][:, r - rs.start, c - cs.start] - wn).max(),
+                    np.abs(got["se_tmin"][:, r - rs.start, c - cs.start] - ws).max())
+    assert worst < TOL, worst
