@@ -322,7 +322,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         launch_ukw<4, 0>(cnt, st, src, w.ws, 3, mi, stream);    // k + 8 <= 64
         launch_ukw<5, 1>(cnt, st, src, w.ws, 4, mi, stream);    // k + 8 <= 72
         launch_ukw<5, 0>(cnt, st, src, w.ws, 5, mi, stream);    // k + 8 <= 80
-        launch_uk<7>(cnt, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: four-wave kernel)
+        launch_uk<7>(cnt, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: two- / four-wave kernels)
         launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);
         launch_uk<9>(cnt, st, src, w.ws, 11, mi, stream);
         launch_uk<10>(cnt, st, src, w.ws, 12, mi, stream);

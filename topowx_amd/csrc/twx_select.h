@@ -40,7 +40,7 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *cdup;       // [ncell] lowest rank i whose neighbour coincides with an earlier one (k_cell_dist): systems with k > i are singular
-    int32_t *bucket_cnt; // [16]: 0..5 and 13, 14 one-wave kernel (8-row units 5..10, 11, 12), 6..12 four-wave kernel NB = 4..10
+    int32_t *bucket_cnt; // [16]: 0..5 and 13, 14 one-wave kernel (8-row units 5..10, 11, 12), 9..12 multi-wave kernels k_uk<NB, NW> NB = 7..10
     int32_t *bucket_cells; // [15][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
