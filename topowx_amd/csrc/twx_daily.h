@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
 // ---------------------------------------------------------------------------------
 // k_daily_tile: (8x8-cell tile) x (month) x (64 month-major days), both variables.  Per variable: the tile-month's
 // station rows (k_tile_union) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave takes
-// four cells, lane = day, and walks the TABLE: each row is read from LDS (conflict-free ds_read_b32 with immediate
+// TWX_DT_CPW = 8 cells, lane = day, and walks the TABLE: each row is read from LDS (conflict-free ds_read_b32 with immediate
 // offsets, lanes = consecutive days) and converted once and feeds one fmac per cell, weighted with the cell's hat row in
 // table order (zero where the cell does not use the row; a DPP row broadcast) -- dt_value4.  Tmin values wait in
 // registers while the table is re-staged for Tmax (whose rows are fetched while the Tmin sums run); cells with any
@@ -391,7 +391,11 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
 // of a tile row) of the [ndays][Y][X] int16 output.
 // A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2: rank-order sums).
 // ---------------------------------------------------------------------------------
-#define TWX_DT_WAVES 16                          // waves per work-group of k_daily_tile (2 work-groups fit a CU: LDS)
+#ifndef TWX_DT_WAVES
+#define TWX_DT_WAVES 8                           // waves per work-group of k_daily_tile (2 work-groups fit a CU: LDS).  The kernel is VALU
+                                                 // bound: 8 cells per wave share each row's LDS read + convert (C4 tile: 16 waves x 4 cells
+                                                 // 35.2 ms, 8 x 8 27.5 ms, 4 x 16 34.5 ms)
+#endif
 #define TWX_DT_CPW (64 / TWX_DT_WAVES)             // cells per wave
 
 // lean argument block of k_daily_tile (the full workspaces would not fit the scalar registers: 97 spilled SGPRs)
@@ -440,10 +444,11 @@ __device__ __forceinline__ void dt_fmac(double &acc, double z, double x)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(z), "v"(x), "n"(N));
 }
 
-// The same sums for the FOUR cells of a wave at once, walking the table's rows instead of each cell's own list:
+// The same sums for the TWX_DT_CPW cells of a wave at once, walking the table's rows instead of each cell's own list:
 // every row is read from LDS and converted once per wave (immediate offsets: no address arithmetic) and feeds one
 // fmac per cell, whose weight -- the cell's hat row scattered to table order by k_tile_union, zero where the cell does
-// not use the row -- is again a DPP row broadcast.  ~2 VALU instructions per useful term instead of 3.9; the terms are
+// not use the row -- is again a DPP row broadcast.  ~2 VALU instructions per useful term instead of 3.9 (1.1 per table
+// term with 8 cells per wave; the table has ~1.8 x the rows a cell uses); the terms are
 // added in table order, not in rank order (the sum differs from daily_value's in the last bits, far below the int16
 // rounding step; observations are finite by construction of the infilled station matrix).
 __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TWX_DT_CPW], int m0, const char *tab, uint32_t lane4,
