@@ -455,17 +455,24 @@ __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TW
                                           int lane, int nu, double (&acc)[TWX_DT_CPW])
 {
     const int l16 = lane & 15;
+    // The hat-row entries of the NEXT chunk travel while this chunk is summed.  For that the loads must be
+    // unconditional (behind a branch the compiler cannot count the loads in flight and waits for all of them, the
+    // prefetch included, before the first fmac of a chunk): a cell outside the grid reads cell 0's row, a chunk past the
+    // table the last one of the 224-entry row; both results are discarded.  And they are relaxed ATOMIC loads
+    // (wavefront scope: plain global_load instructions), which the optimizer leaves where they are -- an ordinary load
+    // it turns back into "load this chunk at the top of the next iteration", right in front of its use.
     const double *zp[TWX_DT_CPW];
     double zv[TWX_DT_CPW], zn[TWX_DT_CPW];
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         acc[i] = 0.0;
-        zp[i] = lc[i] >= 0 ? v.zd + (lc[i] * 12 + m0) * TWX_UROWS + l16 : nullptr;
-        zv[i] = zp[i] ? zp[i][0] : 0.0;
+        zp[i] = v.zd + ((lc[i] >= 0 ? lc[i] : 0) * 12 + m0) * TWX_UROWS + l16;
+        zv[i] = zp[i][0];
     }
     for (int u0 = 0; u0 < nu; u0 += 16) {
+        const int un = min(u0 + 16, TWX_UROWS - 16);
 #pragma unroll
-        for (int i = 0; i < TWX_DT_CPW; ++i) zn[i] = (zp[i] && u0 + 16 < nu) ? zp[i][u0 + 16] : 0.0;   // next chunk, in flight during this one
+        for (int i = 0; i < TWX_DT_CPW; ++i) zn[i] = __hip_atomic_load(zp[i] + un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const char *row = tab + (uint32_t)u0 * 256u + lane4;
         sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
             constexpr int N = decltype(n_)::value;
@@ -477,7 +484,7 @@ __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TW
         for (int i = 0; i < TWX_DT_CPW; ++i) zv[i] = zn[i];
     }
 #pragma unroll
-    for (int i = 0; i < TWX_DT_CPW; ++i) acc[i] += lc[i] >= 0 ? v.zc[lc[i] * 12 + m0] : 0.0;
+    for (int i = 0; i < TWX_DT_CPW; ++i) acc[i] = lc[i] >= 0 ? acc[i] + v.zc[lc[i] * 12 + m0] : 0.0;
 }
 
 #define TWX_DT_RPW ((TWX_UROWS + TWX_DT_WAVES - 1) / TWX_DT_WAVES)   // table rows staged per wave
