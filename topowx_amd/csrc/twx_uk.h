@@ -425,6 +425,16 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     // every load is issued here, before the staging, so that their latency hides behind it (measured: 13.3 -> 12.75 ms
     // per C2 step) (entries outside the neighbourhood are masked by the build; the slab of a cell always spans
     // TWX_DIST_BLOCKS blocks, so the addresses are valid)
+    // (first of all the neighbour indices: the vector-memory counter is in order, so the station gathers that depend on
+    // them can start while the distance blocks are still streaming in; relaxed atomic loads stay where they are written)
+    int jq[RPT];
+    float h0q[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int q = min(t + NTH * u, ws.ksel - 1);
+        jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
     float hd[NT];
     {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
@@ -446,12 +456,12 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         const int q = t + NTH * u;
         xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
         if (q < k) {
-            const int j = ws.near_idx[lc * ws.ksel + q];
+            const int j = jq[u];
             const double lo = st.lon[j], la = st.lat[j];
             xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev; xs[u][3] = st.lst[m0 * n + j] - plst;
             yv[u] = st.norm[m0 * n + j];
             // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
-            const float h0 = ws.h0[lc * ws.ksel + q];
+            const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
             e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));

@@ -66,6 +66,15 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     // the pair distances of this lane's elements (k_cell_dist's cache; 16x16 blocks, element order [column][row]):
     // every load is issued here, before the staging, so that their latency hides behind it (entries outside the
     // neighbourhood are never used; the slab of a cell always spans TWX_DIST_BLOCKS blocks, so the addresses are valid)
+    // (first of all the neighbour indices, see k_uk)
+    int jq[2];
+    float h0q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = min(lane + 64 * u, ws.ksel - 1);
+        jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
     float hd[NT];
     const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
     {
@@ -86,12 +95,12 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         const int t = lane + 64 * u;
         xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
         if (t < k) {
-            const int j = ws.near_idx[lc * ws.ksel + t];
+            const int j = jq[u];
             const double lo = st.lon[j], la = st.lat[j];
             xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev;
             xs[u][3] = st.lst[m0 * n + j] - plst;
             yv[u] = st.norm[m0 * n + j];
-            const float h0 = ws.h0[lc * ws.ksel + t];          // cell -> station distance (k_cell_dist)
+            const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
             e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
