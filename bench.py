@@ -270,7 +270,8 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import pyoracle as orc
             orc.build()
-            rs, cs = slice(100, 104), slice(60, 64)
+            r0w, c0w = min(100, Y - 4), min(60, X - 4)          # (inside the tile also for reduced --size runs)
+            rs, cs = slice(r0w, r0w + 4), slice(c0w, c0w + 4)
             want = orc.interp_grid(orc.Db(sn), orc.Db(sx), orc.params(), grid, daily=True, nthreads=os.cpu_count() or 1,
                                    rows=rs, cols=cs)
             dd = np.concatenate([np.abs(d_dn[:, rs, cs].cpu().numpy().astype(np.int32) - want["daily_tmin"].astype(np.int32)).ravel(),
@@ -338,7 +339,7 @@ def main():
             from oracle import arbiter
             cdb = db.cols
             worst = 0.0
-            for (r, q, m) in ((17, 200, 1), (120, 40, 7)):
+            for (r, q, m) in ((17 % Y, 200 % X, 1), (120 % Y, 40 % X, 7)):   # (inside the tile also for reduced --size runs)
                 pts = ctx.make_pts(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
                 mean, var, used, st, ngh = ctx.krig_points(_lib.TMIN, pts, m, want_idx=True)
                 pt = orc.make_pt(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
