@@ -19,6 +19,16 @@ struct DayAxis {
 };
 
 #define TWX_UROWS 224 // observation rows of a (tile, month) staged in LDS by k_daily_tile (x 64 days x 4 B = 56 KB)
+#ifndef TWX_DT_WAVES
+#define TWX_DT_WAVES 8                           // waves per work-group of k_daily_tile (see there)
+#endif
+#define TWX_DT_CPW (64 / TWX_DT_WAVES)             // cells per wave
+// position of (tile-month tm, cell ci of the tile, table row u) in GwrWs.zd
+__host__ __device__ __forceinline__ int64_t twx_zd_index(int64_t tm, int ci)
+{
+    return ((tm * TWX_DT_WAVES + ci / TWX_DT_CPW) * (TWX_UROWS / 16) * TWX_DT_CPW + ci % TWX_DT_CPW) * 16;
+}
+__host__ __device__ __forceinline__ int twx_zd_row(int u) { return (u >> 4) * (TWX_DT_CPW * 16) + (u & 15); }
 
 struct GwrWs {
     double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank
@@ -29,7 +39,9 @@ struct GwrWs {
     uint32_t *soff;   // [ncell][12][TWX_KZ]  byte offset of the ranked neighbour's row in the tile's table
     int32_t *urow;    // [ntile][12][TWX_UROWS] station index of table row u
     int32_t *nurow;   // [ntile][12] rows in the table; -1 = more than TWX_UROWS (the tile-month gathers from global memory)
-    double *zd;       // [ncell][12][TWX_UROWS] the hat row scattered to table-row order (0 for rows the cell does not use)
+    double *zd;       // [ntile][12][64 / CPW groups][14 chunks][CPW cells][16] the hat rows scattered to table-row order (0 for
+                      // rows a cell does not use), laid out as k_daily_tile's waves read them: one wave = one group of CPW
+                      // cells, one chunk of 16 table rows at a time = CPW x 128 contiguous bytes (twx_zd_index)
 };
 
 // ---------------------------------------------------------------------------------
@@ -368,14 +380,14 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
         const int ka = ws.ka[lc * 12 + m0];
         // the hat row in table-row order, zero where the cell does not use the row (k_daily_tile walks the TABLE, four
         // cells at a time): rows up to the next multiple of 16
-        double *zd = gw.zd + (lc * 12 + m0) * TWX_UROWS;
-        for (int u = lane; u < ((nu + 15) & ~15); u += 64) zd[u] = 0.0;
+        double *zd = gw.zd + twx_zd_index(tl * 12 + m0, ci);
+        for (int u = lane; u < ((nu + 15) & ~15); u += 64) zd[twx_zd_row(u)] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros are out (s_waitcnt vmcnt(0)) before the scatter
         __builtin_amdgcn_wave_barrier();
         for (int r = lane; r < ka; r += 64) {
             const uint32_t u = s_slot[ws.near_pos[lc * ws.ksel + r]];
             gw.soff[(lc * 12 + m0) * TWX_KZ + r] = 256u * u;
-            zd[u] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
+            zd[twx_zd_row(u)] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
         }
     }
 }
@@ -391,12 +403,8 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
 // of a tile row) of the [ndays][Y][X] int16 output.
 // A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2: rank-order sums).
 // ---------------------------------------------------------------------------------
-#ifndef TWX_DT_WAVES
-#define TWX_DT_WAVES 8                           // waves per work-group of k_daily_tile (2 work-groups fit a CU: LDS).  The kernel is VALU
-                                                 // bound: 8 cells per wave share each row's LDS read + convert (C4 tile: 16 waves x 4 cells
-                                                 // 35.2 ms, 8 x 8 27.5 ms, 4 x 16 34.5 ms)
-#endif
-#define TWX_DT_CPW (64 / TWX_DT_WAVES)             // cells per wave
+// TWX_DT_WAVES = 8 waves per work-group (2 work-groups fit a CU: LDS).  The kernel is VALU bound: 8 cells per wave share each
+// row's LDS read + convert (C4 tile: 16 waves x 4 cells 35.2 ms, 8 x 8 27.5 ms, 4 x 16 34.5 ms)
 
 // lean argument block of k_daily_tile (the full workspaces would not fit the scalar registers: 97 spilled SGPRs)
 struct DtVar {
@@ -404,7 +412,7 @@ struct DtVar {
     const int32_t *ka;        // [ncell][12]
     const double *z, *zc;     // hat rows / constants
     const uint32_t *soff;     // [ncell][12][TWX_KZ]
-    const double *zd;         // [ncell][12][TWX_UROWS] hat row in table-row order
+    const double *zd;         // hat rows in table-row order, wave layout (GwrWs.zd)
     const int32_t *urow;      // [ntile][12][TWX_UROWS]
     const int32_t *nurow;     // [ntile][12]
 };
@@ -452,13 +460,13 @@ __device__ __forceinline__ void dt_fmac(double &acc, double z, double x)
 // added in table order, not in rank order (the sum differs from daily_value's in the last bits, far below the int16
 // rounding step; observations are finite by construction of the infilled station matrix).
 __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TWX_DT_CPW], int m0, const char *tab, uint32_t lane4,
-                                          int lane, int nu, double (&acc)[TWX_DT_CPW])
+                                          int lane, int nu, const double *zbase, double (&acc)[TWX_DT_CPW])
 {
-    const int l16 = lane & 15;
     // The hat-row entries of the NEXT chunk travel while this chunk is summed.  For that the loads must be
     // unconditional (behind a branch the compiler cannot count the loads in flight and waits for all of them, the
-    // prefetch included, before the first fmac of a chunk): a cell outside the grid reads cell 0's row, a chunk past the
-    // table the last one of the 224-entry row; both results are discarded.  And they are relaxed ATOMIC loads
+    // prefetch included, before the first fmac of a chunk): a cell outside the grid reads whatever its slot holds, a chunk
+    // past the table the last one of the 14; both results are discarded.  zbase = the wave's group in GwrWs.zd (+ lane & 15):
+    // a chunk of the group's cells is 8 x 128 contiguous bytes, reached with immediate offsets.  And they are relaxed ATOMIC loads
     // (wavefront scope: plain global_load instructions), which the optimizer leaves where they are -- an ordinary load
     // it turns back into "load this chunk at the top of the next iteration", right in front of its use.
     const double *zp[TWX_DT_CPW];
@@ -466,11 +474,11 @@ __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TW
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         acc[i] = 0.0;
-        zp[i] = v.zd + ((lc[i] >= 0 ? lc[i] : 0) * 12 + m0) * TWX_UROWS + l16;
+        zp[i] = zbase + 16 * i;                              // (a cell outside the grid reads whatever its slot holds: discarded)
         zv[i] = zp[i][0];
     }
     for (int u0 = 0; u0 < nu; u0 += 16) {
-        const int un = min(u0 + 16, TWX_UROWS - 16);
+        const int un = min(u0 + 16, TWX_UROWS - 16) * TWX_DT_CPW;       // (chunk stride: CPW x 16 entries)
 #pragma unroll
         for (int i = 0; i < TWX_DT_CPW; ++i) zn[i] = __hip_atomic_load(zp[i] + un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const char *row = tab + (uint32_t)u0 * 256u + lane4;
@@ -549,12 +557,12 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
     double vn[TWX_DT_CPW], vxs[TWX_DT_CPW];
     fetch(a.x, nux);     // the Tmax rows travel while the Tmin sums run (the sums' hat-row loads are prefetched a chunk ahead,
                          // so only their first wait sits behind these loads on the in-order counter: 42.6 -> 41.4 ms per C4 tile)
-    dt_value4(a.n, lcs, m0, tab, lane4, lane, nun, vn);
+    dt_value4(a.n, lcs, m0, tab, lane4, lane, nun, a.n.zd + twx_zd_index(tl * 12 + m0, wv * TWX_DT_CPW) + (lane & 15), vn);
     __syncthreads();
     // ---- Tmax: re-stage the table, walk the cells, flag, pack
     store(nux);
     __syncthreads();
-    dt_value4(a.x, lcs, m0, tab, lane4, lane, nux, vxs);
+    dt_value4(a.x, lcs, m0, tab, lane4, lane, nux, a.x.zd + twx_zd_index(tl * 12 + m0, wv * TWX_DT_CPW) + (lane & 15), vxs);
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         const int cl = wv * TWX_DT_CPW + i;

@@ -183,7 +183,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_union)
     if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
         HIPCHK(w.soff.ensure((size_t)ncell * 12 * TWX_KZ * 4));
-        HIPCHK(w.zd.ensure((size_t)ncell * 12 * TWX_UROWS * 8));
+        HIPCHK(w.zd.ensure((size_t)ntile * 12 * 64 * TWX_UROWS * 8));   // per tile: 64 cell slots x 224 rows, wave layout
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
     }
