@@ -469,27 +469,35 @@ __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TW
     // a chunk of the group's cells is 8 x 128 contiguous bytes, reached with immediate offsets.  And they are relaxed ATOMIC loads
     // (wavefront scope: plain global_load instructions), which the optimizer leaves where they are -- an ordinary load
     // it turns back into "load this chunk at the top of the next iteration", right in front of its use.
+    // Two register sets take turns (chunk pairs), so that no copy is needed at the end of a chunk.
     const double *zp[TWX_DT_CPW];
-    double zv[TWX_DT_CPW], zn[TWX_DT_CPW];
+    double za[TWX_DT_CPW], zb[TWX_DT_CPW];
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         acc[i] = 0.0;
         zp[i] = zbase + 16 * i;                              // (a cell outside the grid reads whatever its slot holds: discarded)
-        zv[i] = zp[i][0];
+        za[i] = zp[i][0];
     }
-    for (int u0 = 0; u0 < nu; u0 += 16) {
-        const int un = min(u0 + 16, TWX_UROWS - 16) * TWX_DT_CPW;       // (chunk stride: CPW x 16 entries)
+    auto prefetch = [&](double (&z)[TWX_DT_CPW], int u) __attribute__((always_inline)) {
+        const int un = min(u, TWX_UROWS - 16) * TWX_DT_CPW;             // (chunk stride: CPW x 16 entries)
 #pragma unroll
-        for (int i = 0; i < TWX_DT_CPW; ++i) zn[i] = __hip_atomic_load(zp[i] + un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int i = 0; i < TWX_DT_CPW; ++i) z[i] = __hip_atomic_load(zp[i] + un, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    auto chunk = [&](const double (&z)[TWX_DT_CPW], int u0) __attribute__((always_inline)) {
         const char *row = tab + (uint32_t)u0 * 256u + lane4;
         sfor<0, 16>([&](auto n_) __attribute__((always_inline)) {
             constexpr int N = decltype(n_)::value;
             const double x = (double)*reinterpret_cast<const float *>(row + 256 * N);
 #pragma unroll
-            for (int i = 0; i < TWX_DT_CPW; ++i) dt_fmac<N>(acc[i], zv[i], x);
+            for (int i = 0; i < TWX_DT_CPW; ++i) dt_fmac<N>(acc[i], z[i], x);
         });
-#pragma unroll
-        for (int i = 0; i < TWX_DT_CPW; ++i) zv[i] = zn[i];
+    };
+    for (int u0 = 0; u0 < nu; u0 += 32) {
+        prefetch(zb, u0 + 16);
+        chunk(za, u0);
+        if (u0 + 16 >= nu) break;                            // (uniform)
+        prefetch(za, u0 + 32);
+        chunk(zb, u0 + 16);
     }
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) acc[i] = lc[i] >= 0 ? acc[i] + v.zc[lc[i] * 12 + m0] : 0.0;
