@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 // LDS space.  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
 // ---------------------------------------------------------------------------------
 #define TWX_TD_U 256
+#ifdef TWX_TD_NT_STORE
+#define TWX_TD_STORE(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define TWX_TD_STORE(p, v) (*(p) = (v))
+#endif
 #define TWX_TD_WAVES 16
 #ifndef TWX_TD_PARTS
 #define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
                         // coincident neighbours: see k_cell_dist
                         if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
-                    ob[64 * q] = h;
+                    TWX_TD_STORE(&ob[64 * q], h);
                 }
             }
         }
