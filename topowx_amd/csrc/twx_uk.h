@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
                 // and the cached distance stays positive so that the build's masks (-inf * h) never see 0.
                 if (h == 0.f) { atomicMin(&s_dup, max(i, j)); h = 1e-30f; }
             }
-            out[(a * (a + 1) / 2 + b) * 256 + t] = h;        // t = tc * 16 + tr
+            __builtin_nontemporal_store(h, &out[(a * (a + 1) / 2 + b) * 256 + t]);   // t = tc * 16 + tr
         }
     }
     __syncthreads();
@@ -194,11 +194,6 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 // LDS space.  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
 // ---------------------------------------------------------------------------------
 #define TWX_TD_U 256
-#ifdef TWX_TD_NT_STORE
-#define TWX_TD_STORE(p, v) __builtin_nontemporal_store(v, p)
-#else
-#define TWX_TD_STORE(p, v) (*(p) = (v))
-#endif
 #define TWX_TD_WAVES 16
 #ifndef TWX_TD_PARTS
 #define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
@@ -323,7 +318,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
                         // coincident neighbours: see k_cell_dist
                         if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
-                    TWX_TD_STORE(&ob[64 * q], h);
+                    __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
                 }
             }
         }
