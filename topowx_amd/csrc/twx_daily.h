@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
         // a predictor that is exactly zero at every neighbour (e.g. TDI on flat terrain) gives X'WX an exactly
         // zero row: np.linalg.inv raises (interp_tair.py:1139) -- with the columns shifted to the cell that case
         // would otherwise only be collinear, which rounding can hide from the Cholesky pivots below
-        if (wave_max_dpp(rawmx[q]) == 0.0) bad = true;
+        if (!__any(rawmx[q] != 0.0)) bad = true;             // (a ballot, not a sixth reduction)
     }
     // M = X'WX (lower triangle, 21 sums)
     double M[6][6];
