@@ -320,11 +320,14 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
     for (int p = lane; p < m; p += 64) {
         const double dj = sd[p];
-        int rank = 0;
+        int rank = 0, eq = 0;                                // two compares + two adds per pair; equal distances are rare
         for (int i = 0; i < m; ++i) {
             const double di = sd[i];
-            rank += (di < dj) || (di == dj && i < p);
+            rank += di < dj;
+            eq += di == dj;
         }
+        if (eq > 1)                                          // (its own entry is one): ties rank in list order
+            for (int i = 0; i < p; ++i) rank += sd[i] == dj;
         if (rank < ws.ksel) snp[rank] = p;
     }
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
