@@ -741,12 +741,12 @@ __device__ void fix_series_block(double *tmin, double *tmax, int32_t *list, cons
                                  int *s_n, int *s_err, double *s_norm /*[2][12]*/)
 {
     // ordered list of invalid days (taken BEFORE any fix, interp_tair.py:173)
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[16];                                // per wave (work-groups of 4 ... 16 waves)
     __shared__ int s_base;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nth = blockDim.x, nwv = nth >> 6;
     if (t == 0) { s_base = 0; *s_err = 0; }
     __syncthreads();
-    for (int d0 = 0; d0 < da.ndays; d0 += 256) {
+    for (int d0 = 0; d0 < da.ndays; d0 += nth) {
         int d = d0 + t;
         bool f = d < da.ndays && tmin[d] >= tmax[d];
         unsigned long long b = __ballot(f);
@@ -757,7 +757,7 @@ __device__ void fix_series_block(double *tmin, double *tmax, int32_t *list, cons
         for (int w = 0; w < wv; ++w) off += s_cnt[w];
         if (f) list[off + pre] = d;
         __syncthreads();
-        if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t == 0) { int a = 0; for (int w = 0; w < nwv; ++w) a += s_cnt[w]; s_base += a; }
         __syncthreads();
     }
     const int ninv = s_base;
@@ -798,7 +798,9 @@ __device__ void fix_series_block(double *tmin, double *tmax, int32_t *list, cons
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_fix_cells(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
+// 8 waves per flagged cell (TWX_FIX_THREADS): the recompute is a chain of gathers per day (memory latency), and a tile has
+// fewer flagged cells than the GPU has CUs (C4 tile: 229): 4 waves per cell 2.36 ms, 8 waves 1.54, 16 waves 1.64
+__global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                    GwrWs gn, GwrWs gx, DayAxis da, twx_grid_out out, FixArgs fa)
 {
     __shared__ int s_n, s_err;
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(256) void k_fix_cells(StnDev stn, StnDev stx, CellS
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
         const int64_t c = wn.cell0 + lc;
-        for (int dm = threadIdx.x; dm < da.ndays; dm += 256) {
+        for (int dm = threadIdx.x; dm < da.ndays; dm += blockDim.x) {
             int m0 = 0;
             while (dm >= da.moff[m0 + 1]) ++m0;
             int d = da.mm2chron[dm];
@@ -827,24 +829,24 @@ __global__ __launch_bounds__(256) void k_fix_cells(StnDev stn, StnDev stx, CellS
                 if (out.status) out.status[c] = TWX_CELL_FIXER;
                 if (out.ninvalid) out.ninvalid[c] = TWX_FILL_I4;
             }
-            for (int m = threadIdx.x; m < 12; m += 256) {
+            for (int m = threadIdx.x; m < 12; m += blockDim.x) {
                 if (out.norm_tmin) out.norm_tmin[m * yx + c] = TWX_FILL_F4;
                 if (out.se_tmin) out.se_tmin[m * yx + c] = TWX_FILL_F4;
                 if (out.norm_tmax) out.norm_tmax[m * yx + c] = TWX_FILL_F4;
                 if (out.se_tmax) out.se_tmax[m * yx + c] = TWX_FILL_F4;
             }
-            for (int d = threadIdx.x; d < da.ndays; d += 256) {
+            for (int d = threadIdx.x; d < da.ndays; d += blockDim.x) {
                 if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = TWX_FILL_I2;
                 if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = TWX_FILL_I2;
             }
         } else {
             if (threadIdx.x == 0 && out.ninvalid) out.ninvalid[c] = ninv;
             if (ninv > 0) {
-                for (int m = threadIdx.x; m < 12; m += 256) {
+                for (int m = threadIdx.x; m < 12; m += blockDim.x) {
                     if (out.norm_tmin) out.norm_tmin[m * yx + c] = (float)s_norm[m];
                     if (out.norm_tmax) out.norm_tmax[m * yx + c] = (float)s_norm[12 + m];
                 }
-                for (int q = threadIdx.x; q < ninv; q += 256) {
+                for (int q = threadIdx.x; q < ninv; q += blockDim.x) {
                     int d = list[q];
                     if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(tmin[d]);
                     if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = pack_i16(tmax[d]);

@@ -70,6 +70,9 @@ struct EvPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+#ifndef TWX_FIX_THREADS
+#define TWX_FIX_THREADS 512
+#endif
 #ifndef TWX_DAILY_BATCH
 #define TWX_DAILY_BATCH 65536   // cells per batch when daily output is requested (workspace ~110 KB per cell and variable: 14 GB; a C2 / C4 tile is one batch: 71.3 -> 68.6 ms per C4 tile against 32 768)
 #endif
@@ -1135,7 +1138,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count;
                 fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
                 EvScope ev(ctx, stream, EV_FIX);
-                hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
+                hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(TWX_FIX_THREADS), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
                                    ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
             }
         }
