@@ -12,9 +12,16 @@ under torchrun (WORLD_SIZE set) it is a rank.
 
 Rank 0 prints ONE JSON line (contract in the task description) carrying
   roofline      dominant kernels = the universal-kriging launches, HIP-event timed inside the library on the
-                launch stream; HBM as BASELINE.json asks, the binding fp64-vector figure next to it (``fp64``)
+                launch stream; HBM as BASELINE.json asks, the binding fp64-vector figure next to it (``fp64``:
+                nominal = SURVEY 8d's flops, executed = factorisation + border only)
   daily         (N = 1) the cell-DAY producing path, timed the same way: the same tile, Tmin + Tmax, normals +
                 GWR + 10 years of daily int16 values + Tmin>=Tmax fixer, outputs resident in HBM
+  configs       (N = 1) the other BASELINE.json configurations, driver-timed in the same run: ``c4_tile`` (the
+                25 203-day tile of configs[3]), ``c5`` (configs[4]: the three cross-validation farms over all
+                stations), ``c3_strip`` (a 750x7000 strip of configs[2]'s masked grid through topowx_amd.driver)
+  strong        (N > 1) the tile farm of topowx_amd.driver on ONE fixed masked grid (the c3_strip workload):
+                LPT tile deal, per-rank device-resident tiles, RCCL gather of the normals mosaic on device
+                tensors; ``--scaling strong`` makes it the top-level line
   cpu_baseline  (N = 1) the CPU oracle on bounded samples of the headline workload: all host cores (>= 64 cells
                 per thread) and one core
 """
@@ -33,16 +40,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_CELL_MONTH = 13.1   # Tmin-only normals, 61 B in + 96 B out per cell / 12
+ALG_BYTES_PER_CELL_MONTH_2V = 12.7   # Tmin + Tmax normals: 305 B / 24 cell-months
 ALG_BYTES_PER_CELL_DAY = 2.03     # int16 out + amortised inputs / observation matrix
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6       # vendor fp64 vector peak
 
 
 def uk_flops(k):
-    """Algorithmic fp64 flops of one (cell, month) kriging system."""
+    """Algorithmic fp64 flops of one (cell, month) kriging system: Cholesky + border rows +
+    pair distances / covariances evaluated per system."""
     k = np.asarray(k, np.float64)
-    p = 4
-    return k ** 3 / 3.0 + (p + 3) * k ** 2 + 60.0 * k * (k - 1) / 2.0
+    return uk_flops_executed(k) + uk_flops_distance(k)
+
+
+def uk_flops_executed(k):
+    """What the kriging kernels execute per system today: k^3/3 (Cholesky) + 7 k^2 (the seven border rows); the pair
+    distances are evaluated once per tile and station pair (k_tile_dist), not per system."""
+    k = np.asarray(k, np.float64)
+    return k ** 3 / 3.0 + 7.0 * k ** 2
+
+
+def uk_flops_distance(k):
+    """SURVEY 8d's nominal distance / covariance term: ~60 flops for each of the k (k - 1) / 2 pairs of a system."""
+    k = np.asarray(k, np.float64)
+    return 60.0 * k * (k - 1) / 2.0
 
 
 def parse():
@@ -57,6 +78,20 @@ def parse():
     ap.add_argument("--daily-years", type=int, default=10, help="years of days of the daily record (1981-...)")
     ap.add_argument("--stream-tiles", type=int, default=4, help="tiles of the streamed (PCIe-inclusive) daily record; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
+    ap.add_argument("--int16-window", type=int, default=24, help="edge of the cell window whose packed int16 days are compared with the oracle")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c4_tile / c5 / c3_strip records (N = 1)")
+    ap.add_argument("--configs", default="c4_tile,c5,c3_strip", help="which of the other configurations to time")
+    ap.add_argument("--force-configs", action="store_true", help="time them also on a reduced --size (tests)")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto: N = 1 headline (+ configs); N > 1 weak headline + a 'strong' record.  strong: the tile farm "
+                         "of topowx_amd.driver on one fixed masked grid is the top-level line")
+    ap.add_argument("--strip-rows", type=int, default=750)
+    ap.add_argument("--strip-cols", type=int, default=7000)
+    ap.add_argument("--strip-nstns", type=int, default=12000)
+    ap.add_argument("--strip-tile", type=int, default=250)
+    ap.add_argument("--strong-steps", type=int, default=3, help="timed passes of the strong record when it is not the top-level line")
+    ap.add_argument("--c5-years", type=int, default=3)
+    ap.add_argument("--dump-mosaic", default=None, help="strong mode: rank 0 writes the gathered mosaic here (.npz)")
     return ap.parse_args()
 
 
@@ -81,43 +116,362 @@ def spawn(args):
 
 
 def latest_traffic():
-    """HBM bytes per kriging launch from the newest committed PMC reduction (profiles/r*_bench_hbm_traffic.json)."""
+    """HBM bytes from the newest committed PMC reduction (profiles/r*_bench_hbm_traffic.json): per kriging launch
+    (roofline.traffic) and per daily step (daily.traffic)."""
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_hbm_traffic.json")))
     if not paths:
-        return None, None
+        return None, None, None
     tj = json.load(open(paths[-1]))
     traffic = tj["FETCH_SIZE"]["k_uk_per_launch_bytes"] + tj["WRITE_SIZE"]["k_uk_per_launch_bytes"]
+    daily = None
+    if "daily_path_per_step_bytes" in tj["FETCH_SIZE"]:
+        daily = tj["FETCH_SIZE"]["daily_path_per_step_bytes"] + tj["WRITE_SIZE"]["daily_path_per_step_bytes"]
     src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this workload, KB units x "
-           "1024, per kriging launch; 4-byte loads of the fp32 pair-distance cache: the guide's x2 correction for "
+           "1024; 4-byte loads of the fp32 pair-distance cache: the guide's x2 correction for "
            "16-B/lane streaming reads does not apply)" % os.path.basename(paths[-1]))
-    return traffic, src
+    return traffic, daily, src
 
 
+class Env(object):
+    """Process-group / device context of this rank."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        # TWX_BENCH_BACKEND=gloo + TWX_BENCH_SHARE_GPU=1: control-flow check of the N > 1 path on a 1-GPU box
+        self.backend = os.environ.get("TWX_BENCH_BACKEND", "nccl")
+        self.shared = os.environ.get("TWX_BENCH_SHARE_GPU") == "1"
+        if self.shared:
+            self.local = 0
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+            else:
+                dist.init_process_group(self.backend)
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_scalar(self, x):
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        parts = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [float(p.item()) for p in parts]
+
+    def sum_over_ranks(self, x):
+        return float(sum(self.all_gather_scalar(x)))
+
+
+def timed(env, step, steps, warmup, after_step=None):
+    """W untimed + K timed steps between barrier + synchronize; max over ranks."""
+    for _ in range(warmup):
+        step()
+        if after_step:
+            after_step(False)
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if after_step:
+            after_step(True)
+    env.barrier()
+    return env.max_over_ranks(time.perf_counter() - t0)
+
+
+# =====================================================================================================================
+# daily record (default: the C2 tile with 10 years of days; c4_tile: 1948-2016)
+# =====================================================================================================================
+def daily_record(env, args, base, grid, g, d_ninv, d_stat, day0, day1, label, steps, warmup, stream_tiles, int16_window,
+                 traffic_bytes=None, traffic_src=None):
+    """Tmin + Tmax normals + daily int16 + fixer of the tile on the day axis day0 .. day1, in a context of its own (a
+    context's day axis is fixed once observations are loaded)."""
+    torch = env.torch
+    from topowx_amd import _lib, synth
+    from topowx_amd.dates import get_days_metadata
+    dev = env.dev
+    Y = X = args.size
+    days = get_days_metadata(day0, day1)
+    nd = int(days.size)
+    t_s = time.perf_counter()
+    sn = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmin", days, with_obs=True)
+    sx = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmax", days, with_obs=True)
+    ctx = _lib.Context(device=env.local)
+    ctx.set_stations(_lib.TMIN, sn)
+    ctx.set_stations(_lib.TMAX, sx)
+    setup_s = time.perf_counter() - t_s
+    outs = {k: torch.full((12, Y, X), float(_lib.FILL_F4), dtype=torch.float32, device=dev)
+            for k in ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")}
+    d_dn = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
+    d_dx = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
+    o2 = _lib.TwxGridOut(outs["norm_tmin"].data_ptr(), outs["se_tmin"].data_ptr(), outs["norm_tmax"].data_ptr(),
+                         outs["se_tmax"].data_ptr(), d_dn.data_ptr(), d_dx.data_ptr(), d_ninv.data_ptr(),
+                         d_stat.data_ptr())
+    both = _lib.VAR_TMIN_BIT | _lib.VAR_TMAX_BIT
+    stream = torch.cuda.current_stream().cuda_stream
+    k2 = []
+    el2 = timed(env, lambda: ctx.interp_grid_dev(g, o2, both, stream), steps, warmup,
+                lambda keep: k2.append(ctx.timing()) if keep else ctx.timing())
+    ok2 = int((d_stat.cpu().numpy() == 0).sum())
+    cell_days = ok2 * nd * 2
+    tm = {k: float(np.mean([t[k] for t in k2])) for k in ("tile_cand_ms", "select_ms", "uk_ms", "gwr_ms",
+                                                          "daily_ms", "fix_ms", "total_ms")}
+    kan = ctx.last_bandwidths(_lib.TMIN).ravel()      # kriging bandwidths (GWR ones are of the same ladder)
+    dgbs = ALG_BYTES_PER_CELL_DAY * cell_days / (tm["daily_ms"] * 1e-3) / 1e9
+    ninv = d_ninv.cpu().numpy()
+    rec = {
+        "value": cell_days * steps / el2, "unit": "cell-days/s (whole path: selection + 24 normals per cell + GWR + "
+                                                 "daily int16 + fixer, outputs resident in HBM)",
+        "workload": "%s: the %dx%d tile and %d stations per variable, Tmin + Tmax, %d days (%s .. %s), int16 daily "
+                    "outputs + normals + SE + ninvalid" % (label, Y, X, args.nstns, nd, day0.isoformat(), day1.isoformat()),
+        "steps": steps, "warmup": warmup,
+        "ms_per_step": el2 / steps * 1e3, "cell_days_per_step": cell_days, "cells_ok": ok2,
+        "cells_with_fixed_days": int((ninv[d_stat.cpu().numpy() == 0] > 0).sum()),
+        "timing_ms": tm, "setup_s": setup_s,
+        "daily_kernel": {"kernel": "k_tile_union + k_daily_tile (+ k_row_offsets, k_daily_ok, k_daily_tile_gather)", "ms_per_step": tm["daily_ms"],
+                         "cell_days_per_s": cell_days / (tm["daily_ms"] * 1e-3),
+                         "roofline": {"bound": "hbm", "achieved": dgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": dgbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_DAY * cell_days,
+                                      "note": "every cell-day is a ~80-term dot product over observation rows; the rows "
+                                              "of a tile-month are staged in LDS (VALU / LDS bound), DESIGN.md section 4"}},
+        "mean_nnghs": float(kan[kan > 0].mean()),
+    }
+    if traffic_bytes is not None:
+        # measured HBM bytes of the launches behind daily_ms + gwr_ms (k_tile_union, k_daily_tile, k_gwr_z, ...) per step
+        alg = ALG_BYTES_PER_CELL_DAY * cell_days
+        rec["traffic"] = {"bytes_per_step": traffic_bytes, "algorithmic_bytes_per_step": alg, "ratio": traffic_bytes / alg,
+                          "source": traffic_src}
+    # packed int16 days against the oracle on a window of cells (integer output: identical except isolated +-1 LSB
+    # where the fp64 value sits on a 0.005 rounding boundary and the summation order decides; DESIGN.md section 2)
+    if not args.no_cpu_baseline and int16_window > 0:
+        from oracle import pyoracle as orc
+        orc.build()
+        w = min(int16_window, Y, X)
+        r0w, c0w = min(100, Y - w), min(60, X - w)          # (inside the tile also for reduced --size runs)
+        rs, cs = slice(r0w, r0w + w), slice(c0w, c0w + w)
+        t1 = time.perf_counter()
+        want = orc.interp_grid(orc.Db(sn), orc.Db(sx), orc.params(), grid, daily=True, nthreads=os.cpu_count() or 1,
+                               rows=rs, cols=cs)
+        dd = np.concatenate([np.abs(d_dn[:, rs, cs].cpu().numpy().astype(np.int32) - want["daily_tmin"].astype(np.int32)).ravel(),
+                             np.abs(d_dx[:, rs, cs].cpu().numpy().astype(np.int32) - want["daily_tmax"].astype(np.int32)).ravel()])
+        nerr = float(max(np.abs(outs[k][:, rs, cs].cpu().numpy().astype(np.float64) - want[k]).max()
+                         for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax")))
+        rec["packed_int16_vs_oracle"] = {"cells": w * w, "values": int(dd.size), "identical_frac": float((dd == 0).mean()),
+                                         "flips": int((dd != 0).sum()), "flip_rate": float((dd != 0).mean()),
+                                         "max_abs_lsb": int(dd.max()),
+                                         "ninvalid_equal": bool(np.array_equal(ninv[rs, cs], want["ninvalid"])),
+                                         "status_equal": bool(np.array_equal(d_stat[rs, cs].cpu().numpy(), want["status"])),
+                                         "normals_max_abs_degC": nerr, "oracle_s": time.perf_counter() - t1}
+    del d_dn, d_dx, outs, sn, sx
+    torch.cuda.empty_cache()
+    # the same tile streamed: outputs of tile t travel to pinned host memory while tile t + 1 is computed
+    # (twx_stream_*); end to end = host wall clock from the first submit to the last tile in host memory
+    if stream_tiles > 0:
+        ts = ctx.stream(Y, X, daily=True, nslots=2)
+        ts.submit(0, grid); ts.wait(0)                       # warm-up: workspace, pinned pages
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dev_ms = 0.0
+        for i in range(stream_tiles):
+            ts.submit(i & 1, grid)
+            if i:
+                dev_ms += ts.wait((i - 1) & 1)["device_ms"]
+        last = ts.wait((stream_tiles - 1) & 1)
+        dev_ms += last["device_ms"]
+        wall = time.perf_counter() - t1
+        okc = int((last["status"] == 0).sum())
+        out_bytes = sum(v.nbytes for k, v in last.items() if hasattr(v, "nbytes"))
+        ts.close()
+        e2e = okc * nd * 2 * stream_tiles / wall
+        rec["stream"] = {
+            "tiles": stream_tiles, "end_to_end_cell_days_per_s": e2e,
+            "device_only_cell_days_per_s": okc * nd * 2 * stream_tiles / (dev_ms * 1e-3),
+            "ratio": e2e / (okc * nd * 2 * stream_tiles / (dev_ms * 1e-3)),
+            "wall_s": wall, "device_ms_per_tile": dev_ms / stream_tiles,
+            "d2h_bytes_per_tile": out_bytes, "d2h_GBps_if_exposed": out_bytes * stream_tiles / wall / 1e9,
+            "note": "host pointers in, pinned host memory out (PCIe-inclusive; never the headline value)"}
+    ctx.close()
+    return rec
+
+
+# =====================================================================================================================
+# the tile farm of topowx_amd.driver on ONE fixed masked grid (strong scaling; at N = 1 the c3_strip record)
+# =====================================================================================================================
+def strip_run(env, args, steps, warmup, spot_check):
+    """BASELINE.json configs[2] shape on a strip of the seed-7 masked CONUS-shaped grid: Tmin + Tmax normals + SE of
+    every valid cell, tiles dealt to the ranks with driver.assign_tiles (LPT), every rank's tiles computed device-
+    resident into the send buffer of ONE dist.gather (RCCL over xGMI) that assembles the four mosaics on rank 0.
+    One step = the whole strip: deal + all tiles + gather.  Reference shape: step25:266-314 (coordinator farm)."""
+    torch = env.torch
+    from topowx_amd import _lib, driver, synth
+    T = args.strip_tile
+    t_s = time.perf_counter()
+    # rows of configs[2]'s grid south of 45 N (the C3 grid starts at 51.6 N): same generator, same mask seed
+    grid = synth.make_grid("C3", nrows=args.strip_rows, ncols=args.strip_cols, lat_north=45.0, full_mask=False)
+    tmin = synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmin")
+    tmax = synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmax")
+    ctx = _lib.Context(device=env.local)
+    ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
+    ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
+    tiles = driver.tile_list(grid["mask"], T, T)
+    assignment = driver.assign_tiles(tiles, env.world)
+    mine = assignment[env.rank]
+    nmax = max(len(a) for a in assignment)
+    dgrid = driver.upload_grid(grid, env.dev)
+    setup_s = time.perf_counter() - t_s
+    shape = grid["mask"].shape
+    state = {}
+    dev_ms, gather_ms, tile_wall = [], [], []
+
+    def step():
+        t0 = time.perf_counter()
+        buf, stat, ms = driver.interp_tiles_device(ctx, dgrid, mine, T, T, nslots=nmax)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if env.world > 1:
+            env.dist.barrier()          # so that gather_ms is the collective, not the wait for the slowest rank
+        t2 = time.perf_counter()
+        mosaic = driver.gather_mosaic_device(buf, assignment, shape, T, T, env.rank, env.world, backend=env.backend)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        state.update(buf=buf, stat=stat, mosaic=mosaic, ms=float(sum(ms)), tile_wall=t1 - t0, gather=(t3 - t2) * 1e3)
+
+    def after(keep):
+        if keep:
+            dev_ms.append(state["ms"]); gather_ms.append(state["gather"]); tile_wall.append(state["tile_wall"])
+
+    elapsed = timed(env, step, steps, warmup, after)
+    cells_ok = int(env.sum_over_ranks(int((state["stat"][:len(mine)] == 0).sum().item()) if mine else 0))
+    per_rank_ms = env.all_gather_scalar(float(np.mean(dev_ms)))
+    per_rank_wall = env.all_gather_scalar(float(np.mean(tile_wall)) * 1e3)
+    per_rank_cells = [sum(t[3] for t in a) for a in assignment]
+    units = cells_ok * 24
+    rec = {
+        "value": units * steps / elapsed, "unit": "cell-months/s (Tmin + Tmax normals, mean + SE each)",
+        "workload": "c3_strip: %dx%d cells of the seed-7 masked CONUS-shaped 30-arcsec grid (rows south of 45 N of "
+                    "BASELINE.json configs[2]), %d synthetic stations per variable, 12 monthly Tmin + Tmax normals + SE; "
+                    "%dx%d tiles dealt by topowx_amd.driver.assign_tiles" % (shape[0], shape[1], args.strip_nstns, T, T),
+        "n_gpus": env.world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "cells_valid": int((grid["mask"] != 0).sum()), "cells_ok": cells_ok, "tiles": len(tiles),
+        "tiles_per_rank": [len(a) for a in assignment], "valid_cells_per_rank": per_rank_cells,
+        "device_ms_per_rank": per_rank_ms, "tile_loop_wall_ms_per_rank": per_rank_wall,
+        "imbalance_max_over_mean": max(per_rank_ms) / max(1e-9, float(np.mean(per_rank_ms))),
+        "gather_ms": float(np.mean(gather_ms)),
+        "gather_bytes_per_rank": int(nmax * 4 * 12 * T * T * 4),
+        "gather": "one dist.gather of the [tiles, 4, 12, %d, %d] f4 device tensor per rank (%s)" % (
+            T, T, "RCCL over xGMI" if env.backend == "nccl" and env.world > 1 else
+            ("gloo through host memory: control-flow run" if env.world > 1 else "single rank: device copies only")),
+        "hbm": {"algorithmic_bytes_per_cell_month": ALG_BYTES_PER_CELL_MONTH_2V,
+                "achieved_GBps": ALG_BYTES_PER_CELL_MONTH_2V * units * steps / elapsed / 1e9,
+                "frac_of_peak": ALG_BYTES_PER_CELL_MONTH_2V * units * steps / elapsed / 1e9 / (HBM_PEAK_GBS * env.world)},
+        "setup_s": setup_s,
+    }
+    if env.rank == 0 and args.dump_mosaic:
+        np.savez(args.dump_mosaic, **{k: v.cpu().numpy() for k, v in state["mosaic"].items()})
+    if env.rank == 0 and spot_check and not args.no_cpu_baseline:
+        # a 6x6 window of valid cells of the mosaic against the oracle
+        from oracle import pyoracle as orc
+        orc.build()
+        m = grid["mask"] != 0
+        rr, cc = np.nonzero(m[:-6, :-6] & m[6:, 6:] & m[:-6, 6:] & m[6:, :-6])
+        worst, stat_eq = 0.0, True
+        if rr.size:
+            r0, c0 = int(rr[rr.size // 2]), int(cc[rr.size // 2])
+            rs, cs = slice(r0, r0 + 6), slice(c0, c0 + 6)
+            want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, nthreads=min(8, os.cpu_count() or 1), rows=rs, cols=cs)
+            okw = want["status"] == 0
+            for k in driver.NORMAL_KEYS:
+                got = state["mosaic"][k][:, rs, cs].cpu().numpy().astype(np.float64)
+                worst = max(worst, float(np.abs(got - want[k])[:, okw].max()) if okw.any() else 0.0)
+                stat_eq = stat_eq and bool(np.all(got[:, ~okw] == float(_lib.FILL_F4)))
+            rec["spot_check_vs_oracle"] = {"cells": 36, "window": [r0, c0], "max_abs_degC": worst, "fills_where_oracle_fails": stat_eq}
+    ctx.close()
+    return rec
+
+
+def config5_record(env, args):
+    """BASELINE.json configs[4]: leave-one-out cross-validation + bandwidth optimisation over all stations."""
+    from topowx_amd import xval
+    res, arr = xval.run_config5(args.nstns, args.c5_years, "tmin", 0, 0, 1, env.local, "cpu")
+    rec = dict(res)
+    rec["workload"] = ("c5: step21 (variogram fit + kriging), step23 (GWR series + statistics), step24 (normals + daily) over all "
+                       "%d cross-validated stations of the %d-station C2 database x 16 bandwidths x 12 months, %d years of days; "
+                       "bandwidth optimisation (optimize.py:268-374) between the steps" % (res["stations"], args.nstns, args.c5_years))
+    if not args.no_cpu_baseline:
+        # step21's leave-one-out errors of three stations x three bandwidths against the oracle
+        from oracle import pyoracle as orc
+        from topowx_amd import stationdb as sdb
+        orc.build()
+        stn = arr["stn"]
+        before = sdb.StationSerialDataDb(arr["stns_step21"], "tmin", stn.days, None)
+        db, prm = orc.Db(before), orc.params()
+        c = db.cols
+        good = np.isnan(before.stns[sdb.BAD])
+        idx = {s: i for i, s in enumerate(before.stns[sdb.STN_ID][good])}
+        worst, n = 0.0, 0
+        for q in np.random.default_rng(5).choice(arr["ids"].size, 3, replace=False):
+            j = idx[arr["ids"][q]]
+            pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+            for x in (0, 7, 13):
+                rc, want, _ = orc.krigall(db, prm, pt, int(xval.DFLT_LADDER[x]), excl=j, rm_zero_dist=True)
+                if rc == 0 and np.isfinite(arr["mae_norm"][:, x, q]).all():
+                    worst = max(worst, float(np.abs(arr["mae_norm"][:, x, q] - np.abs(want - c["norm"][:, j])).max()))
+                    n += 12
+        rec["spot_check_vs_oracle"] = {"step21_values": n, "max_abs_degC": worst}
+    return rec
+
+
+# =====================================================================================================================
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)
 
-    import torch
-    import torch.distributed as dist
+    env = Env()
+    torch = env.torch
     from topowx_amd import _lib, synth
+    world, rank, dev = env.world, env.rank, env.dev
+    scaling = args.scaling
+    top_strong = scaling == "strong"
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # TWX_BENCH_BACKEND=gloo + TWX_BENCH_SHARE_GPU=1: control-flow check of the N > 1 path on a 1-GPU box
-    backend = os.environ.get("TWX_BENCH_BACKEND", "nccl")
-    shared = os.environ.get("TWX_BENCH_SHARE_GPU") == "1"
-    if shared:
-        local = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if top_strong:
+        rec = strip_run(env, args, args.steps, args.warmup, spot_check=world == 1)
+        if rank == 0:
+            res = {"metric": "grid-cell-days interpolated/sec", "value": rec["value"],
+                   "unit": "cell-months/s (normals config: one time step = one calendar month, mean + SE)",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": rec["workload"], "cells_ok": rec["cells_ok"],
+                              "parallelism": "tiles of ONE grid dealt over %d GPU(s) (LPT), station table replicated, "
+                                             "normals mosaic gathered on rank 0" % world},
+                   "roofline": {"bound": "hbm", "achieved": rec["hbm"]["achieved_GBps"], "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                "frac": rec["hbm"]["frac_of_peak"], "traffic": None,
+                                "note": "whole-job figure (all ranks); the per-kernel roofline is in the N = 1 headline line"},
+                   "strong": rec}
+            if env.shared:
+                res["note"] = "control-flow run: %d ranks share ONE GPU over gloo (fewer GPUs than ranks); not a scaling figure" % world
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            env.dist.destroy_process_group()
+        return
 
     # ---- synthetic workload -----------------------------------------------------------------
     # Every rank holds the SAME replicated station table (the N = 1 table) and interpolates its own
@@ -132,7 +486,7 @@ def main():
         grid = synth.make_grid("C2", nrows=Y, ncols=X, lon_west=-111.0 + 0.125 * (rank % 4),
                                lat_north=46.0 - 0.125 * (rank // 4))
 
-    ctx = _lib.Context(device=local)
+    ctx = _lib.Context(device=env.local)
     ctx.set_stations(_lib.TMIN, stn, with_obs=False)
 
     def up(a):
@@ -150,30 +504,9 @@ def main():
                         d_stat.data_ptr())
     stream = torch.cuda.current_stream().cuda_stream
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(step):
-        """W untimed + K timed steps between barrier + synchronize; max over ranks; per-step kernel timings."""
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        kern = []
-        for _ in range(args.steps):
-            step()
-            kern.append(ctx.timing())       # HIP events on the launch stream (synchronises this step)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        return elapsed, kern
-
-    elapsed, kern = timed(lambda: ctx.interp_grid_dev(g, o, _lib.VAR_TMIN_BIT, stream))
+    kern = []
+    elapsed = timed(env, lambda: ctx.interp_grid_dev(g, o, _lib.VAR_TMIN_BIT, stream), args.steps, args.warmup,
+                    lambda keep: kern.append(ctx.timing()) if keep else ctx.timing())   # HIP events on the launch stream (synchronises the step)
     status = d_stat.cpu().numpy()
     ncell_ok = int((status == 0).sum())
     units_per_step = ncell_ok * 12                     # (cell, month) outputs, each mean + SE
@@ -186,15 +519,18 @@ def main():
     ach_gbs = ALG_BYTES_PER_CELL_MONTH * solves / (uk_ms * 1e-3) / 1e9
     # bandwidths actually used by the timed steps (diagnostic accessor, no extra launches)
     ks = ctx.last_bandwidths(_lib.TMIN).ravel()
-    flops_per_solve = float(uk_flops(ks[ks > 0]).mean())
+    kpos = ks[ks > 0]
+    flops_per_solve = float(uk_flops(kpos).mean())
+    flops_exec = float(uk_flops_executed(kpos).mean())
     # systems per kriging launch: matrix rows (k + 8, rounded up to the kernel's size) -> count
     edges = np.array([40, 48, 56, 64, 72, 80, 88, 96, 112, 128, 144, 160])
-    rows_hist = np.bincount(np.searchsorted(edges, ks[ks > 0] + 8), minlength=edges.size + 1)
+    rows_hist = np.bincount(np.searchsorted(edges, kpos + 8), minlength=edges.size + 1)
     ach_tflops = flops_per_solve * solves / (uk_ms * 1e-3) / 1e12
+    ach_tflops_exec = flops_exec * solves / (uk_ms * 1e-3) / 1e12
     # PMC counters cannot be read from inside the process: the committed measurement of THIS workload is quoted
-    traffic, traffic_src = (None, None)
+    traffic, daily_traffic, traffic_src = (None, None, None)
     if world == 1 and args.size == 250 and args.nstns == 10000:
-        traffic, traffic_src = latest_traffic()
+        traffic, daily_traffic, traffic_src = latest_traffic()
 
     res = {
         "metric": "grid-cell-days interpolated/sec",
@@ -206,7 +542,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C2: one %dx%d 30-arcsec tile per GPU, %d synthetic stations, 12 monthly Tmin "
                                "normals + SE (BASELINE.json configs[1])" % (Y, X, ctx.nstn[_lib.TMIN]),
-                   "cells_ok": ncell_ok, "mean_nnghs": float(ks[ks > 0].mean()),
+                   "cells_ok": ncell_ok, "mean_nnghs": float(kpos.mean()),
                    "parallelism": "tiles partitioned over %d GPU(s), station table replicated" % world},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
@@ -217,96 +553,27 @@ def main():
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},
         "fp64": {"achieved": ach_tflops, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach_tflops / FP64_VEC_PEAK_TFLOPS, "flops_per_solve": flops_per_solve,
+                 # what the fraction is made of: the nominal figure counts ~60 flops per station pair of EVERY system
+                 # (SURVEY 8d); the kernels evaluate each pair once per tile (k_tile_dist), so that term is not executed
+                 "frac_executed": ach_tflops_exec / FP64_VEC_PEAK_TFLOPS, "achieved_executed": ach_tflops_exec,
+                 "flops_per_solve_executed": flops_exec,
+                 "distance_flops_share": float(uk_flops_distance(kpos).mean()) / flops_per_solve,
+                 "note": "frac = SURVEY 8d's nominal flops (k^3/3 + 7k^2 + 30k(k-1)) / kernel time / peak; frac_executed counts "
+                         "k^3/3 + 7k^2 only (Cholesky + border rows)",
                  "systems_by_matrix_rows": {str(int(e)): int(c) for e, c in zip(edges, rows_hist) if c}},
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},
     }
-    if shared:
+    if env.shared:
         res["note"] = "control-flow run: %d ranks share ONE GPU over gloo (fewer GPUs than ranks); not a scaling figure" % world
 
+    import datetime as dt
     # ---- daily record: the path that produces cell-DAYS (N = 1) --------------------------------------
     if world == 1 and not args.no_daily:
-        import datetime as dt
-        from topowx_amd.dates import get_days_metadata
-        days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + args.daily_years, 12, 31))
-        nd = int(days.size)
-        sn = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmin", days, with_obs=True)
-        sx = synth.make_stations(base["bbox"], args.nstns, synth.CONFIGS["C2"][5], "tmax", days, with_obs=True)
-        ctx.set_stations(_lib.TMIN, sn)
-        ctx.set_stations(_lib.TMAX, sx)
-        outs = {k: torch.full((12, Y, X), float(_lib.FILL_F4), dtype=torch.float32, device=dev)
-                for k in ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")}
-        d_dn = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
-        d_dx = torch.full((nd, Y, X), int(_lib.FILL_I2), dtype=torch.int16, device=dev)
-        o2 = _lib.TwxGridOut(outs["norm_tmin"].data_ptr(), outs["se_tmin"].data_ptr(), outs["norm_tmax"].data_ptr(),
-                             outs["se_tmax"].data_ptr(), d_dn.data_ptr(), d_dx.data_ptr(), d_ninv.data_ptr(),
-                             d_stat.data_ptr())
-        both = _lib.VAR_TMIN_BIT | _lib.VAR_TMAX_BIT
-        el2, k2 = timed(lambda: ctx.interp_grid_dev(g, o2, both, stream))
-        ok2 = int((d_stat.cpu().numpy() == 0).sum())
-        cell_days = ok2 * nd * 2
-        tm = {k: float(np.mean([t[k] for t in k2])) for k in ("tile_cand_ms", "select_ms", "uk_ms", "gwr_ms",
-                                                              "daily_ms", "fix_ms", "total_ms")}
-        kan = ctx.last_bandwidths(_lib.TMIN).ravel()      # kriging bandwidths (GWR ones are of the same ladder)
-        dgbs = ALG_BYTES_PER_CELL_DAY * cell_days / (tm["daily_ms"] * 1e-3) / 1e9
-        res["daily"] = {
-            "value": cell_days * args.steps / el2, "unit": "cell-days/s (whole path: selection + 24 normals per cell + GWR + "
-                                                          "daily int16 + fixer, outputs resident in HBM)",
-            "workload": "the same %dx%d tile and %d stations per variable, Tmin + Tmax, %d days (%d years), int16 daily "
-                        "outputs + normals + SE + ninvalid" % (Y, X, args.nstns, nd, args.daily_years),
-            "ms_per_step": el2 / args.steps * 1e3, "cell_days_per_step": cell_days, "cells_ok": ok2,
-            "timing_ms": tm,
-            "daily_kernel": {"kernel": "k_tile_union + k_daily_tile (+ k_row_offsets, k_daily_ok, k_daily_tile_gather)", "ms_per_step": tm["daily_ms"],
-                             "cell_days_per_s": cell_days / (tm["daily_ms"] * 1e-3),
-                             "roofline": {"bound": "hbm", "achieved": dgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": dgbs / HBM_PEAK_GBS,
-                                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_DAY * cell_days,
-                                          "note": "every cell-day is a ~80-term dot product over observation rows; the rows "
-                                                  "of a tile-month are staged in LDS (VALU / LDS bound), DESIGN.md section 4"}},
-            "mean_nnghs": float(kan[kan > 0].mean()),
-        }
-        # packed int16 days against the oracle on a 4 x 4 window (integer output: identical except isolated +-1 LSB
-        # where the fp64 value sits on a 0.005 rounding boundary and the summation order decides)
-        if not args.no_cpu_baseline:
-            from oracle import pyoracle as orc
-            orc.build()
-            r0w, c0w = min(100, Y - 4), min(60, X - 4)          # (inside the tile also for reduced --size runs)
-            rs, cs = slice(r0w, r0w + 4), slice(c0w, c0w + 4)
-            want = orc.interp_grid(orc.Db(sn), orc.Db(sx), orc.params(), grid, daily=True, nthreads=os.cpu_count() or 1,
-                                   rows=rs, cols=cs)
-            dd = np.concatenate([np.abs(d_dn[:, rs, cs].cpu().numpy().astype(np.int32) - want["daily_tmin"].astype(np.int32)).ravel(),
-                                 np.abs(d_dx[:, rs, cs].cpu().numpy().astype(np.int32) - want["daily_tmax"].astype(np.int32)).ravel()])
-            res["daily"]["packed_int16_vs_oracle"] = {"cells": 16, "values": int(dd.size), "identical_frac": float((dd == 0).mean()),
-                                                      "max_abs_lsb": int(dd.max()),
-                                                      "ninvalid_equal": bool(np.array_equal(d_ninv[rs, cs].cpu().numpy(), want["ninvalid"]))}
-        del d_dn, d_dx, outs, sn, sx
-        torch.cuda.empty_cache()
-        # the same tile streamed: outputs of tile t travel to pinned host memory while tile t + 1 is computed
-        # (twx_stream_*); end to end = host wall clock from the first submit to the last tile in host memory
-        if args.stream_tiles > 0:
-            ts = ctx.stream(Y, X, daily=True, nslots=2)
-            ts.submit(0, grid); ts.wait(0)                       # warm-up: workspace, pinned pages
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            dev_ms = 0.0
-            for i in range(args.stream_tiles):
-                ts.submit(i & 1, grid)
-                if i:
-                    dev_ms += ts.wait((i - 1) & 1)["device_ms"]
-            last = ts.wait((args.stream_tiles - 1) & 1)
-            dev_ms += last["device_ms"]
-            wall = time.perf_counter() - t1
-            okc = int((last["status"] == 0).sum())
-            out_bytes = sum(v.nbytes for k, v in last.items() if hasattr(v, "nbytes"))
-            ts.close()
-            e2e = okc * nd * 2 * args.stream_tiles / wall
-            res["daily"]["stream"] = {
-                "tiles": args.stream_tiles, "end_to_end_cell_days_per_s": e2e,
-                "device_only_cell_days_per_s": okc * nd * 2 * args.stream_tiles / (dev_ms * 1e-3),
-                "ratio": e2e / (okc * nd * 2 * args.stream_tiles / (dev_ms * 1e-3)),
-                "wall_s": wall, "device_ms_per_tile": dev_ms / args.stream_tiles,
-                "d2h_bytes_per_tile": out_bytes, "d2h_GBps_if_exposed": out_bytes * args.stream_tiles / wall / 1e9,
-                "note": "host pointers in, pinned host memory out (PCIe-inclusive; never the headline value)"}
+        res["daily"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(1981, 1, 1),
+                                    dt.date(1980 + args.daily_years, 12, 31), "C2 tile, %d years" % args.daily_years,
+                                    args.steps, args.warmup, args.stream_tiles, args.int16_window,
+                                    daily_traffic if args.daily_years == 10 else None, traffic_src)
 
     # ---- CPU baseline: the oracle on bounded samples of the headline workload ---------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -342,7 +609,6 @@ def main():
             for (r, q, m) in ((17 % Y, 200 % X, 1), (120 % Y, 40 % X, 7)):   # (inside the tile also for reduced --size runs)
                 pts = ctx.make_pts(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
                 mean, var, used, st, ngh = ctx.krig_points(_lib.TMIN, pts, m, want_idx=True)
-                pt = orc.make_pt(grid["lon"][q], grid["lat"][r], grid["elev"][r, q], grid["tdi"][r, q], grid["lst_night"][:, r, q])
                 vp = np.zeros(3)
                 import ctypes as C
                 rc, idx, _, wgt = orc.select(db, grid["lat"][r], grid["lon"][q], int(used[0]))
@@ -359,11 +625,46 @@ def main():
             res["parity_vs_arbiter_max_abs_degC"] = worst
         except ImportError:
             pass
+
+    # ---- the other BASELINE.json configurations, driver-timed in the same line (N = 1) ----------------
+    if world == 1 and not args.no_configs and (args.size == 250 or args.force_configs):
+        want_cfg = [c for c in args.configs.split(",") if c]
+        cfg = {}
+        if "c4_tile" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c4_tile"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(1948, 1, 1), dt.date(2016, 12, 31),
+                                          "c4_tile (BASELINE.json configs[3], one tile)", 3, 1, 0, 2)
+            cfg["c4_tile"]["record_wall_s"] = time.perf_counter() - t1
+        ctx.close()
+        ctx = None
+        del d_in, d_norm, d_se
+        torch.cuda.empty_cache()
+        if "c5" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c5"] = config5_record(env, args)
+            cfg["c5"]["record_wall_s"] = time.perf_counter() - t1
+        if "c3_strip" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c3_strip"] = strip_run(env, args, args.strong_steps, 1, spot_check=True)
+            cfg["c3_strip"]["record_wall_s"] = time.perf_counter() - t1
+        res["configs"] = cfg
+    if ctx is not None:
+        ctx.close()
+        ctx = None
+
+    # ---- N > 1: the tile farm on one fixed grid next to the weak headline ------------------------------
+    if world > 1 and scaling == "auto":
+        del d_in, d_norm, d_se
+        torch.cuda.empty_cache()
+        rec = strip_run(env, args, args.strong_steps, 1, spot_check=False)
+        rec["scaling"] = "strong"
+        rec["note"] = ("total work fixed as N grows; the N = 1 counterpart is configs.c3_strip of the N = 1 line "
+                       "(same code path: topowx_amd.driver)")
+        res["strong"] = rec
     if rank == 0:
         print(json.dumps(res), flush=True)
-    ctx.close()
     if world > 1:
-        dist.destroy_process_group()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

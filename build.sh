@@ -1,6 +1,17 @@
 #!/bin/bash
 # Build libtwxhip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+# The compiler's per-kernel resource remarks (VGPRs / AGPRs / scratch / LDS / occupancy) are reduced into
+# topowx_amd/libtwxhip.resources.txt: tests/test_isa_resources.py fails when a kriging / daily kernel spills or
+# outgrows the register budget its waves_per_eu tuning assumes (a compiler bump would otherwise cost 10-20 % silently).
 set -e
 cd "$(dirname "$0")"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Iinclude -Itopowx_amd/csrc \
-    "$@" -o topowx_amd/libtwxhip.so topowx_amd/csrc/twx_hip.hip
+LOG=$(mktemp /tmp/twx_build.XXXXXX)
+if ! hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Iinclude -Itopowx_amd/csrc \
+    -Rpass-analysis=kernel-resource-usage "$@" -o topowx_amd/libtwxhip.so topowx_amd/csrc/twx_hip.hip 2> "$LOG"; then
+    grep -v "Rpass-analysis=kernel-resource-usage\|^ *[0-9]* | \|^ *| \|^In file included from" "$LOG" >&2 || true
+    rm -f "$LOG"
+    exit 1
+fi
+grep -v "Rpass-analysis=kernel-resource-usage\|^ *[0-9]* | \|^ *| \|^In file included from" "$LOG" >&2 || true
+python3 tests/tools/isa_resources.py "$LOG" > topowx_amd/libtwxhip.resources.txt
+rm -f "$LOG"

@@ -47,6 +47,11 @@ extern "C" {
 #define TWX_CELL_NUMERIC 4      /* FloatingPointError (np.seterr, step25:319) / singular kriging system */
 #define TWX_CELL_FIXER 5        /* 'No valid tmin/tmax in window' interp_tair.py:192 */
 #define TWX_CELL_RANGE 6        /* bandwidth above TWX_MAX_NNGHS */
+#define TWX_CELL_CAND_OVERFLOW 7 /* library limit, no reference counterpart: the candidate list of the cell's 8x8-cell tile
+                                  * (stations that can be among the nearest TWX_MAX_NNGHS + 1 of any of its cells) holds
+                                  * more than 2 048 stations (512 per point in the point entries): the cell is failed
+                                  * rather than ranked from a truncated list.  Only reached by station clusters far
+                                  * denser than the grid (> 2 048 stations within ~10 km). */
 #define TWX_CELL_MASKED (-1)    /* cell outside the interpolation mask: nothing computed */
 
 /* netCDF4 default fill values the reference worker pre-fills with (step25:73-88) */
@@ -69,7 +74,8 @@ typedef struct {
 } twx_params;
 
 /* address the observation matrix with 64-bit element offsets even when it is smaller than 4 GiB (the
- * path a > 4 GiB matrix takes; results are bit-identical -- a test / diagnostic switch) */
+ * path a > 4 GiB matrix takes -- a test / diagnostic switch).  It implies TWX_FLAG_DAILY_GATHER, see there for
+ * how the results compare with the default path. */
 #define TWX_FLAG_OBS_ADDR64 1
 /* twx_interp_grid_dev / twx_stream_submit enqueue a whole batch without ANY host synchronisation: the kriging
  * launches then cover the worst case and surplus work-groups exit at once (about +9 % kriging time on the C2 tile).
@@ -77,8 +83,17 @@ typedef struct {
  * waits for the selection kernels; everything after them -- kriging, GWR, daily values, fixer -- is asynchronous. */
 #define TWX_FLAG_NO_HOST_SYNC 2
 /* daily values: gather every (cell, neighbour) observation row from global memory instead of staging the rows of a
- * tile-month in LDS (the path a tile-month with more than 224 distinct rows takes; results are bit-identical -- a
- * test / diagnostic switch).  TWX_FLAG_OBS_ADDR64 implies it. */
+ * tile-month in LDS (the path a tile-month with more than 224 distinct rows takes -- a test / diagnostic switch;
+ * TWX_FLAG_OBS_ADDR64 implies it).  The two gather forms (32- / 64-bit addressing) and the fixer's recompute add a
+ * cell-day's terms in neighbour-rank order and agree bit for bit; the default LDS-table path adds the same terms in
+ * table (station-index) order, so its fp64 sums differ from theirs in the last bits: packed int16 values are identical
+ * up to isolated +-1 LSB (a value within rounding distance of a 0.005 degC boundary), and a day with tmin within an
+ * ulp of tmax can be flagged for the fixer by one path and not the other.  Which path a tile-month takes depends on
+ * its station union (<= 224 rows: table), i.e. on tiling and station density.
+ * Precondition of every daily path: observations are finite (the reference's database is serially complete,
+ * station_data.py:547-616); twx_set_stations rejects a table whose obs hold NaN / Inf, because the table walk
+ * multiplies every row of a tile-month by every cell's weight (0 for rows a cell does not use: 0 * NaN = NaN would
+ * reach all 64 cells of the tile). */
 #define TWX_FLAG_DAILY_GATHER 4
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
@@ -233,11 +248,14 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *grid_dev, const twx_grid_o
 /* ---- streamed tiles: the worker writes every chunk as soon as it is finished (step25:177-185,
  * tiling.py:488-537).  A twx_stream owns two device images and nslots pinned host blocks for tiles of one shape;
  * twx_stream_submit copies the predictors of a tile (host pointers) up, enqueues its kernels on the stream's own
- * compute stream and the copy-out of all outputs on a second (copy) stream, and returns at once: the copy-out of
- * tile t overlaps the kernels of tile t + 1.  twx_stream_wait blocks until the slot's outputs are in host memory
+ * compute stream and the copy-out of all outputs on a second (copy) stream: the copy-out of
+ * tile t overlaps the kernels of tile t + 1.  The call is fully asynchronous only with TWX_FLAG_NO_HOST_SYNC; by
+ * default it returns once the tile's selection kernels are done (one 64-byte read-back per variable, i.e. after the
+ * previous tile's kernels have drained), with kriging, GWR, daily values, fixer and copy-out still in flight.  twx_stream_wait blocks until the slot's outputs are in host memory
  * and returns pointers into the slot's pinned block (valid until the slot is submitted again); device_ms
  * (optional) = device time of the tile's kernels.  One stream per context at a time; do not mix with other
- * calls on the context while tiles are in flight. */
+ * calls on the context while tiles are in flight.  twx_destroy destroys a context's open streams (their handles are
+ * dead afterwards: do not pass them to twx_stream_destroy). */
 typedef struct twx_stream twx_stream;
 int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslots, twx_stream **out);
 int twx_stream_submit(twx_stream *st, int slot, const twx_grid *grid);

@@ -44,7 +44,49 @@ def test_bench_line_contract():
     assert dd["value"] > 0 and dd["packed_int16_vs_oracle"]["max_abs_lsb"] <= 1 and dd["stream"]["tiles"] == 2
 
 
+SMALL_STRIP = ("--strip-rows", "100", "--strip-cols", "400", "--strip-tile", "50", "--strip-nstns", "2500")
+
+
 def test_bench_spawns_ranks_itself():
-    d = _run("--gpus", "2", "--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1")
+    d = _run("--gpus", "2", "--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1", "--strong-steps", "1", *SMALL_STRIP)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "daily" not in d and "cpu_baseline" not in d          # rank-0, N = 1 records only
+    s = d["strong"]                                              # ... and the tile farm on one fixed grid next to it
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["value"] > 0 and len(s["device_ms_per_rank"]) == 2
+    assert sum(s["tiles_per_rank"]) == s["tiles"] and s["cells_ok"] == s["cells_valid"] and s["imbalance_max_over_mean"] >= 1.0
+
+
+def test_bench_strong_two_ranks_equal_one_rank(tmp_path):
+    """--scaling strong: ONE masked grid, tiles dealt by driver.assign_tiles, every rank's tiles computed device-resident,
+    the mosaic gathered on rank 0 (driver.gather_mosaic_device).  Two ranks (fresh children; on a 1-GPU box they share
+    the GPU and the collective runs over gloo) give the mosaic of one rank bit for bit."""
+    import numpy as np
+    outs = []
+    for n in (1, 2):
+        path = str(tmp_path / ("mosaic%d.npz" % n))
+        d = _run("--gpus", str(n), "--scaling", "strong", "--steps", "1", "--warmup", "0", "--dump-mosaic", path, *SMALL_STRIP)
+        assert d["scaling"] == "strong" and d["n_gpus"] == n and d["value"] > 0
+        s = d["strong"]
+        assert s["cells_ok"] == s["cells_valid"] > 0 and len(s["tiles_per_rank"]) == n and s["gather_ms"] >= 0
+        if n == 1:
+            assert s["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4 and s["spot_check_vs_oracle"]["fills_where_oracle_fails"]
+        outs.append(np.load(path))
+    assert sorted(outs[0].files) == ["norm_tmax", "norm_tmin", "se_tmax", "se_tmin"]
+    for k in outs[0].files:
+        assert outs[0][k].shape == (12, 100, 400) and np.array_equal(outs[0][k], outs[1][k]), k
+    assert (outs[0]["norm_tmin"] != np.float32(9.969209968386869e36)).mean() > 0.3      # the masked grid has valid cells
+
+
+def test_bench_other_configs_reduced():
+    """The c4_tile / c5 / c3_strip records of the default line, on reduced sizes (--force-configs)."""
+    d = _run("--size", "64", "--nstns", "2500", "--steps", "1", "--warmup", "1", "--no-daily", "--cpu-sample", "16",
+             "--force-configs", "--c5-years", "1", "--strong-steps", "1", *SMALL_STRIP)
+    c = d["configs"]
+    t = c["c4_tile"]
+    assert t["value"] > 0 and t["cell_days_per_step"] == t["cells_ok"] * 25203 * 2 and t["cells_ok"] == 64 * 64
+    assert t["packed_int16_vs_oracle"]["max_abs_lsb"] <= 1 and t["packed_int16_vs_oracle"]["ninvalid_equal"]
+    x = c["c5"]
+    assert x["step21_s"] > 0 and x["step23_s"] > 0 and x["step24_s"] > 0 and x["stations"] > 2000
+    assert x["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4 and x["spot_check_vs_oracle"]["step21_values"] > 0
+    s = c["c3_strip"]
+    assert s["value"] > 0 and s["cells_ok"] == s["cells_valid"] and s["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4

@@ -98,8 +98,9 @@ def test_all_stations_leave_one_out_normals(orc):
 
 
 def test_daily_64bit_obs_addressing_equals_32bit(golden_case):
-    """The three ways a daily value is formed give the same packed values (the two gathers sum in rank order and agree in
-    fp64, the LDS-table kernel sums in table order: last-bit differences far below the int16 step): rows of the tile-month staged in LDS (default),
+    """The three ways a daily value is formed: the two gathers sum in rank order and agree bit for bit; the LDS-table
+    kernel sums in table order (last-bit differences in fp64: packed values identical up to isolated +-1 LSB):
+    rows of the tile-month staged in LDS (default),
     gathered from global memory with 32-bit offsets (a tile-month with too many distinct rows; TWX_FLAG_DAILY_GATHER)
     and with 64-bit offsets (stations x days >= 2^30; TWX_FLAG_OBS_ADDR64)."""
     from topowx_amd import _lib
@@ -113,11 +114,22 @@ def test_daily_64bit_obs_addressing_equals_32bit(golden_case):
         ctx.set_stations(_lib.TMAX, tmax)
         outs.append(ctx.interp_grid(grid, daily=True, rows=slice(40, 75), cols=slice(3, 70)))
         ctx.close()
-    a = outs[0]
+    a, g32, g64 = outs
     assert np.all(a["status"] == 0) and a["ninvalid"].max() > 0
-    for b in outs[1:]:
-        for k in a:
-            assert np.array_equal(a[k], b[k]), k
+    # the two gather forms add a cell-day's terms in the same (rank) order: bit for bit
+    for k in g32:
+        assert np.array_equal(g32[k], g64[k]), k
+    # the LDS-table path adds them in table order (include/twx.h, TWX_FLAG_DAILY_GATHER): normals / SE / status are the
+    # same kernels; packed days agree up to isolated +-1 LSB, and where a day sits within an ulp of tmin == tmax the
+    # fixer flag -- hence ninvalid and the fixed days around it -- may differ
+    for k in ("status", "norm_tmin", "se_tmin", "norm_tmax", "se_tmax"):
+        same = a["ninvalid"] == g32["ninvalid"]
+        assert np.array_equal(a[k][..., same], g32[k][..., same]), k
+    same = a["ninvalid"] == g32["ninvalid"]
+    assert same.mean() > 0.99
+    for k in ("daily_tmin", "daily_tmax"):
+        dd = np.abs(a[k].astype(np.int32) - g32[k].astype(np.int32))[:, same]
+        assert dd.max() <= 1 and (dd != 0).mean() < 1e-3, (k, int(dd.max()), float((dd != 0).mean()))
 
 
 def test_singular_gwr_abandons_the_cell(golden_case, orc):
@@ -170,7 +182,7 @@ def test_destroy_returns_all_device_memory():
 
 def test_single_variable_daily_equals_two_variable_run(golden_case):
     """A one-variable daily request runs the strip kernel (k_daily_grid), the two-variable request the tile kernel
-    (k_daily_tile): same values, bit for bit, where the fixer has nothing to do."""
+    (k_daily_tile): same normals bit for bit, same packed days up to isolated +-1 LSB, where the fixer has nothing to do."""
     from topowx_amd import _lib
     grid, tmin, tmax = golden_case
     ctx = _lib.Context()
@@ -182,7 +194,10 @@ def test_single_variable_daily_equals_two_variable_run(golden_case):
     one_x = ctx.interp_grid(grid, variables=("tmax",), daily=True, rows=rs, cols=cs)
     ctx.close()
     assert np.all(both["status"] == 0) and both["ninvalid"].max() == 0
-    assert np.array_equal(one_n["daily_tmin"], both["daily_tmin"]) and np.array_equal(one_x["daily_tmax"], both["daily_tmax"])
+    # (rank-order sums there, table-order sums here: identical up to isolated +-1 LSB, include/twx.h)
+    for one, k in ((one_n, "daily_tmin"), (one_x, "daily_tmax")):
+        dd = np.abs(one[k].astype(np.int32) - both[k].astype(np.int32))
+        assert dd.max() <= 1 and (dd != 0).mean() < 1e-3, (k, int(dd.max()), float((dd != 0).mean()))
     assert np.array_equal(one_n["norm_tmin"], both["norm_tmin"]) and np.array_equal(one_x["se_tmax"], both["se_tmax"])
 
 

@@ -84,3 +84,81 @@ def test_daily_tile_windows_and_sampled_cells(orc):
             assert dd.max() <= 1 and (dd == 0).mean() > 0.999, (k, r, c)
         for k in ("norm_tmin", "norm_tmax"):
             assert np.abs(full[k][:, r, c].astype(np.float64) - want[k][:, 0, 0]).max() < 1e-4
+
+
+def test_c1_every_cell_vs_oracle(orc):
+    """BASELINE.json configs[0] exactly -- synth.make_case("C1"): 100 x 100 cells, 500 stations, seed 0 -- Tmin + Tmax
+    normals + SE of EVERY cell against the oracle (status equal, <= 1e-4 degC), and the daily path (one year) on a
+    32 x 32 block: packed days within 1 LSB, ninvalid equal; the block's int16 flip rate is printed."""
+    import datetime as dt
+    from topowx_amd import _lib, synth
+    from topowx_amd.dates import get_days_metadata
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 12, 31))
+    grid, tmin, tmax = synth.make_case("C1", with_obs=True, days=days)
+    assert grid["mask"].shape == (100, 100) and tmin.stns.size <= 500 and tmin.stns.size > 490
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    got = ctx.interp_grid(grid)
+    rs, cs = slice(34, 66), slice(50, 82)
+    gd = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    ctx.close()
+    dbn, dbx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
+    want = orc.interp_grid(dbn, dbx, prm, grid, nthreads=8)
+    assert np.array_equal(got["status"], want["status"])
+    ok = want["status"] == 0
+    assert ok.mean() > 0.9
+    for k in ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax"):
+        err = np.abs(got[k].astype(np.float64) - want[k])[:, ok].max()
+        assert err < 1e-4, (k, err)
+        assert np.all(got[k][:, ~ok] == _lib.FILL_F4)
+    wd = orc.interp_grid(dbn, dbx, prm, grid, daily=True, nthreads=8, rows=rs, cols=cs)
+    assert np.array_equal(gd["status"], wd["status"]) and np.array_equal(gd["ninvalid"], wd["ninvalid"])
+    okd = wd["status"] == 0
+    flips = total = 0
+    for k in ("daily_tmin", "daily_tmax"):
+        dd = np.abs(gd[k].astype(np.int32) - wd[k].astype(np.int32))[:, okd]
+        assert dd.max() <= 1, k
+        flips += int((dd != 0).sum()); total += dd.size
+    print("C1 32x32 block: int16 flip rate %.3g (%d of %d values)" % (flips / total, flips, total))
+    assert flips / total < 1e-3
+
+
+def test_full_day_axis_1948_2016(orc):
+    """The day axis of BASELINE.json configs[3] (1948-01-01 .. 2016-12-31, 25 203 days) on a 64 x 64 cut of the C2 tile
+    (2 500 stations bound the synthetic observations to 2 x 0.25 GB): every cell done, windows == full tile bit for
+    bit, four cells against the oracle incl. ninvalid; the tile-scale int16 flip rate of those cells is printed."""
+    import datetime as dt
+    from topowx_amd import _lib, synth
+    from topowx_amd.dates import get_days_metadata
+    days = get_days_metadata(dt.date(1948, 1, 1), dt.date(2016, 12, 31))
+    assert days.size == 25203
+    grid = synth.make_grid("C2", nrows=64, ncols=64)
+    tmin = synth.make_stations(grid["bbox"], 2500, 1, "tmin", days, with_obs=True)
+    tmax = synth.make_stations(grid["bbox"], 2500, 1, "tmax", days, with_obs=True)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    full = ctx.interp_grid(grid, daily=True)
+    assert np.all(full["status"] == 0) and full["daily_tmin"].shape == (25203, 64, 64)
+    assert (full["daily_tmin"] != _lib.FILL_I2).all() and (full["daily_tmax"] != _lib.FILL_I2).all()
+    rs, cs = slice(16, 35), slice(40, 64)
+    win = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    ctx.close()
+    for k in ("daily_tmin", "daily_tmax", "norm_tmin", "norm_tmax", "se_tmin", "se_tmax", "ninvalid"):
+        assert np.array_equal(win[k], full[k][..., rs, cs]), k
+    dbn, dbx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
+    flips = total = 0
+    fixed = np.argwhere(full["ninvalid"] > 0)
+    cells = [(5, 9), (33, 60), (63, 0)] + ([tuple(fixed[0])] if fixed.size else [(20, 20)])
+    for r, c in cells:
+        want = orc.interp_grid(dbn, dbx, prm, grid, daily=True, nthreads=8, rows=slice(r, r + 1), cols=slice(c, c + 1))
+        assert want["status"][0, 0] == 0 and want["ninvalid"][0, 0] == full["ninvalid"][r, c]
+        for k in ("daily_tmin", "daily_tmax"):
+            dd = np.abs(full[k][:, r, c].astype(np.int32) - want[k][:, 0, 0].astype(np.int32))
+            assert dd.max() <= 1, (k, r, c)
+            flips += int((dd != 0).sum()); total += dd.size
+        for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+            assert np.abs(full[k][:, r, c].astype(np.float64) - want[k][:, 0, 0]).max() < 1e-4
+    print("25 203-day axis: int16 flip rate %.3g (%d of %d values, 4 cells)" % (flips / total, flips, total))
+    assert flips / total < 1e-3

@@ -44,7 +44,7 @@ def test_tile_stream_equals_synchronous_entry(golden_case):
 def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
     """A cluster of stations far denser than the tile size: the candidate lists of its tiles outgrow the 512-slot LDS
     path.  Up to 2 048 candidates the full-list kernel ranks them (results = oracle, which searches all stations);
-    beyond that the cells fail with TWX_CELL_RANGE instead of using a truncated list."""
+    beyond that the cells fail with TWX_CELL_CAND_OVERFLOW instead of using a truncated list."""
     from topowx_amd import _lib, stationdb as sdb, synth
     grid, tmin, _ = golden_case
     rng = np.random.default_rng(9)
@@ -59,7 +59,7 @@ def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
     got = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
     ctx.close()
     if expect_range:
-        assert np.all(got["status"] == 6) and np.all(got["norm_tmin"] == _lib.FILL_F4)
+        assert np.all(got["status"] == 7) and np.all(got["norm_tmin"] == _lib.FILL_F4)
         return
     assert np.all(got["status"] == 0)
     want = orc.interp_grid(orc.Db(db), None, orc.params(), grid, nthreads=8, rows=rs, cols=cs)

@@ -1,0 +1,69 @@
+"""CPU: the register / scratch / LDS budget of the built kernels (topowx_amd/libtwxhip.resources.txt, written by build.sh
+from hipcc's -Rpass-analysis=kernel-resource-usage remarks).  The kriging and daily kernels are tuned to a number of
+resident waves per SIMD (amdgpu_waves_per_eu in twx_uk.h / twx_ukw.h, the LDS footprint of k_daily_tile): a compiler
+bump that adds registers or starts spilling would cost 10-20 % without any test noticing.  This one notices."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+RES = os.path.join(ROOT, "topowx_amd", "libtwxhip.resources.txt")
+
+# kernel -> (resident waves per SIMD the tuning assumes, scratch bytes per lane tolerated)
+# gfx950: 512 VGPRs per SIMD lane, allocated in granules of 8: waves w fit when VGPRs + AGPRs <= (512 / w) & ~7.
+EXPECT = {
+    "k_ukw<3, 0>": (5, 0), "k_ukw<3, 1>": (5, 0), "k_ukw<4, 0>": (4, 0), "k_ukw<4, 1>": (4, 0),
+    "k_ukw<5, 0>": (3, 0), "k_ukw<5, 1>": (3, 0), "k_ukw<6, 0>": (2, 0), "k_ukw<6, 1>": (2, 0),
+    "k_uk<7, 2>": (3, 0), "k_uk<8, 4>": (4, 0), "k_uk<9, 2>": (2, 0),
+    # 160 rows on two waves: 220 VGPRs of matrix alone; measured faster with 4 systems per CU and a few spilled
+    # registers of the build phase than with 3 (profiles/README.md, round 2): a bounded allowance, not a free pass
+    "k_uk<10, 2>": (2, 128),
+    "k_tile_dist": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
+    "k_select<4>": (4, 0), "k_select<1>": (4, 0), "k_tile_cand": (4, 0),
+    "k_gwr_z": (4, 0), "k_tile_union": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
+    "k_daily_grid": (4, 0), "k_fix_cells": (4, 0),
+}
+LDS_PER_CU = 160 * 1024
+
+
+def budget(waves):
+    return (512 // waves) & ~7
+
+
+@pytest.fixture(scope="module")
+def table():
+    import subprocess
+    import isa_resources
+    so = os.path.join(ROOT, "topowx_amd", "libtwxhip.so")
+    if not os.path.exists(RES) or not os.path.exists(so) or os.path.getmtime(RES) < os.path.getmtime(so) - 120:
+        subprocess.check_call([os.path.join(ROOT, "build.sh")])      # (hipcc cross-compiles without a GPU: ~1 min)
+    return isa_resources.parse(RES)
+
+
+def test_every_tuned_kernel_is_listed(table):
+    missing = [k for k in EXPECT if k not in table]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("kernel", sorted(EXPECT))
+def test_register_and_scratch_budget(table, kernel):
+    waves, scratch_ok = EXPECT[kernel]
+    r = table[kernel]
+    assert r["scratch"] <= scratch_ok, "%s: %d B/lane of scratch (%d spilled VGPRs)" % (kernel, r["scratch"], r["vgpr_spill"])
+    assert r["vgprs"] + r["agprs"] <= budget(waves), "%s: %d VGPRs + %d AGPRs > %d (%d waves per SIMD)" % (
+        kernel, r["vgprs"], r["agprs"], budget(waves), waves)
+    assert r["occupancy"] >= waves, "%s: occupancy %d < %d waves per SIMD" % (kernel, r["occupancy"], waves)
+
+
+def test_daily_tile_keeps_two_workgroups_per_cu(table):
+    # k_daily_tile stages a tile-month's rows in LDS; its tuning (8 waves x 2 work-groups per CU) needs <= 80 KB each
+    assert table["k_daily_tile"]["lds"] <= LDS_PER_CU // 2
+    # the pair table of k_tile_dist takes nearly all of a CU's LDS by design (one work-group per CU)
+    assert table["k_tile_dist"]["lds"] <= LDS_PER_CU
+
+
+def test_no_kernel_uses_dynamic_scratch_unexpectedly(table):
+    spilled = {k: r["scratch"] for k, r in table.items() if r["scratch"] > 0}
+    assert set(spilled) <= {"k_uk<10, 2>"}, spilled

@@ -60,6 +60,43 @@ def test_set_optim_nstns_matches_executed_reference(golden_xval, golden_case):
         np.testing.assert_array_equal(a[d], b[d])
 
 
+
+def test_set_optim_nstns_from_mae_files_matches_executed_reference(golden_xval, golden_case, tmp_path):
+    """The route the reference takes (optimize.py:285-316): per-division MAE files written by the step21 / step23
+    writer rank (step21:83-128), read back by set_optim_nstns_tair_*.  Files are NetCDF-3 here (ncio); the result is
+    bit-identical to the executed reference, incl. a never-written (fill-valued) station."""
+    from topowx_amd import ncio, stationdb as sdb, xval
+    g = golden_xval
+    _, tmin, _ = golden_case
+    for namer, key in ((sdb.get_optim_varname, "so_optim"), (sdb.get_optim_anom_varname, "so_optim_anom")):
+        stns = tmin.stns.copy()
+        stns[sdb.CLIMDIV] = g["so_climdiv"]
+        for m in range(1, 13):
+            stns[namer(m)] = g["so_fill"]
+        ids, mae = _cube_from_golden(g, stns)
+        da = sdb.StationSerialDataDb(stns, "tmin", tmin.days)
+        d = str(tmp_path / key)
+        paths = xval.write_optim_nstns_files(d, da, ids, mae, g["xa_ladder"])
+        assert sorted(os.path.basename(p) for p in paths) == ["optim_nstns_tmin_climdiv%d.nc" % c for c in (101, 102, 4407)]
+        cube, nghs, fids = ncio.read_climdiv_optim_nstns_db(paths[0])
+        np.testing.assert_array_equal(nghs, g["xa_ladder"])
+        sel = [int(np.nonzero(ids == s)[0][0]) for s in fids]
+        np.testing.assert_array_equal(cube, mae[:, :, sel])
+        chosen = xval.set_optim_nstns_from_files(da, d, namer)
+        got = np.stack([da.stns[namer(m)] for m in range(1, 13)])
+        np.testing.assert_array_equal(got, g[key])
+        assert sorted(chosen) == [101.0, 102.0, 4407.0]
+    # a station whose slot was never written holds the fill value and is masked out of the mean
+    mae2 = mae.copy()
+    mae2[:, :, 0] = np.nan
+    d2 = str(tmp_path / "nan")
+    xval.write_optim_nstns_files(d2, da, ids, mae2, g["xa_ladder"])
+    stns_a, stns_b = stns.copy(), stns.copy()
+    a = xval.set_optim_nstns(stns_a, ids, mae2, g["xa_ladder"], sdb.get_optim_varname)[1]
+    b = xval.set_optim_nstns_from_files(sdb.StationSerialDataDb(stns_b, "tmin", tmin.days), d2, sdb.get_optim_varname)
+    for dv in a:
+        np.testing.assert_array_equal(a[dv], b[dv])
+
 def test_shard_unshard_roundtrip():
     from topowx_amd import xval
     for n in (0, 1, 7, 16):

@@ -30,9 +30,12 @@ def pmc(sub, pre, key):
     return per
 
 
-def group(per, prefixes):
-    n = sum(c for k, (c, v) in per.items() if k.startswith(prefixes))
-    kb = sum(v for k, (c, v) in per.items() if k.startswith(prefixes))
+def group(per, prefixes, exact=False):
+    """Dispatches and KB of the kernels whose name starts with one of ``prefixes`` (``exact``: equals one of them --
+    "k_daily_tile" must not swallow "k_daily_tile_gather", which halved the per-launch bytes in round 2)."""
+    hit = (lambda k: k in prefixes) if exact else (lambda k: k.startswith(prefixes))
+    n = sum(c for k, (c, v) in per.items() if hit(k))
+    kb = sum(v for k, (c, v) in per.items() if hit(k))
     return n, kb
 
 
@@ -53,11 +56,14 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
             for k, (n, v) in sorted(dper.items(), key=lambda kv: -kv[1][1]):
                 if k.startswith(DAILY_ONLY):
                     fh.write('"%s",%d,%.1f\n' % (k, n, v))
-        n, kb = group(dper, ("k_daily_tile",))
-        res[key]["k_daily_tile"] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
-        for o in ("k_tile_union", "k_gwr_z", "k_fix_cells"):
-            n, kb = group(dper, (o,))
+        for o in ("k_daily_tile", "k_daily_tile_gather", "k_tile_union", "k_gwr_z", "k_fix_cells"):
+            n, kb = group(dper, (o,), exact=True)
             res[key][o] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
+        # the launches behind bench.py's daily.timing_ms.daily_ms + gwr_ms, per daily step (Tmin + Tmax): the record's
+        # measured traffic (steps = dispatches of k_daily_tile)
+        steps = max(1, group(dper, ("k_daily_tile",), exact=True)[0])
+        n, kb = group(dper, DAILY + ("k_gwr_z",))
+        res[key]["daily_path_per_step_bytes"] = kb * 1024.0 / steps
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 
 

@@ -6,6 +6,7 @@ infrastructure and is never imported from here.)
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -30,6 +31,7 @@ CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)
                3: "Cannot determine variogram params!",
                4: "floating point error / singular kriging system",
                5: "No valid tmin/tmax in window", 6: "bandwidth above the supported maximum",
+               7: "candidate list of the tile overflows (station cluster denser than the library supports)",
                -1: "masked"}
 
 _dp = C.POINTER(C.c_double)
@@ -156,9 +158,12 @@ class Context(object):
         self.nstn = {}
         self.id_to_idx = {}
         self.mth_days = None
+        self._streams = weakref.WeakSet()       # open TileStreams: closed before the context (twx_destroy frees them too)
 
     def close(self):
         if getattr(self, "h", None):
+            for st in list(self._streams):
+                st.close()
             self.lib.twx_destroy(self.h)
             self.h = None
 
@@ -460,6 +465,7 @@ class TileStream(object):
         ctx._chk(ctx.lib.twx_stream_create(ctx.h, C.c_int(Y), C.c_int(X), C.c_int(self.vars_mask), C.c_int(int(daily)),
                                            C.c_int(nslots), C.byref(h)), "twx_stream_create")
         self.h = h
+        ctx._streams.add(self)
 
     def submit(self, slot, grid, rows=None, cols=None):
         a = Context.grid_arrays(grid, rows, cols)
@@ -490,7 +496,8 @@ class TileStream(object):
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.twx_stream_destroy(self.h)
+            if getattr(self.ctx, "h", None):            # (a closed context has destroyed its streams: the handle is dead)
+                self.ctx.lib.twx_stream_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -36,7 +36,6 @@ struct GwrWs {
     int32_t *gstat;   // [ncell]
     uint32_t *noff;   // [ncell][ksel] byte offset of each ranked neighbour's observation row (k_row_offsets)
     // k_tile_union -> k_daily_tile: the stations the cells of an 8x8 tile use in a month, as rows of an LDS table
-    uint32_t *soff;   // [ncell][12][TWX_KZ]  byte offset of the ranked neighbour's row in the tile's table
     int32_t *urow;    // [ntile][12][TWX_UROWS] station index of table row u
     int32_t *nurow;   // [ntile][12] rows in the table; -1 = more than TWX_UROWS (the tile-month gathers from global memory)
     double *zd;       // [ntile][12][64 / CPW groups][14 chunks][CPW cells][16] the hat rows scattered to table-row order (0 for
@@ -386,7 +385,6 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
         __builtin_amdgcn_wave_barrier();
         for (int r = lane; r < ka; r += 64) {
             const uint32_t u = s_slot[ws.near_pos[lc * ws.ksel + r]];
-            gw.soff[(lc * 12 + m0) * TWX_KZ + r] = 256u * u;
             zd[twx_zd_row(u)] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
         }
     }
@@ -411,7 +409,6 @@ struct DtVar {
     const float *obs;         // [n][ndays] month-major
     const int32_t *ka;        // [ncell][12]
     const double *z, *zc;     // hat rows / constants
-    const uint32_t *soff;     // [ncell][12][TWX_KZ]
     const double *zd;         // hat rows in table-row order, wave layout (GwrWs.zd)
     const int32_t *urow;      // [ntile][12][TWX_UROWS]
     const int32_t *nurow;     // [ntile][12]

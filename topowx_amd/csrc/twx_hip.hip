@@ -50,7 +50,7 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, soff, urow,
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, urow,
         nurow, zd;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
@@ -59,7 +59,7 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
-                          &near_pos, &soff, &urow, &nurow, &zd})
+                          &near_pos, &urow, &nurow, &zd})
             b->release();
     }
 };
@@ -109,6 +109,7 @@ struct twx_ctx {
     int ncu = 256;                // compute units (sizes the fixed grids of the kriging launches)
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     bool have_total = false;
+    std::vector<struct twx_stream *> streams;   // open twx_stream objects: twx_destroy closes them before the context goes away
 };
 
 namespace {
@@ -185,7 +186,6 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     }
     if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_union)
     if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
-        HIPCHK(w.soff.ensure((size_t)ncell * 12 * TWX_KZ * 4));
         HIPCHK(w.zd.ensure((size_t)ntile * 12 * 64 * TWX_UROWS * 8));   // per tile: 64 cell slots x 224 rows, wave layout
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
@@ -214,7 +214,6 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
     s.near_pos = grid ? w.near_pos.as<uint16_t>() : nullptr;
-    w.gw.soff = tile_tab ? w.soff.as<uint32_t>() : nullptr;
     w.gw.zd = tile_tab ? w.zd.as<double>() : nullptr;
     w.gw.urow = tile_tab ? w.urow.as<int32_t>() : nullptr;
     w.gw.nurow = tile_tab ? w.nurow.as<int32_t>() : nullptr;
@@ -276,7 +275,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
     const int nblk = (int)std::min<int64_t>(ntile, 2048);
-    // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_RANGE): the host
+    // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW): the host
     // never looks at them.  The bucket counts are read back once (exact kriging grids) unless TWX_FLAG_NO_HOST_SYNC.
     w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
     if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0, src.mode == 0)) return -1;
@@ -398,11 +397,14 @@ int twx_create(int device, const twx_params *params, twx_ctx **out)
     return 0;
 }
 
+void twx_stream_destroy(struct twx_stream *st);
+
 void twx_destroy(twx_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    while (!ctx->streams.empty()) twx_stream_destroy(ctx->streams.back());   // (removes itself from the list)
     for (int v = 0; v < 2; ++v) { ctx->var[v].cols.release(); ctx->var[v].obs.release(); ctx->work[v].release(); }
     for (DevBuf *b : ctx->all_bufs()) b->release();
     for (auto &e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -534,14 +536,24 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
         if (ctx->ndays <= 0) return fail(ctx, "twx_set_stations: call twx_set_days before passing observations");
         const size_t nd = (size_t)ctx->ndays;
         // (time, station) -> [station][month-major day]: days become the contiguous axis
+        // The database is serially complete (station_data.py:547-616): a NaN / Inf observation is rejected here, because
+        // the daily table walk multiplies every row of a tile-month by every cell's weight (0 * NaN would reach all 64
+        // cells of a tile, where the reference would only lose the cells that use the station)
         std::vector<float> tr(n * nd);
         const size_t B = 64;
+        uint32_t nonfinite = 0;                            // set when an exponent field is all ones
         for (size_t j0 = 0; j0 < n; j0 += B)
             for (size_t p0 = 0; p0 < nd; p0 += B)
                 for (size_t p = p0; p < std::min(nd, p0 + B); ++p) {
                     const float *row = t->obs + (size_t)ctx->mm2chron[p] * n;
-                    for (size_t j = j0; j < std::min(n, j0 + B); ++j) tr[j * nd + p] = row[j];
+                    for (size_t j = j0; j < std::min(n, j0 + B); ++j) {
+                        const float x = row[j];
+                        uint32_t b; std::memcpy(&b, &x, 4);
+                        nonfinite |= ((b & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+                        tr[j * nd + p] = x;
+                    }
                 }
+        if (nonfinite) return fail(ctx, "twx_set_stations: the observation matrix holds NaN / Inf (it must be serially complete)");
         HIPCHK(vd.obs.ensure(tr.size() * 4));
         HIPCHK(hipMemcpy(vd.obs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
         s.obs = vd.obs.as<float>();
@@ -1108,7 +1120,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                     for (int v = 0; v < 2; ++v) {
                         DtVar &dv = v == 0 ? da.n : da.x;
                         const Work &wk = ctx->work[v];
-                        dv.obs = ctx->var[v].dev.obs; dv.ka = wk.ws.ka; dv.z = wk.gw.z; dv.zc = wk.gw.zc; dv.soff = wk.gw.soff; dv.zd = wk.gw.zd;
+                        dv.obs = ctx->var[v].dev.obs; dv.ka = wk.ws.ka; dv.z = wk.gw.z; dv.zc = wk.gw.zc; dv.zd = wk.gw.zd;
                         dv.urow = wk.gw.urow; dv.nurow = wk.gw.nurow;
                     }
                     da.okc = d_okc; da.mm2chron = ctx->da.mm2chron; da.out_n = o->daily_tmin; da.out_x = o->daily_tmax;
@@ -1218,6 +1230,7 @@ int twx_interp_grid(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, int 
 // ---- streamed tiles (step25:177-185, tiling.py:488-537: every chunk is written as soon as it is finished) ---------
 struct twx_stream {
     twx_ctx *ctx = nullptr;
+    int device = 0;                               // (kept here: destroy must not reach through a context that may be gone)
     int Y = 0, X = 0, vars = 0, daily = 0, nslots = 0;
     size_t in_bytes = 0, out_bytes = 0;
     hipStream_t s_comp = nullptr, s_copy = nullptr;
@@ -1240,7 +1253,7 @@ int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslot
     if (daily && ctx->ndays <= 0) return fail(ctx, "twx_stream_create: daily output needs the day axis (twx_set_days)");
     HIPCHK(hipSetDevice(ctx->device));
     twx_stream *st = new twx_stream();
-    st->ctx = ctx; st->Y = Y; st->X = X; st->vars = vars; st->daily = daily; st->nslots = nslots;
+    st->ctx = ctx; st->device = ctx->device; st->Y = Y; st->X = X; st->vars = vars; st->daily = daily; st->nslots = nslots;
     const bool has_n = vars & TWX_VAR_TMIN_BIT, has_x = vars & TWX_VAR_TMAX_BIT;
     st->in_bytes = grid_in_bytes(Y, X);
     st->out_bytes = grid_out_bytes(Y, X, ctx->ndays, daily && has_n, daily && has_x);
@@ -1256,6 +1269,7 @@ int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslot
              hipHostMalloc((void **)&st->hout[i], st->out_bytes, hipHostMallocDefault) == hipSuccess &&
              hipEventCreate(&st->ev_start[i]) == hipSuccess && hipEventCreate(&st->ev_comp[i]) == hipSuccess &&
              hipEventCreate(&st->ev_done[i]) == hipSuccess;
+    ctx->streams.push_back(st);
     if (!ok) { twx_stream_destroy(st); return fail(ctx, "twx_stream_create: allocation failed (device images / pinned host staging)"); }
     *out = st;
     return 0;
@@ -1264,7 +1278,11 @@ int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslot
 void twx_stream_destroy(twx_stream *st)
 {
     if (!st) return;
-    (void)hipSetDevice(st->ctx->device);
+    (void)hipSetDevice(st->device);
+    if (st->ctx) {
+        auto &v = st->ctx->streams;
+        v.erase(std::remove(v.begin(), v.end(), st), v.end());
+    }
     if (st->s_comp) (void)hipStreamSynchronize(st->s_comp);
     if (st->s_copy) (void)hipStreamSynchronize(st->s_copy);
     for (int d = 0; d < 2; ++d) { st->din[d].release(); st->dout[d].release(); if (st->ev_free[d]) (void)hipEventDestroy(st->ev_free[d]); }

@@ -20,7 +20,7 @@
 
 struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
-    int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_RANGE)
+    int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW)
     int init_nnghs;
     int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_ukw)
     int64_t cell0;       // first global cell id of the batch
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
         return;
     }
     // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
-    int status = too_many ? TWX_CELL_RANGE : TWX_CELL_OK;
+    int status = too_many ? TWX_CELL_CAND_OVERFLOW : TWX_CELL_OK;
     const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;

@@ -7,9 +7,11 @@ gloo in the CPU tests): tiles are dealt to ranks balanced by their number of
 unmasked cells, every rank holds the full station table (a few MB; the obs matrix
 ~1 GB per variable) and interpolates whole tiles with one library call each.
 Cells are independent, so the data path needs NO collective; the optional
-``gather_mosaic`` assembles the f4 normals / SE mosaics on rank 0 over xGMI
-(SURVEY.md section 8e).  netCDF output is out of scope (8f-2): results are
-returned as arrays / written as ``.npz``.
+``gather_mosaic_device`` assembles the f4 normals / SE mosaics on rank 0 over xGMI
+straight from the device tensor the tiles were computed into (``interp_tiles_device``;
+``gather_mosaic`` is the host-array form the streamed / daily paths use) (SURVEY.md
+section 8e).  Results are returned as arrays / written as ``.npz``; the netCDF tile
+writer is ``topowx_amd.ncio`` / ``topowx_amd.step25``.
 """
 import argparse
 import json
@@ -84,6 +86,87 @@ def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, d
                 m = mosaic[key][:, i:i + tile_y, j:j + tile_x]    # clipped at the grid edge
                 m[...] = arr[s, q][:, :m.shape[1], :m.shape[2]]
     return mosaic
+
+
+NORMAL_KEYS = ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")
+
+
+def upload_grid(grid, device):
+    """The predictor planes of a grid as device tensors (native dtypes, tiling.py:190-213)."""
+    import torch
+    from . import _lib
+    a = _lib.Context.grid_arrays(grid)
+    return {k: torch.from_numpy(v).to(device) for k, v in a.items()}
+
+
+def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), nslots=None, stream=None):
+    """Normals + SE of this rank's tiles with everything resident in HBM: the predictor planes come from the device
+    tensors of ``upload_grid`` (each tile's 61 B / cell are gathered into a contiguous image by a device copy), and
+    ``twx_interp_grid_dev`` writes every tile's outputs straight into slot s of ONE device tensor
+    ``buf[nslots, 4, 12, tile_y, tile_x]`` -- the send buffer of ``gather_mosaic_device``; nothing crosses PCIe.
+    ``nslots`` >= len(tiles) pads the buffer to the size every rank of a gather must share.
+    Returns (buf, status[nslots, tile_y, tile_x] i4 device tensor, per-tile device ms)."""
+    import torch
+    from . import _lib
+    dev = dgrid["mask"].device
+    nslots = len(tiles) if nslots is None else nslots
+    assert nslots >= len(tiles)
+    buf = torch.full((max(nslots, 1), 4, 12, tile_y, tile_x), float(FILL_F4), dtype=torch.float32, device=dev)
+    stat = torch.full((max(nslots, 1), tile_y, tile_x), -1, dtype=torch.int32, device=dev)
+    ninv = torch.empty((tile_y, tile_x), dtype=torch.int32, device=dev)
+    Yg, Xg = dgrid["mask"].shape
+    vars_mask = (_lib.VAR_TMIN_BIT if "tmin" in variables else 0) | (_lib.VAR_TMAX_BIT if "tmax" in variables else 0)
+    strm = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    ms = []
+    for s, (_, i, j, _) in enumerate(tiles):
+        y, x = min(tile_y, Yg - i), min(tile_x, Xg - j)
+        t = {k: dgrid[k][i:i + y, j:j + x].contiguous() for k in ("mask", "elev", "tdi", "climdiv")}
+        t["lat"] = dgrid["lat"][i:i + y].contiguous()
+        t["lon"] = dgrid["lon"][j:j + x].contiguous()
+        for k in ("lst_night", "lst_day"):
+            t[k] = dgrid[k][:, i:i + y, j:j + x].contiguous()
+        full = y == tile_y and x == tile_x
+        # an edge tile is smaller than its slot: computed into a scratch image and placed afterwards
+        o = buf[s] if full else torch.full((4, 12, y, x), float(FILL_F4), dtype=torch.float32, device=dev)
+        so = stat[s] if full else torch.full((y, x), -1, dtype=torch.int32, device=dev)
+        g = _lib.TwxGrid(y, x, *[t[k].data_ptr() for k in ("mask", "lat", "lon", "elev", "tdi", "climdiv", "lst_night", "lst_day")])
+        ptr = [o[q].data_ptr() if v in variables else None for q, v in enumerate(("tmin", "tmin", "tmax", "tmax"))]
+        go = _lib.TwxGridOut(ptr[0], ptr[1], ptr[2], ptr[3], None, None, ninv.data_ptr(), so.data_ptr())
+        ctx.interp_grid_dev(g, go, vars_mask, strm)
+        ms.append(ctx.timing()["total_ms"])          # HIP events of this tile (synchronises: the inputs may go)
+        if not full:
+            buf[s, :, :, :y, :x] = o
+            stat[s, :y, :x] = so
+    return buf, stat, ms
+
+
+def gather_mosaic_device(buf, assignment, shape, tile_y, tile_x, rank, world, keys=NORMAL_KEYS, backend="nccl"):
+    """``gather_mosaic`` on device tensors: ``buf[nmax, len(keys), 12, tile_y, tile_x]`` of every rank (the tensor
+    ``interp_tiles_device`` has filled, same nmax everywhere) goes to rank 0 with ONE ``dist.gather`` -- over RCCL
+    world - 1 concurrent xGMI transfers into rank 0's HBM -- and is placed into ``[12, Y, X]`` mosaics by device
+    copies; no host staging (with the gloo backend of the CPU / shared-GPU control-flow runs the collective itself
+    travels through host memory).  Returns {key: device tensor} on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        send = buf if backend == "nccl" else buf.cpu()
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, parts, dst=0)
+    else:
+        parts = [buf]
+    if rank != 0:
+        return None
+    dev = buf.device
+    Y, X = shape
+    mosaic = {key: torch.full((12, Y, X), float(FILL_F4), dtype=torch.float32, device=dev) for key in keys}
+    for r in range(world):
+        arr = parts[r].to(dev)
+        for s, (_, i, j, _) in enumerate(assignment[r]):
+            y, x = min(tile_y, Y - i), min(tile_x, X - j)
+            for q, key in enumerate(keys):
+                mosaic[key][:, i:i + y, j:j + x] = arr[s, q, :, :y, :x]
+    return mosaic
+
 
 
 def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
@@ -171,37 +254,56 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    grid, tmin, tmax = synth.make_case(args.config, with_obs=args.daily)
+    even = grid["mask"].shape[0] % args.tile == 0 and grid["mask"].shape[1] % args.tile == 0
+    if args.tile_dir and not even:
+        # the streamed writer works on tiles of ONE shape (twx_stream_*): say so before anything is computed
+        raise SystemExit("--tile-dir needs a grid that --tile divides evenly (grid %dx%d, tile %d): choose another "
+                         "--tile or drop --tile-dir" % (grid["mask"].shape + (args.tile,)))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    grid, tmin, tmax = synth.make_case(args.config, with_obs=args.daily)
+    torch.cuda.set_device(local)
     ctx = _lib.Context(device=local)
     ctx.set_stations(_lib.TMIN, tmin, with_obs=args.daily)
     ctx.set_stations(_lib.TMAX, tmax, with_obs=args.daily)
     tiles = tile_list(grid["mask"], args.tile, args.tile)
     assignment = assign_tiles(tiles, world)
     t0 = time.perf_counter()
-    even = grid["mask"].shape[0] % args.tile == 0 and grid["mask"].shape[1] % args.tile == 0
-    if args.tile_dir and even:
-        # streamed: outputs of tile t travel to the host and to disk while tile t + 1 is computed
+    if args.tile_dir:
+        # streamed: outputs of tile t travel to the host and to disk while tile t + 1 is computed; the normals (small)
+        # are kept for --gather
         os.makedirs(args.tile_dir, exist_ok=True)
+        mine = {}
 
         def sink(k, arrays):
             np.savez(os.path.join(args.tile_dir, "tile%05d.npz" % k), **{n: v for n, v in arrays.items() if hasattr(v, "shape")})
-        mine, dt, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=args.daily, sink=sink)
-        mine = mine or {}
-    else:
-        mine = interp_tiles(grid, gpu_compute(ctx, daily=args.daily), assignment[rank], args.tile, args.tile)
+            if args.gather:
+                mine[k] = {n: np.array(arrays[n]) for n in NORMAL_KEYS}
+        _, _, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=args.daily, sink=sink)
+        mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, NORMAL_KEYS, rank, world,
+                               device="cuda:%d" % local) if args.gather else None
+    elif args.daily:
+        mine = interp_tiles(grid, gpu_compute(ctx, daily=True), assignment[rank], args.tile, args.tile)
         dev_ms = None
+        mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, NORMAL_KEYS, rank, world,
+                               device="cuda:%d" % local) if args.gather else None
+    else:
+        # normals only: everything stays in HBM, tiles land in the gather's send buffer
+        dgrid = upload_grid(grid, "cuda:%d" % local)
+        nmax = max(len(a) for a in assignment)
+        buf, _, ms = interp_tiles_device(ctx, dgrid, assignment[rank], args.tile, args.tile, nslots=nmax)
+        dev_ms = float(sum(ms))
+        mosaic = None
+        if args.gather:
+            mosaic = gather_mosaic_device(buf, assignment, grid["mask"].shape, args.tile, args.tile, rank, world)
+            if mosaic is not None:
+                mosaic = {k: v.cpu().numpy() for k, v in mosaic.items()}
     dt = time.perf_counter() - t0
     ncell = sum(t[3] for t in assignment[rank])
     print(json.dumps({"rank": rank, "tiles": len(assignment[rank]), "cells": ncell, "seconds": dt, "device_ms": dev_ms}), flush=True)
-    if args.gather and not args.tile_dir:
-        keys = ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")
-        mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, keys, rank, world,
-                               device="cuda:%d" % local)
-        if rank == 0 and args.out:
-            np.savez_compressed(args.out, **mosaic)
+    if rank == 0 and args.out and mosaic is not None:
+        np.savez_compressed(args.out, **mosaic)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

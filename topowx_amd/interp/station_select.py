@@ -16,7 +16,7 @@ def raise_for_status(status):
         raise IndexError(msg)
     if status == 4:
         raise FloatingPointError(msg)
-    if status == 6:
+    if status in (6, 7):
         raise ValueError(msg)
     raise Exception(msg)
 

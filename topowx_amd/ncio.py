@@ -18,7 +18,8 @@ from scipy.io import netcdf_file
 from . import stationdb as sdb
 from .dates import DAY, MONTH, YEAR, get_days_metadata
 
-__all__ = ["TileWriter", "read_tile", "write_station_db", "read_station_db", "read_tile_stores"]
+__all__ = ["TileWriter", "read_tile", "write_station_db", "read_station_db", "read_tile_stores",
+           "climdiv_optim_nstns_path", "write_climdiv_optim_nstns_db", "read_climdiv_optim_nstns_db"]
 
 FILL_I2 = np.int16(-32767)
 FILL_F4 = np.float32(9.969209968386869e36)
@@ -274,3 +275,70 @@ def read_station_db(path, var_name, cls=None):
     finally:
         ds.close()
     return cls(stns, var_name, days, obs)
+
+
+# ---- per-climate-division cross-validation MAE files (optimize.py:39-82, step21:66-128) ------------------
+FILL_F8 = 9.969209968386869e36          # netCDF4.default_fillvals['f8'] (create_db_all_stations.py:164)
+
+
+def climdiv_optim_nstns_path(path_out, tair_var, climdiv):
+    """``optim_nstns_<var>_climdiv<id>.nc`` (optimize.py:61, :302, :356)."""
+    return os.path.join(path_out, "optim_nstns_%s_climdiv%d.nc" % (tair_var, int(climdiv)))
+
+
+def write_climdiv_optim_nstns_db(path_out, tair_var, stn_ids, nstns_rng, climdiv, mae):
+    """``create_climdiv_optim_nstns_db`` (optimize.py:39-82) + the writer rank's ``ds.variables['mae'][:, :, dim2] =
+    np.abs(err)`` (step21:124-128), in one call: dimensions ``min_nghs``, ``stn_id`` (+ ``string<N>``: classic netCDF
+    has no variable-length strings), ``mth``; variables ``min_nghs`` i4, ``mth`` i4 = 1..12, ``stn_id`` and
+    ``mae`` f8 ``(mth, min_nghs, stn_id)`` with ``missing_value`` = the f8 default fill; a station that was never
+    written (NaN here) holds the fill value, as a never-written slot of the reference's file does."""
+    stn_ids = np.asarray(stn_ids)
+    nstns_rng = np.asarray(nstns_rng, np.int32)
+    mae = np.asarray(mae, np.float64)
+    if mae.shape != (12, nstns_rng.size, stn_ids.size):
+        raise ValueError("mae must be [12, n_bandwidths, n_stations]")
+    fpath = climdiv_optim_nstns_path(path_out, tair_var, climdiv)
+    ds = netcdf_file(fpath, "w", version=2, mmap=False)
+    try:
+        ds.title = "Cross Validation MAE for Different N Neighboring Stations: " + tair_var
+        ds.institution = "University of Montana Numerical Terradynamics Simulation Group"
+        ds.history = "Created on: " + _dt.date.today().strftime("%Y-%m-%d")
+        idlen = max([1] + [len(s) for s in stn_ids])
+        ds.createDimension("min_nghs", int(nstns_rng.size))
+        ds.createDimension("stn_id", int(stn_ids.size))
+        ds.createDimension("string%d" % idlen, idlen)
+        ds.createDimension("mth", 12)
+        ids = ds.createVariable("stn_id", "c", ("stn_id", "string%d" % idlen))
+        ids.long_name = ids.standard_name = "station id"
+        if stn_ids.size:
+            ids[:] = np.array([list(s.ljust(idlen, "\0")) for s in stn_ids], "S1")
+        ng = ds.createVariable("min_nghs", "i", ("min_nghs",))
+        ng.long_name = ng.standard_name = "min_nghs"
+        ng[:] = nstns_rng
+        mv = ds.createVariable("mth", "i", ("mth",))
+        mv[:] = np.arange(1, 13, dtype=np.int32)
+        v = ds.createVariable("mae", "d", ("mth", "min_nghs", "stn_id"))
+        v.long_name, v.units, v.standard_name = "mean absolute error", "C", "mean_absolute_error"
+        v.missing_value = FILL_F8
+        v[:] = np.where(np.isnan(mae), FILL_F8, mae)
+    finally:
+        ds.close()
+    return fpath
+
+
+def read_climdiv_optim_nstns_db(fpath):
+    """What ``set_optim_nstns_tair_norm / _anom`` read from a division's file (optimize.py:304-307): ``(mae[12, nb, n]``
+    with fill / missing values as NaN -- netCDF4's auto-mask --, ``min_nghs[nb]``, ``stn_ids[n])``."""
+    ds = netcdf_file(fpath, "r", mmap=False)
+    try:
+        v = ds.variables["mae"]
+        mae = np.asarray(v[:], np.float64).copy()
+        for att in ("missing_value", "_FillValue"):
+            if hasattr(v, att):
+                mae[mae == float(getattr(v, att))] = np.nan
+        nghs = np.asarray(ds.variables["min_nghs"][:], np.int32).copy()
+        raw = ds.variables["stn_id"][:]
+        ids = np.array([b"".join(r).rstrip(b"\0 ").decode() for r in raw]) if len(raw) else np.array([], "U1")
+    finally:
+        ds.close()
+    return mae, nghs, ids

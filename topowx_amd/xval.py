@@ -26,7 +26,8 @@ from .interp.optimize import XvalTairAnom, XvalTairNorm, XvalTairOverall, build_
 from .stationdb import BAD, CLIMDIV, MASK, STN_ID, get_optim_anom_varname, get_optim_varname
 
 __all__ = ["xval_station_ids", "shard", "optim_nstns_norms", "optim_nstns_anoms", "xval_interp", "set_optim_nstns",
-           "set_optim_nstns_tair_norm", "set_optim_nstns_tair_anom", "DFLT_LADDER"]
+           "set_optim_nstns_tair_norm", "set_optim_nstns_tair_anom", "write_optim_nstns_files",
+           "set_optim_nstns_from_files", "run_config5", "DFLT_LADDER"]
 
 DFLT_LADDER = build_nstn_bandwidths(35, 150, 0.10)        # step21:198, step23
 
@@ -182,6 +183,50 @@ def set_optim_nstns(stns, stn_ids, mae, ladder, namer):
     return stns, chosen
 
 
+def write_optim_nstns_files(path_out, stn_da, stn_ids, mae, ladder=DFLT_LADDER):
+    """The side product of the step21 / step23 writer rank (step21:83-128, optimize.py:39-82): one
+    ``optim_nstns_<var>_climdiv<id>.nc`` per climate division holding the MAE cube ``[12, n_bandwidths, stations of
+    the division]`` of the cross-validated stations (NetCDF-3 through ``topowx_amd.ncio``).  Returns the paths."""
+    import os
+    from . import ncio
+    os.makedirs(path_out, exist_ok=True)
+    stns = stn_da.stns
+    ids = np.asarray(stn_ids)
+    pos = {s: i for i, s in enumerate(stns[STN_ID])}
+    div_of_xval = stns[CLIMDIV][[pos[s] for s in ids]]
+    paths = []
+    for clim_div in np.unique(div_of_xval[np.isfinite(div_of_xval)]):       # step21:83 loops the divisions of the xval stations
+        cols = np.nonzero(div_of_xval == clim_div)[0]
+        paths.append(ncio.write_climdiv_optim_nstns_db(path_out, stn_da.var_name, ids[cols], ladder, clim_div,
+                                                       np.asarray(mae)[:, :, cols]))
+    return paths
+
+
+def set_optim_nstns_from_files(stn_da, path_xval_ds, namer):
+    """``set_optim_nstns_tair_norm / _anom`` as the reference runs them (optimize.py:285-316, :339-370): from the
+    per-division MAE files under ``path_xval_ds``.  A division without a file is skipped (the reference would fail
+    opening it).  Same arithmetic as ``set_optim_nstns`` (masked mean over the division's stations, first minimum)."""
+    import os
+    from . import ncio
+    stns = stn_da.stns
+    climdiv_stns = stns[CLIMDIV]
+    chosen = {}
+    for clim_div in np.unique(climdiv_stns[np.isfinite(climdiv_stns)]):       # :300
+        fpath = ncio.climdiv_optim_nstns_path(path_xval_ds, stn_da.var_name, clim_div)
+        if not os.path.exists(fpath):
+            continue
+        mae_climdiv, nnghs_climdiv, _ = ncio.read_climdiv_optim_nstns_db(fpath)  # :304-307
+        climdiv_mask = np.nonzero(climdiv_stns == clim_div)[0]                   # :308
+        pick = np.zeros(12, nnghs_climdiv.dtype)
+        for mth in range(1, 13):
+            mmae = np.ma.mean(np.ma.masked_invalid(mae_climdiv[mth - 1]), axis=1)    # :311-312
+            min_idx = int(np.argmin(mmae))                                       # :313
+            stns[namer(mth)][climdiv_mask] = nnghs_climdiv[min_idx]              # :314
+            pick[mth - 1] = nnghs_climdiv[min_idx]
+        chosen[float(clim_div)] = pick
+    return chosen
+
+
 def set_optim_nstns_tair_norm(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
     """optimize.py:268-316 (the end of step21): writes ``optim_nnghsMM``."""
     return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_varname)[1]
@@ -192,16 +237,50 @@ def set_optim_nstns_tair_anom(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
     return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_anom_varname)[1]
 
 
+def run_config5(nstns=2000, years=3, var="tmin", max_stations=0, rank=0, world=1, device=0, gather_device="cpu"):
+    """BASELINE.json configs[4] end to end on a synthetic database, timed: step21 (variogram fit + kriging per
+    (station, bandwidth, month), step21:34-64), ``set_optim_nstns_tair_norm``, step23 (GWR series + statistics,
+    step23:35-70), ``set_optim_nstns_tair_anom``, step24 (normals + daily values with the optimised bandwidths,
+    step24:36-69).  Returns (timings / rates dict, arrays dict for spot checks)."""
+    import time
+    import datetime as dt
+    from . import synth
+    from .dates import get_days_metadata
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + years, 12, 31))
+    grid = synth.make_grid("C2")
+    stn = synth.make_stations(grid["bbox"], nstns, 1, var, days, with_obs=True)
+    ids = xval_station_ids(stn)
+    if max_stations:
+        ids = ids[:max_stations]
+    res = {"stations": int(len(ids)), "ladder": int(DFLT_LADDER.size), "days": int(days.size), "n_gpus": world}
+    t0 = time.perf_counter()
+    _, mae_n = optim_nstns_norms(stn, var, stn_ids=ids, rank=rank, world=world, device=device, gather_device=gather_device)
+    res["step21_s"] = time.perf_counter() - t0
+    stn_before = stn.stns.copy()                     # the table step21 cross-validated against (for spot checks)
+    set_optim_nstns_tair_norm(stn, ids, mae_n)
+    t0 = time.perf_counter()
+    _, mae_a, _, _ = optim_nstns_anoms(stn, var, stn_ids=ids, rank=rank, world=world, device=device, gather_device=gather_device)
+    res["step23_s"] = time.perf_counter() - t0
+    set_optim_nstns_tair_anom(stn, ids, mae_a)
+    t0 = time.perf_counter()
+    _, norms, _, _, st = xval_interp(stn, var, stn_ids=ids, daily=True, rank=rank, world=world, device=device,
+                                     gather_device=gather_device)
+    res["step24_s"] = time.perf_counter() - t0
+    res["step21_systems_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step21_s"]
+    res["step23_series_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step23_s"]
+    res["step24_station_days_per_s"] = len(ids) * days.size / res["step24_s"]
+    res["failed"] = int((st != 0).sum())
+    res["step21_mae_finite_frac"] = float(np.isfinite(mae_n).mean())
+    return res, {"ids": ids, "mae_norm": mae_n, "mae_anom": mae_a, "norms": norms, "status": st, "stn": stn,
+                 "stns_step21": stn_before}
+
+
 def main():
     """All three farms on a synthetic database, timed: ``python -m topowx_amd.xval --nstns 10000``
     (under torchrun every rank takes its share)."""
     import argparse
     import json
     import os
-    import time
-    import datetime as dt
-    from . import synth
-    from .dates import get_days_metadata
     ap = argparse.ArgumentParser()
     ap.add_argument("--nstns", type=int, default=2000)
     ap.add_argument("--years", type=int, default=3)
@@ -218,29 +297,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         gdev = "cuda:%d" % local
-    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + args.years, 12, 31))
-    grid = synth.make_grid("C2")
-    stn = synth.make_stations(grid["bbox"], args.nstns, 1, args.var, days, with_obs=True)
-    ids = xval_station_ids(stn)
-    if args.max_stations:
-        ids = ids[:args.max_stations]
-    res = {"stations": int(len(ids)), "ladder": int(DFLT_LADDER.size), "days": int(days.size), "n_gpus": world}
-    t0 = time.perf_counter()
-    _, mae_n = optim_nstns_norms(stn, args.var, stn_ids=ids, rank=rank, world=world, device=local, gather_device=gdev)
-    res["step21_s"] = time.perf_counter() - t0
-    set_optim_nstns_tair_norm(stn, ids, mae_n)
-    t0 = time.perf_counter()
-    _, mae_a, _, _ = optim_nstns_anoms(stn, args.var, stn_ids=ids, rank=rank, world=world, device=local, gather_device=gdev)
-    res["step23_s"] = time.perf_counter() - t0
-    set_optim_nstns_tair_anom(stn, ids, mae_a)
-    t0 = time.perf_counter()
-    _, norms, _, _, st = xval_interp(stn, args.var, stn_ids=ids, daily=True, rank=rank, world=world, device=local,
-                                     gather_device=gdev)
-    res["step24_s"] = time.perf_counter() - t0
-    res["step21_systems_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step21_s"]
-    res["step23_series_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step23_s"]
-    res["step24_station_days_per_s"] = len(ids) * days.size / res["step24_s"]
-    res["failed"] = int((st != 0).sum())
+    res, _ = run_config5(args.nstns, args.years, args.var, args.max_stations, rank, world, local, gdev)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
