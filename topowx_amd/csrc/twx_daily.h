@@ -44,77 +44,102 @@ struct GwrWs {
 };
 
 // ---------------------------------------------------------------------------------
-// k_gwr_z: one wavefront per (cell, month).  _gwr_series (interp_tair.py:1099-1146):
-// z = x0' (X'WX)^-1 X'W with X = [1, lon, lat, elev, tdi, lst] of the ka nearest
-// stations and their own bisquare weights.  Predictor columns are shifted to the
-// cell and scaled (z is invariant to it), the 6x6 SPD system is Cholesky-solved
-// redundantly by every lane.
+// k_gwr_z: one 16-lane DPP row per (cell, month) item, four items per wavefront.  _gwr_series
+// (interp_tair.py:1099-1146): z = x0' (X'WX)^-1 X'W with X = [1, lon, lat, elev, tdi, lst] of the ka nearest
+// stations and their own bisquare weights (:1128-1140).
+//
+// Round 2 gave an item a whole wave and paid 32 full-wave reductions for it (3 % of the fp64 rate: reduction
+// latency, not arithmetic).  Here a lane walks the item's neighbours tr, tr + 16, ... and keeps the 21 sums of
+// the normal matrix in registers; they are reduced ONCE over the 16 lanes of the row (row_shr steps, the total of
+// lane 15 broadcast back with row_newbcast: no cross-row traffic, every lane of a row holds the same bits), the 6x6
+// SPD system is Cholesky-solved redundantly by every lane (four items at a time), and a second walk over the
+// neighbours forms the hat row.  Predictor columns are shifted to the cell (cancellation) and left unscaled: z is
+// invariant to a column scaling and an unpivoted Cholesky only changes its roundings under one (see k_uk).
 // ---------------------------------------------------------------------------------
+#define TWX_GZ_SLOTS ((TWX_MAX_NNGHS + 15) / 16)   // neighbours per lane
+
+// sum over the 16 lanes of a DPP row, returned in all of them
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v = dpp_add_step<0x111, 0xf>(v);           // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);           // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);           // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);           // row_shr:8 -> lane 15 of the row holds the row's sum
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x15f, 0xf, 0xf, false);   // row_newbcast:15
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x15f, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws, GwrWs gw,
                                                const double *pt_norm_in)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wgi = xcd_contig(blockIdx.x, (int)((ws.ncell * 12 + 3) / 4));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tr = lane & 15, row = lane >> 4;
+    const int64_t nitems = ws.ncell * 12;
+    const int wgi = xcd_contig(blockIdx.x, (int)((nitems + 15) / 16));
     if (wgi < 0) return;
-    const int64_t item = (int64_t)wgi * 4 + wv;
-    if (item >= ws.ncell * 12) return;
-    const int64_t lc = item / 12;
-    const int m0 = (int)(item % 12);
+    const int64_t item = (int64_t)wgi * 16 + wv * 4 + row;   // the four items of a wave: mostly months of one cell
+    const bool in_range = item < nitems;
+    const int64_t lc = in_range ? item / 12 : 0;
+    const int m0 = in_range ? (int)(item % 12) : 0;
     const int64_t c = ws.cell0 + lc;
-    if (ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0) return;
-    const int ka = ws.ka[lc * 12 + m0];
-    if (ka <= 0) return;
+    int ka = 0;
+    if (in_range && ws.cstat[lc] == 0 && ws.uk_stat[lc] == 0) ka = ws.ka[lc * 12 + m0];
+    if (!__any(ka > 0)) return;
     const size_t n = (size_t)st.n;
     const CellVals cv = cell_load(src, c);
     const double plst = cell_lst(src, c, m0);
-    const double dbw = ws.near_dist[lc * ws.ksel + ka];
-    double row[3][6], w[3], nrm[3];
-    double mx[5] = {0, 0, 0, 0, 0}, rawmx[5] = {0, 0, 0, 0, 0};
+    const double dbw = ka > 0 ? ws.near_dist[lc * ws.ksel + ka] : 1.0;
+    const int32_t *ni = ws.near_idx + lc * ws.ksel;
+    const double *nd = ws.near_dist + lc * ws.ksel;
+    int kamax = ka;                                          // slots this wave walks (uniform)
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        int r = lane + 64 * s;
-        w[s] = 0.0; nrm[s] = 0.0;
+    for (int o = 32; o > 0; o >>= 1) kamax = max(kamax, __shfl_xor(kamax, o, 64));
+    const int nslot = (kamax + 15) >> 4;
+
+    // ---- pass 1: M = X'WX (lower triangle, 21 sums) over this lane's neighbours ------------------------------
+    double M[6][6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) row[s][q] = 0.0;
-        if (r < ka) {
-            int j = ws.near_idx[lc * ws.ksel + r];
-            w[s] = bisq(ws.near_dist[lc * ws.ksel + r], dbw);
-            row[s][0] = 1.0;
-            const double raw[5] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j], st.lst[m0 * n + j]};
-            row[s][1] = raw[0] - cv.lon; row[s][2] = raw[1] - cv.lat;
-            row[s][3] = raw[2] - cv.elev; row[s][4] = raw[3] - cv.tdi;
-            row[s][5] = raw[4] - plst;
-            nrm[s] = st.norm[m0 * n + j];
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { mx[q] = fmax(mx[q], fabs(row[s][1 + q])); rawmx[q] = fmax(rawmx[q], fabs(raw[q])); }
+        for (int b = 0; b <= a; ++b) M[a][b] = 0.0;
+    double w[TWX_GZ_SLOTS];
+    bool nz[5] = {false, false, false, false, false};        // a predictor that is non-zero at some neighbour
+#pragma unroll
+    for (int s = 0; s < TWX_GZ_SLOTS; ++s) {
+        w[s] = 0.0;
+        if (s < nslot) {                                     // uniform
+            const int r = tr + 16 * s;
+            if (r < ka) {
+                const int j = ni[r];
+                const double wj = bisq(nd[r], dbw);
+                w[s] = wj;
+                const double raw[5] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j], st.lst[m0 * n + j]};
+                const double x[6] = {1.0, raw[0] - cv.lon, raw[1] - cv.lat, raw[2] - cv.elev, raw[3] - cv.tdi, raw[4] - plst};
+#pragma unroll
+                for (int q = 0; q < 5; ++q) nz[q] = nz[q] || raw[q] != 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double wx = wj * x[a];
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) M[a][b] = fma(wx, x[b], M[a][b]);
+                }
+            }
         }
     }
     bool bad = false;
+    // a predictor that is exactly zero at every neighbour (e.g. TDI on flat terrain) gives X'WX an exactly zero row:
+    // np.linalg.inv raises (interp_tair.py:1139) -- with the columns shifted to the cell that case would otherwise
+    // only be collinear, which rounding can hide from the Cholesky pivots below.  (ballots, restricted to the row)
+    const unsigned long long rowmask = 0xffffull << (16 * row);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        double s = wave_max_dpp(mx[q]);       // (32 wave reductions per item: DPP row shifts, not the LDS crossbar)
-        s = s > 0.0 ? 1.0 / s : 1.0;
+    for (int q = 0; q < 5; ++q)
+        if (!(__ballot(nz[q]) & rowmask)) bad = true;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) row[u][1 + q] *= s;
-        // a predictor that is exactly zero at every neighbour (e.g. TDI on flat terrain) gives X'WX an exactly
-        // zero row: np.linalg.inv raises (interp_tair.py:1139) -- with the columns shifted to the cell that case
-        // would otherwise only be collinear, which rounding can hide from the Cholesky pivots below
-        if (!__any(rawmx[q] != 0.0)) bad = true;             // (a ballot, not a sixth reduction)
-    }
-    // M = X'WX (lower triangle, 21 sums)
-    double M[6][6];
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            double s = 0.0;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) s += w[u] * row[u][a] * row[u][b];
-            M[a][b] = wave_sum_dpp(s);
-        }
-    }
-    // Cholesky with one reciprocal per pivot (33 fp64 divisions -> 6: the kernel is VALU bound and a division is
-    // a dozen instructions; the hat row changes in the last bit only, all consumers use the same stored z)
+        for (int b = 0; b <= a; ++b) M[a][b] = row16_sum(M[a][b]);
+    // Cholesky with one reciprocal per pivot (33 fp64 divisions -> 6: a division is a dozen instructions; the hat
+    // row changes in the last bit only, all consumers use the same stored z)
     double inv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -143,25 +168,178 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
         for (int p = i + 1; p < 6; ++p) s -= M[p][i] * a[p];
         a[i] = s * inv[i];
     }
+    // ---- pass 2: hat row z_j = w_j a'x_j (the neighbours' predictors come back from the caches) -----------------
     double zn = 0.0;
+    double *zout = gw.z + (lc * 12 + m0) * TWX_KZ;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        int r = lane + 64 * u;
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) t += a[q] * row[u][q];
-        double z = w[u] * t;
-        if (r < ka) {
-            gw.z[(lc * 12 + m0) * TWX_KZ + r] = z;
-            zn += z * nrm[u];
-            if (!finite_d(z)) bad = true;
+    for (int s = 0; s < TWX_GZ_SLOTS; ++s) {
+        if (s < nslot) {
+            const int r = tr + 16 * s;
+            if (r < ka) {
+                const int j = ni[r];
+                double t = a[0];
+                t = fma(a[1], st.lon[j] - cv.lon, t); t = fma(a[2], st.lat[j] - cv.lat, t);
+                t = fma(a[3], st.elev[j] - cv.elev, t); t = fma(a[4], st.tdi[j] - cv.tdi, t);
+                t = fma(a[5], st.lst[m0 * n + j] - plst, t);
+                const double z = w[s] * t;
+                zout[r] = z;
+                zn = fma(z, st.norm[m0 * n + j], zn);
+                if (!finite_d(z)) bad = true;
+            }
         }
     }
-    zn = wave_sum_dpp(zn);
-    bad = __any(bad);
-    if (lane == 0) {
-        double pn = pt_norm_in ? pt_norm_in[c] : ws.uk_mean[lc * 12 + m0];
+    zn = row16_sum(zn);
+    bad = (__ballot(bad) & rowmask) != 0;
+    if (tr == 0 && ka > 0) {
+        const double pn = pt_norm_in ? pt_norm_in[c] : ws.uk_mean[lc * 12 + m0];
         gw.zc[lc * 12 + m0] = pn - zn;
+        if (bad) gw.gstat[lc] = TWX_CELL_NUMERIC;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_gwr_z_cell (grid mode): the same hat rows, one work-group of 12 DPP rows (3 waves) per CELL, row = month.
+// k_gwr_z is bound by its gathers (14 scattered 8-byte loads per neighbour and month: the station columns of both
+// passes); the twelve GWR neighbourhoods of a cell are nested, so here the month-independent columns (lon, lat, elev,
+// tdi, shifted to the cell) and the distances are staged ONCE per cell in LDS and only lst / norm of the row's month
+// are gathered (2 per neighbour and month; lst waits in registers for the second pass).  Sum_j z_j norm_j is formed
+// as a'(X'W norm) from six more sums of pass 1, so pass 2 reads no station column at all.
+// Same arithmetic per sum as k_gwr_z (lane = neighbour r mod 16, row_shr reduction) -- the two kernels give the same
+// z bit for bit; zc differs in the last bits (a'v instead of sum z_j norm_j).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelWs ws, GwrWs gw)
+{
+    __shared__ double s_x[TWX_KSEL_MAX][4];
+    __shared__ double s_d[TWX_KSEL_MAX];
+    __shared__ int s_j[TWX_KSEL_MAX];
+    __shared__ int s_first[4];                               // lowest rank at which static column q is non-zero
+    const int t = threadIdx.x, tr = t & 15, m0 = t >> 4, lane = t & 63, row = lane >> 4;
+    const int lci = xcd_contig(blockIdx.x, (int)ws.ncell);
+    if (lci < 0) return;
+    const int64_t lc = lci;
+    if (ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0) return;   // (uniform)
+    const int64_t c = ws.cell0 + lc;
+    int kamax = 0;
+#pragma unroll
+    for (int m = 0; m < 12; ++m) kamax = max(kamax, ws.ka[lc * 12 + m]);
+    if (kamax <= 0) return;
+    const int ka = ws.ka[lc * 12 + m0];
+    const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    if (t < 4) s_first[t] = 0x7fffffff;
+    __syncthreads();
+    for (int r = t; r <= kamax && r < ws.ksel; r += 192) {   // (rank kamax carries the bandwidth distance of the largest month)
+        const int j = ws.near_idx[lc * ws.ksel + r];
+        s_j[r] = j;
+        s_d[r] = ws.near_dist[lc * ws.ksel + r];
+        if (r < kamax) {
+            const double raw[4] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j]};
+            s_x[r][0] = raw[0] - cv.lon; s_x[r][1] = raw[1] - cv.lat; s_x[r][2] = raw[2] - cv.elev; s_x[r][3] = raw[3] - cv.tdi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (raw[q] != 0.0) atomicMin(&s_first[q], r);
+        }
+    }
+    __syncthreads();
+    const double dbw = ka > 0 ? s_d[ka] : 1.0;
+    const int nslot = (kamax + 15) >> 4;                     // (uniform: every row walks the largest month's slots)
+
+    double M[6][6], v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        v[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) M[a][b] = 0.0;
+    }
+    double w[TWX_GZ_SLOTS], xl[TWX_GZ_SLOTS];
+    bool nzl = false;
+#pragma unroll
+    for (int s = 0; s < TWX_GZ_SLOTS; ++s) {
+        w[s] = 0.0; xl[s] = 0.0;
+        if (s < nslot) {
+            const int r = tr + 16 * s;
+            if (r < ka) {
+                const int j = s_j[r];
+                const double lraw = st.lst[m0 * n + j], nrm = st.norm[m0 * n + j];
+                const double wj = bisq(s_d[r], dbw);
+                w[s] = wj;
+                xl[s] = lraw - plst;
+                nzl = nzl || lraw != 0.0;
+                const double x[6] = {1.0, s_x[r][0], s_x[r][1], s_x[r][2], s_x[r][3], xl[s]};
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double wx = wj * x[a];
+                    v[a] = fma(wx, nrm, v[a]);
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) M[a][b] = fma(wx, x[b], M[a][b]);
+                }
+            }
+        }
+    }
+    bool bad = false;
+    const unsigned long long rowmask = 0xffffull << (16 * row);
+    // an exactly-zero predictor column (see k_gwr_z): static columns by the first rank that is non-zero, lst per row
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (!(s_first[q] < ka)) bad = true;
+    if (!(__ballot(nzl) & rowmask)) bad = true;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        v[a] = row16_sum(v[a]);
+#pragma unroll
+        for (int b = 0; b <= a; ++b) M[a][b] = row16_sum(M[a][b]);
+    }
+    double inv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = M[i][j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) s -= M[i][p] * M[j][p];
+            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); inv[i] = 1.0 / M[i][i]; }
+            else M[i][j] = s * inv[j];
+        }
+    }
+    double a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = (i == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < i; ++p) s -= M[i][p] * a[p];
+        a[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = a[i];
+#pragma unroll
+        for (int p = i + 1; p < 6; ++p) s -= M[p][i] * a[p];
+        a[i] = s * inv[i];
+    }
+    double *zout = gw.z + (lc * 12 + m0) * TWX_KZ;
+#pragma unroll
+    for (int s = 0; s < TWX_GZ_SLOTS; ++s) {
+        if (s < nslot) {
+            const int r = tr + 16 * s;
+            if (r < ka) {
+                double tt = a[0];
+                tt = fma(a[1], s_x[r][0], tt); tt = fma(a[2], s_x[r][1], tt);
+                tt = fma(a[3], s_x[r][2], tt); tt = fma(a[4], s_x[r][3], tt);
+                tt = fma(a[5], xl[s], tt);
+                const double z = w[s] * tt;
+                zout[r] = z;
+                if (!finite_d(z)) bad = true;
+            }
+        }
+    }
+    double zn = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) zn = fma(a[q], v[q], zn);
+    if (!finite_d(zn)) bad = true;
+    bad = (__ballot(bad) & rowmask) != 0;
+    if (tr == 0 && ka > 0) {
+        gw.zc[lc * 12 + m0] = ws.uk_mean[lc * 12 + m0] - zn;
         if (bad) gw.gstat[lc] = TWX_CELL_NUMERIC;
     }
 }

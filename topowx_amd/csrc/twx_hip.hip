@@ -349,8 +349,11 @@ int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, 
     HIPCHK(hipMemsetAsync(w.gstat.p, 0, (size_t)w.ws.ncell * 4, stream));
     EvScope ev(ctx, stream, EV_GWR);
     int64_t items = w.ws.ncell * 12;
-    hipLaunchKernelGGL(k_gwr_z, dim3((unsigned)(((items + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, stream, ctx->var[v].dev, src, w.ws,
-                       w.gw, pt_norm_dev);
+    if (src.mode == 0 && !pt_norm_dev)       // grid: one work-group per cell, the month-independent columns staged once
+        hipLaunchKernelGGL(k_gwr_z_cell, dim3((unsigned)((w.ws.ncell + 7) / 8 * 8)), dim3(192), 0, stream, ctx->var[v].dev, src, w.ws, w.gw);
+    else                                     // points: most of a point's twelve months are not asked for
+        hipLaunchKernelGGL(k_gwr_z, dim3((unsigned)(((items + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, stream, ctx->var[v].dev, src, w.ws,
+                           w.gw, pt_norm_dev);
     return 0;
 }
 

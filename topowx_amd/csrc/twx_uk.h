@@ -387,7 +387,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                                                                               // the next panel is factorised while this one is still being applied
     __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
-    __shared__ double s_red[NW][4];
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
@@ -449,49 +448,33 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     }
 
     // ---- staging: neighbours t, t + NTH (NP <= 2 NTH) ------------------------------------------
-    double xs[RPT][4], yv[RPT], c0v[RPT];
-    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    // The trend columns are shifted to the cell (that is what guards against cancellation) but NOT scaled: the
+    // bordered elimination and the 5x5 Cholesky of k_uk_solve have no pivoting, so a diagonal scaling of the trend
+    // columns changes nothing but roundings (componentwise backward error of Cholesky is scaling-invariant) -- and
+    // the per-neighbourhood max-scaling of rounds 1-2 cost four wave reductions, four fp64 divisions, an LDS round
+    // trip and a barrier per system (~260 VALU instructions per wave: 7 % of a 112-row system, 28 % of a 48-row one).
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const int q = t + NTH * u;
-        xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
         if (q < k) {
             const int j = jq[u];
             const double lo = st.lon[j], la = st.lat[j];
-            xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev; xs[u][3] = st.lst[m0 * n + j] - plst;
-            yv[u] = st.norm[m0 * n + j];
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
+            yv = st.norm[m0 * n + j];
             // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
-            e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
-            e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
+            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+        }
+        if (q < NP) {
+            s_B[0][q] = q < k ? 1.0 : 0.0;
+            s_B[1][q] = x0; s_B[2][q] = x1; s_B[3][q] = x2; s_B[4][q] = x3;
+            s_B[5][q] = yv; s_B[6][q] = c0v;
         }
     }
-    e0 = wave_max_dpp(e0); e1 = wave_max_dpp(e1); e2 = wave_max_dpp(e2); e3 = wave_max_dpp(e3);   // (non-negative: DPP row shifts, no LDS crossbar)
-    if (lane == 0) { s_red[wv][0] = e0; s_red[wv][1] = e1; s_red[wv][2] = e2; s_red[wv][3] = e3; }
     if (t == 0) s_err = 0;
     for (int q = t; q < 2 * NP * PS; q += NTH) (&s_pan[0][0])[q] = 0.0;   // finished rows are never written: keep them finite
-    __syncthreads();
-    {
-        double sc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double s = s_red[0][q];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) s = fmax(s, s_red[w][q]);
-            sc[q] = s > 0.0 ? 1.0 / s : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int q = t + NTH * u;
-            if (q < NP) {
-                s_B[0][q] = q < k ? 1.0 : 0.0;
-                s_B[1][q] = xs[u][0] * sc[0]; s_B[2][q] = xs[u][1] * sc[1]; s_B[3][q] = xs[u][2] * sc[2]; s_B[4][q] = xs[u][3] * sc[3];
-                s_B[5][q] = yv[u]; s_B[6][q] = c0v[u];
-            }
-        }
-    }
     __syncthreads();
 
     // ---- build this thread's elements: covariance of the cached pair distance (k_cell_dist) --------------

@@ -88,35 +88,25 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     }
 
     // ---- staging: neighbours t = lane, lane + 64 (NP <= 96) -----------------------------------
-    double xs[2][4], yv[2], c0v[2];
-    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    // (trend columns shifted to the cell, not scaled: see k_uk)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int t = lane + 64 * u;
-        xs[u][0] = xs[u][1] = xs[u][2] = xs[u][3] = 0.0; yv[u] = 0.0; c0v[u] = 0.0;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
         if (t < k) {
             const int j = jq[u];
             const double lo = st.lon[j], la = st.lat[j];
-            xs[u][0] = lo - cv.lon; xs[u][1] = la - cv.lat; xs[u][2] = st.elev[j] - cv.elev;
-            xs[u][3] = st.lst[m0 * n + j] - plst;
-            yv[u] = st.norm[m0 * n + j];
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev;
+            x3 = st.lst[m0 * n + j] - plst;
+            yv = st.norm[m0 * n + j];
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v[u] = same ? c00 : (double)cov_exp2(h0, chi, lgp);
-            e0 = fmax(e0, fabs(xs[u][0])); e1 = fmax(e1, fabs(xs[u][1]));
-            e2 = fmax(e2, fabs(xs[u][2])); e3 = fmax(e3, fabs(xs[u][3]));
+            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
-    }
-    e0 = wave_max_dpp(e0); e1 = wave_max_dpp(e1); e2 = wave_max_dpp(e2); e3 = wave_max_dpp(e3);   // (non-negative: DPP row shifts, no LDS crossbar)
-    const double sc0 = e0 > 0.0 ? 1.0 / e0 : 1.0, sc1 = e1 > 0.0 ? 1.0 / e1 : 1.0;
-    const double sc2 = e2 > 0.0 ? 1.0 / e2 : 1.0, sc3 = e3 > 0.0 ? 1.0 / e3 : 1.0;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = lane + 64 * u;
         if (t < NP) {
             s_B[0][t] = t < k ? 1.0 : 0.0;
-            s_B[1][t] = xs[u][0] * sc0; s_B[2][t] = xs[u][1] * sc1; s_B[3][t] = xs[u][2] * sc2; s_B[4][t] = xs[u][3] * sc3;
-            s_B[5][t] = yv[u]; s_B[6][t] = c0v[u];
+            s_B[1][t] = x0; s_B[2][t] = x1; s_B[3][t] = x2; s_B[4][t] = x3;
+            s_B[5][t] = yv; s_B[6][t] = c0v;
         }
     }
     for (int q = lane; q < NP * PS; q += 64) s_pan[q] = 0.0;   // finished rows are never written: keep them finite

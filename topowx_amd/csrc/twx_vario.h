@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     const double plst = cell_lst(src, c, m0);
     if (t == 0) s_bad = 0;
 
-    // ---- neighbours (rank order), trend columns shifted to the point and scaled exactly as in k_uk
+    // ---- neighbours (rank order), trend columns shifted to the point exactly as in k_uk
     double x[5] = {0, 0, 0, 0, 0}, y = 0, dh = 0;
     if (t < k) {
         const int j = ws.near_idx[lc * ws.ksel + t];
@@ -66,11 +66,7 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
         y = st.norm[m0 * n + j];
         dh = ws.near_dist[lc * ws.ksel + t];
     }
-#pragma unroll
-    for (int q = 1; q < 5; ++q) {
-        const double mx = block_max(fabs(x[q]), s_red);
-        x[q] = x[q] * (mx > 0.0 ? 1.0 / mx : 1.0);
-    }
+    // (unscaled, as in k_uk: the GLS beta of pass 1 is expressed in this basis)
     const double cutoff = 1.4 * block_max(dh, s_red);    // interp.R:63 (ngh_dist = haversine km)
 
     // ---- residuals ---------------------------------------------------------------------------------
