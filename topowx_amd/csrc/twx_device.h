@@ -19,6 +19,7 @@ struct StnDev {
     const double *lst, *norm, *optim, *optim_anom;              // [12][n]
     const double *nug, *psill, *rng;                            // [12][n]
     const double *sph, *cph, *slh, *clh;                        // sin/cos(lat/2), sin/cos(lon/2) [n]
+    const double *coslat;                                       // cos(lat * TWX_DEG2RAD) [n] (k_stn_coslat; k_tile_cand's fp32 bound)
     const float *obs;                                           // [n][ndays_mm] month-major days, or null
 };
 
@@ -96,6 +97,18 @@ __device__ __forceinline__ double hav_km(double lon1, double lat1, double lon2, 
     double s1 = sin(dlat / 2), s2 = sin(dlon / 2);
     double h = __dadd_rn(__dmul_rn(s1, s1), __dmul_rn(__dmul_rn(cos(lat1r), cos(lat2r)), __dmul_rn(s2, s2)));
     return TWX_EARTH_KM * (2 * asin(sqrt(h)));
+}
+
+__device__ __forceinline__ double cos_lat(double lat) { return cos(lat * TWX_DEG2RAD); }
+
+// fp32 haversine for CONSERVATIVE bounds only (k_tile_cand's candidate radius carries a 50 m margin; this is good to
+// ~1 m at the few hundred km it is used for: the coordinate differences are formed in fp64)
+__device__ __forceinline__ float hav_km_f32(double lon1, double lat1, float cos1, double lon2, double lat2, float cos2)
+{
+    const float dlat = (float)((lat1 - lat2) * (0.5 * TWX_DEG2RAD)), dlon = (float)((lon1 - lon2) * (0.5 * TWX_DEG2RAD));
+    const float s1 = sinf(dlat), s2 = sinf(dlon);
+    const float h = fmaf(cos1 * cos2, s2 * s2, s1 * s1);
+    return (float)(2.0 * TWX_EARTH_KM) * asinf(fminf(sqrtf(h), 1.f));
 }
 
 #define TWX_WGS84_A 6378.137

@@ -170,7 +170,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.vario.ensure((size_t)ncell * 36 * 8));
     HIPCHK(w.cstat.ensure((size_t)ncell * 4));
     HIPCHK(w.cdup.ensure((size_t)ncell * 4));
-    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * 15 * 4));
+    HIPCHK(w.bucket_cells.ensure((size_t)ncell * 12 * TWX_NBUCKET * 4));
     HIPCHK(w.uk_mean.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_var.ensure((size_t)ncell * 96));
     HIPCHK(w.uk_stat.ensure((size_t)ncell * 4));
@@ -202,7 +202,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
     s.ncand_max = w.small.as<int32_t>();          // [0]
     s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16..31]
-    s.small_kmax = TWX_UKW_MAXK;   // largest k handled by the one-wave kernel (k + 8 <= 96 rows; measured on the C2 bench)
+    s.reserved0 = 0;
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
     s.nnear = w.nnear.as<int32_t>(); s.kk = w.kk.as<int32_t>(); s.ka = w.ka.as<int32_t>();
@@ -257,6 +257,15 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
 #else
     hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB)>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 #endif
+}
+
+template <int NBR>
+void launch_ukwz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+{
+    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
+    if (cnt && cnt[bucket] <= 0) return;
+    const unsigned grid = krig_grid(cnt, bucket, max_items);
+    hipLaunchKernelGGL((k_ukwz<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
 template <int NBR, int HALF>
@@ -316,18 +325,20 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         else
             hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
         const int64_t mi = ncell * 12;
-        launch_ukw<6, 1>(cnt, st, src, w.ws, 13, mi, stream);   // k + 8 <= 88
-        launch_ukw<6, 0>(cnt, st, src, w.ws, 14, mi, stream);   // k + 8 <= 96
-        launch_ukw<3, 1>(cnt, st, src, w.ws, 0, mi, stream);    // k + 8 <= 40
-        launch_ukw<3, 0>(cnt, st, src, w.ws, 1, mi, stream);    // k + 8 <= 48
-        launch_ukw<4, 1>(cnt, st, src, w.ws, 2, mi, stream);    // k + 8 <= 56
-        launch_ukw<4, 0>(cnt, st, src, w.ws, 3, mi, stream);    // k + 8 <= 64
-        launch_ukw<5, 1>(cnt, st, src, w.ws, 4, mi, stream);    // k + 8 <= 72
-        launch_ukw<5, 0>(cnt, st, src, w.ws, 5, mi, stream);    // k + 8 <= 80
-        launch_uk<7>(cnt, st, src, w.ws, 9, mi, stream);        // k + 8 <= 112 (k > TWX_UKW_MAXK: two- / four-wave kernels)
-        launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);
-        launch_uk<9>(cnt, st, src, w.ws, 11, mi, stream);
-        launch_uk<10>(cnt, st, src, w.ws, 12, mi, stream);
+        // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
+        // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
+        launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
+        launch_ukw<6, 0>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
+        launch_ukw<3, 0>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
+        launch_ukwz<3>(cnt, st, src, w.ws, 1, mi, stream);      // 40 < k <= 48
+        launch_ukw<4, 0>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
+        launch_ukwz<4>(cnt, st, src, w.ws, 3, mi, stream);      // 56 < k <= 64
+        launch_ukw<5, 0>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
+        launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80
+        launch_uk<7>(cnt, st, src, w.ws, 8, mi, stream);        // 96 < k <= 104
+        launch_uk<8>(cnt, st, src, w.ws, 9, mi, stream);        // 104 < k <= 120
+        launch_uk<9>(cnt, st, src, w.ws, 10, mi, stream);       // 120 < k <= 136
+        launch_uk<10>(cnt, st, src, w.ws, 11, mi, stream);      // 136 < k <= 152
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit
@@ -504,8 +515,8 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     HIPCHK(hipSetDevice(ctx->device));
     VarData &vd = ctx->var[var];
     const size_t n = (size_t)t->n;
-    // one allocation: 4 static + 7 monthly + 4 trig columns
-    const size_t ncol = 4 + 7 * 12 + 4;
+    // one allocation: 4 static + 7 monthly + 4 trig columns + cos(lat) (filled on the device)
+    const size_t ncol = 4 + 7 * 12 + 4 + 1;
     std::vector<double> host(ncol * n);
     double *h = host.data();
     auto put = [&](const double *srcp, size_t cnt) { std::memcpy(h, srcp, cnt * 8); h += cnt; };
@@ -533,6 +544,9 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     s.nug = mcol + 48 * n; s.psill = mcol + 60 * n; s.rng = mcol + 72 * n;
     const double *tcol = mcol + 84 * n;
     s.sph = tcol; s.cph = tcol + n; s.slh = tcol + 2 * n; s.clh = tcol + 3 * n;
+    s.coslat = tcol + 4 * n;
+    hipLaunchKernelGGL(k_stn_coslat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.lat, const_cast<double *>(s.coslat), (int)n);
+    HIPCHK(hipGetLastError());
     s.obs = nullptr;
     vd.n = (int)n; vd.kmax = s.kmax; vd.has_obs = false;
     if (t->obs) {

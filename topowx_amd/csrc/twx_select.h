@@ -11,7 +11,6 @@
 #include "twx_device.h"
 
 #define TWX_UK_SLEN 29
-#define TWX_UKW_MAXK 88                                            // largest k of the one-wave kriging kernel
 #define TWX_DIST_NB ((TWX_MAX_NNGHS + 15) / 16)                 // block rows of the distance cache
 #define TWX_DIST_BLOCKS (TWX_DIST_NB * (TWX_DIST_NB + 1) / 2)
 
@@ -22,7 +21,7 @@ struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
     int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW)
     int init_nnghs;
-    int small_kmax;      // systems with k <= small_kmax go to the one-wave kernel (k_ukw)
+    int reserved0;
     int64_t cell0;       // first global cell id of the batch
     int64_t ncell;       // cells in the batch
     int64_t tile0;       // first tile id of the batch
@@ -40,8 +39,8 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *cdup;       // [ncell] lowest rank i whose neighbour coincides with an earlier one (k_cell_dist): systems with k > i are singular
-    int32_t *bucket_cnt; // [16]: 0..5 and 13, 14 one-wave kernel (8-row units 5..10, 11, 12), 9..12 multi-wave kernels k_uk<NB, NW> NB = 7..10
-    int32_t *bucket_cells; // [15][ncell * 12] (cell, month) items per matrix-size bucket
+    int32_t *bucket_cnt; // [16]: systems per bucket of twx_krig_bucket: 0..7 one-wave kernels (steps of 8 neighbours up to 96), 8..11 k_uk<7..10>
+    int32_t *bucket_cells; // [TWX_NBUCKET][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
@@ -56,6 +55,13 @@ struct SelWs {
     unsigned long long *dbg;
 #endif
 };
+
+// cos(latitude) of every station, by the device function hav_km() itself would call (twx_set_stations)
+__global__ void k_stn_coslat(const double *lat, double *out, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = cos_lat(lat[j]);
+}
 
 // ---------------------------------------------------------------------------------
 // k_tile_cand: one workgroup per tile (grid-stride).  Distances from the tile
@@ -109,10 +115,14 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
         // distances (float is enough for a conservative bound; margin below)
         float dmax = 0.f;
         int nvalid = 0;
+        const float ccos = (float)cos_lat(clat);
         for (int j = t; j < st.n; j += nth) {
-            double d = hav_km(clon, clat, st.lon[j], st.lat[j]);
-            float f = (float)d;
-            if (j == excl || (src.rm_zero && d == 0.0)) f = -1.f; // dropped (point mode)
+            // a conservative bound is all that is needed here (margin below): fp32 trigonometry.  The haversine is
+            // exactly 0 only for identical coordinates (sin(x) = 0 <=> x = 0 at these magnitudes): the zero-distance
+            // test of rm_zero_dist_stns (station_select.py:111-119) is the coordinate comparison
+            const double slon = st.lon[j], slat = st.lat[j];
+            float f = hav_km_f32(clon, clat, ccos, slon, slat, (float)st.coslat[j]);
+            if (j == excl || (src.rm_zero && slon == clon && slat == clat)) f = -1.f; // dropped (point mode)
             else { dmax = fmaxf(dmax, f); ++nvalid; }
             dsc[j] = f;
         }
@@ -544,12 +554,21 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 }
 
 // ---------------------------------------------------------------------------------
-// k_bucket_items: counting sort of the (cell, month) kriging items by matrix size.
-// NB = ceil((k + 8) / 16) block rows: k C rows + 7 RHS rows at the fixed rows
-// NP-7..NP-1, with the last C column kept out of the 4-column panel that holds the
-// first RHS column.  LDS counters per workgroup, one global atomic per (workgroup,
-// bucket).  Order inside a bucket is irrelevant (items are independent).
+// k_bucket_items: counting sort of the (cell, month) kriging items by matrix size, in steps of 8 neighbours.
+// With m = ceil(k / 16) block rows of 16:
+//   k <= 16 m - 8   bordered form: k C rows + 7 border rows at the fixed rows NP-7..NP-1 of NP = 16 m rows (the last C
+//                   column stays out of the 4-column panel that holds the first border column): k_ukw<m, 0> / k_uk<m>
+//   k >  16 m - 8   the border would open a block row of its own: k_ukwz<m> keeps it as columns beside NP = 16 m C rows
+//                   (twx_ukw.h) up to m = 6; larger systems take the bordered form with m + 1 block rows
+// LDS counters per workgroup, one global atomic per (workgroup, bucket).  Order inside a bucket is irrelevant.
 // ---------------------------------------------------------------------------------
+#define TWX_NBUCKET 12
+__host__ __device__ __forceinline__ int twx_krig_bucket(int k)
+{
+    const int e = (k + 7) / 8;                               // eighths: 5 (k <= 40) .. 19 (k <= 152)
+    const int b = (e < 5 ? 5 : (e > 19 ? 19 : e)) - 5;      // 0 .. 14
+    return b < 9 ? b : 9 + (b - 9) / 2;                      // from 105 neighbours on in steps of 16 (one kernel each)
+}
 __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 {
     __shared__ int s_cnt[16], s_base[16];
@@ -562,18 +581,12 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         const int64_t lc = item / 12;
         const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
         if (k > 0) {
-            if (k <= ws.small_kmax) {
-                int nb8 = (k + 8 + 7) / 8;
-                id = nb8 <= 10 ? (nb8 < 5 ? 5 : nb8) - 5 : 13 + (nb8 - 11);      // 11, 12 -> 13, 14
-            } else {
-                int nb = (k + 8 + 15) / 16;
-                id = 6 + (nb < 4 ? 4 : nb) - 4;
-            }
+            id = twx_krig_bucket(k);
             rank = atomicAdd(&s_cnt[id], 1);
         }
     }
     __syncthreads();
-    if (t < 15 && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
+    if (t < TWX_NBUCKET && s_cnt[t] > 0) s_base[t] = atomicAdd(&ws.bucket_cnt[t], s_cnt[t]);
     __syncthreads();
     if (id >= 0) ws.bucket_cells[(int64_t)id * ws.ncell * 12 + s_base[id] + rank] = (int32_t)item;
 }
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 __global__ void k_bucket_stats(SelWs ws, long long *stats)
 {
     const int b = threadIdx.x;
-    const int c = b < 15 ? ws.bucket_cnt[b] : 0;
+    const int c = b < TWX_NBUCKET ? ws.bucket_cnt[b] : 0;
     const int tot = wave_sum_i(c), nz = wave_sum_i(c > 0 ? 1 : 0);
     if (b == 0) { atomicAdd((unsigned long long *)&stats[0], (unsigned long long)tot); atomicAdd((unsigned long long *)&stats[1], (unsigned long long)(nz + 1)); }
 }

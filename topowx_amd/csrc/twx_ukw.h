@@ -239,3 +239,228 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     }
     if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (-nmax > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
 }
+
+// ---------------------------------------------------------------------------------
+// k_ukwz<NBR>: the same one-wave elimination with the seven border rows held as COLUMNS.
+//
+// The bordered form pads C's k rows + 7 border rows to a multiple of 16 ROWS -- and the rows at the end of a lower
+// triangle are the long ones.  For k in (16 NBR - 8, 16 NBR] the border would open a block row of its own (16 lanes
+// of every instruction for 7 rows); here the matrix holds the C rows only (NP = 16 NBR >= k rows, identity padding)
+// and the border B (7 x k) lives transposed in two registers per block row: lane (tr, tc) holds Z[16a + tr][tc] and
+// Z[16a + tr][4 + tc] (column 7 is a zero dummy).  Algebraically nothing changes -- an entry of a border row is
+// updated with the row factor of ITS COLUMN's matrix row (the u registers of the block row, already loaded) and the
+// border row's own panel factor (a DPP broadcast, as the column factors are) -- but every panel issues 8 fmacs per
+// block row for the border instead of 4 per block column of a whole extra block row: 15-23 % fewer fmacs at these
+// sizes (tests/tools/count_fmac.py), and one block row less of registers (96 rows fit one wave at 2 waves per SIMD:
+// the systems of 89..96 neighbours leave the two-wave kernel).  The panel's four border columns are published with
+// the panel (rows NP .. NP+6 of the panel image), row-solved like any other row, and the 7 x 7 corner B'C^-1B is
+// accumulated from the solved border factors in two registers of the lanes (tr = c', tc = c mod 4).
+// ---------------------------------------------------------------------------------
+#ifndef TWX_UKWZ_WV
+#define TWX_UKWZ_WV 2, 2, 3, 4   // NBR = 6, 5, 4, 3 (the budgets of the bordered kernels they replace: k_ukw<NBR + 1, 1>)
+#endif
+__host__ __device__ constexpr int twx_ukwz_waves(int nbr)
+{
+    constexpr int w[4] = {TWX_UKWZ_WV};
+    return w[6 - nbr];
+}
+
+template <int NBR>
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(twx_ukwz_waves(NBR), twx_ukwz_waves(NBR))))
+void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
+{
+    constexpr int NP = NBR * 16, NC = NP / 4, NT = 2 * NBR * (NBR + 1);
+    constexpr int NPX = NP + 8;     // rows of the panel image / slab: C rows + 7 border rows (+ 1 dummy)
+    constexpr int PS = 6;           // slab row stride (doubles): 48-byte rows, 16-B aligned
+    __shared__ __attribute__((aligned(16))) double s_pan[NPX * PS];
+    __shared__ __attribute__((aligned(16))) double s_raw[NPX * 4];
+    __shared__ double s_B[7][NP];
+
+    const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
+    const int it = xcd_contig(blockIdx.x, *nitems_dev);
+    if (it < 0) return;
+    const int item = item_list[it];
+    const int64_t lc = item / 12;
+    const int m0 = item % 12;
+    const int64_t c = ws.cell0 + lc;
+    const int k = ws.kk[lc * 12 + m0];
+    const size_t n = (size_t)st.n;
+    const CellVals cv = cell_load(src, c);
+    const double plst = cell_lst(src, c, m0);
+    const double nug = ws.vario[(lc * 12 + m0) * 3 + 0];
+    const double psill = ws.vario[(lc * 12 + m0) * 3 + 1];
+    const double rng = ws.vario[(lc * 12 + m0) * 3 + 2];
+    const double c00 = nug + psill;
+    const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
+    const float chi = (float)c2;
+    const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
+    const float lgp = __builtin_amdgcn_logf((float)psill_e);          // log2 psill (-inf for a pure nugget)
+    const int kdup = ws.cdup[lc];                                     // systems larger than this hold coincident neighbours: singular
+
+    int jq[2];
+    float h0q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = min(lane + 64 * u, ws.ksel - 1);
+        jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    float hd[NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
+    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            hd[widx(a, b)] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
+        });
+    });
+
+    // ---- staging: neighbours lane, lane + 64 (NP <= 96); trend columns shifted to the cell, not scaled (see k_uk)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * u;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
+        if (t < k) {
+            const int j = jq[u];
+            const double lo = st.lon[j], la = st.lat[j];
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev;
+            x3 = st.lst[m0 * n + j] - plst;
+            yv = st.norm[m0 * n + j];
+            const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
+            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+        }
+        if (t < NP) {
+            s_B[0][t] = t < k ? 1.0 : 0.0;
+            s_B[1][t] = x0; s_B[2][t] = x1; s_B[3][t] = x2; s_B[4][t] = x3;
+            s_B[5][t] = yv; s_B[6][t] = c0v;
+        }
+    }
+    for (int q = lane; q < NPX * PS; q += 64) s_pan[q] = 0.0;   // finished rows are never written: keep them finite
+    __syncthreads();
+
+    // ---- build (negated: the registers hold N = -M): C with an identity block in rows / columns k .. NP-1, and the
+    //      border transposed: Z[a][h] = -B[tc + 4h][16a + tr] (0 for the dummy column 7 and from row k on)
+    double A[NT], Z[NBR][2], Sacc[2] = {0.0, 0.0};
+    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        const int i = 16 * a + tr;
+        const float ca = i < k ? chi : -__builtin_inff();
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            const int j = 4 * b + tc;
+            // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
+            // not multiplied by -inf)
+            double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
+            if (b >= 4 * a && i == j) v = i < k ? c00 : 1.0;
+            A[widx(a, b)] = -v;
+        });
+        Z[a][0] = -s_B[tc][i];
+        Z[a][1] = tc < 3 ? -s_B[4 + (tc < 3 ? tc : 0)][i] : 0.0;
+    });
+    // ---- elimination: one panel per block column ----------------------------------------------------------
+    double nmax = -1.0;                                      // -(smallest pivot)
+    sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_)::value;
+        constexpr int a0 = b / 4;                            // block row holding rows / columns 4b..4b+3
+        if (k - 4 * b > 0) {                                 // uniform: the panel holds a C column
+            // (1) publish the panel as it is: its C rows, and its four border columns as rows NP .. NP+7
+            sfor<a0, NBR>([&](auto a_) __attribute__((always_inline)) {
+                constexpr int a = decltype(a_)::value;
+                s_raw[tc * NPX + 16 * a + tr] = A[widx(a, b)];
+            });
+            if ((tr >> 2) == (b & 3)) {
+                s_raw[(tr & 3) * NPX + NP + tc] = Z[a0][0];
+                s_raw[(tr & 3) * NPX + NP + 4 + tc] = Z[a0][1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (2) the 4x4 diagonal block, its Cholesky factor, one row solve per lane and round (see k_ukw)
+            const double *dg = &s_raw[4 * b];
+            const double g00 = dg[0];
+            const double2 g1 = double2{dg[1], dg[NPX + 1]};
+            const double2 g2 = double2{dg[2], dg[NPX + 2]};
+            const double g22 = dg[2 * NPX + 2];
+            const double2 g3 = double2{dg[3], dg[NPX + 3]};
+            const double2 g3b = double2{dg[2 * NPX + 3], dg[3 * NPX + 3]};
+            auto pivot = [&](double nd) __attribute__((always_inline)) {
+                nmax = max_raw(nmax, nd);
+                return -rsqrt_nr(-nd);
+            };
+            const double r0 = pivot(g00);
+            const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
+            const double r1 = pivot(fma(l10, l10, g1.y));
+            const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
+            const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
+            const double l32 = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
+            const double r3 = pivot(fma(l32, l32, fma(l31, l31, fma(l30, l30, g3b.y))));
+            constexpr int ROW0 = 4 * b + 4, NROW = NPX - ROW0;
+#pragma unroll
+            for (int u = 0; u < (NROW + 63) / 64; ++u) {
+                if (u) __builtin_amdgcn_wave_barrier();      // one round's registers at a time
+                const int row = ROW0 + lane + 64 * u;
+                if (row < NPX) {
+                    const double2 n01 = double2{s_raw[row], s_raw[NPX + row]};
+                    const double2 n23 = double2{s_raw[2 * NPX + row], s_raw[3 * NPX + row]};
+                    const double L0 = n01.x * r0;
+                    const double L1 = fma(L0, l10, n01.y) * r1;
+                    const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                    const double L3 = fma(L2, l32, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
+                    *reinterpret_cast<double2 *>(&s_pan[row * PS]) = double2{L0, L1};
+                    *reinterpret_cast<double2 *>(&s_pan[row * PS + 2]) = double2{L2, L3};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (3) rank-4 update: C block columns b+1 .., the border entries of the rows below the panel, the corner
+            {
+                // the panel factors of the border rows tc and 4 + tc (lane n of a DPP row holds factor n & 3) and of
+                // border row tr & 7 (the corner's other operand)
+                const double pz0 = s_pan[(NP + tc) * PS + (tr & 3)], pz1 = s_pan[(NP + 4 + tc) * PS + (tr & 3)];
+                const double2 c0 = *reinterpret_cast<const double2 *>(&s_pan[(NP + (tr & 7)) * PS]);
+                const double2 c1 = *reinterpret_cast<const double2 *>(&s_pan[(NP + (tr & 7)) * PS + 2]);
+                fmac_rowbcast<0>(Sacc[0], pz0, c0.x); fmac_rowbcast<1>(Sacc[0], pz0, c0.y);
+                fmac_rowbcast<2>(Sacc[0], pz0, c1.x); fmac_rowbcast<3>(Sacc[0], pz0, c1.y);
+                fmac_rowbcast<0>(Sacc[1], pz1, c0.x); fmac_rowbcast<1>(Sacc[1], pz1, c0.y);
+                fmac_rowbcast<2>(Sacc[1], pz1, c1.x); fmac_rowbcast<3>(Sacc[1], pz1, c1.y);
+                constexpr int NE = 4 * (NC - b - 1), NR = (NE + 15) / 16;
+                double P[NR > 0 ? NR : 1];
+                sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    const int e = min(16 * r + tr, NE - 1);
+                    P[r] = s_pan[(4 * (b + 1 + (e >> 2)) + tc) * PS + (e & 3)];
+                });
+                constexpr int a1 = (b + 1) / 4;              // first block row with rows below the panel
+                sfor<a1, NBR>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS + 2]);
+                    fmac_rowbcast<0>(Z[a][0], pz0, u0.x); fmac_rowbcast<1>(Z[a][0], pz0, u0.y);
+                    fmac_rowbcast<2>(Z[a][0], pz0, u1.x); fmac_rowbcast<3>(Z[a][0], pz0, u1.y);
+                    fmac_rowbcast<0>(Z[a][1], pz1, u0.x); fmac_rowbcast<1>(Z[a][1], pz1, u0.y);
+                    fmac_rowbcast<2>(Z[a][1], pz1, u1.x); fmac_rowbcast<3>(Z[a][1], pz1, u1.y);
+                    sfor<b + 1, 4 * a + 4>([&](auto bb_) __attribute__((always_inline)) {
+                        constexpr int bb = decltype(bb_)::value;
+                        constexpr int e = 4 * (bb - b - 1);
+                        double acc = A[widx(a, bb)];
+                        fmac_rowbcast<(e + 0) % 16>(acc, P[(e + 0) / 16], u0.x);
+                        fmac_rowbcast<(e + 1) % 16>(acc, P[(e + 1) / 16], u0.y);
+                        fmac_rowbcast<(e + 2) % 16>(acc, P[(e + 2) / 16], u1.x);
+                        fmac_rowbcast<(e + 3) % 16>(acc, P[(e + 3) / 16], u1.y);
+                        A[widx(a, bb)] = acc;
+                    });
+                });
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    });
+
+    // ---- Schur complement out (k_uk_solve finishes): lane (tr = c', tc) holds S[tc + 4h][c'] in Sacc[h] -------------
+    if (tr < 7) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = tc + 4 * h;
+            if (r < 7 && tr <= r) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + r * (r + 1) / 2 + tr] = Sacc[h];
+        }
+    }
+    if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (-nmax > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
+}
