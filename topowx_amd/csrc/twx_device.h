@@ -19,6 +19,11 @@ struct StnDev {
     const double *lst, *norm, *optim, *optim_anom;              // [12][n]
     const double *nug, *psill, *rng;                            // [12][n]
     const double *sph, *cph, *slh, *clh;                        // sin/cos(lat/2), sin/cos(lon/2) [n]
+    // station-major copies of the columns the monthly smoothing of k_select gathers for ALL twelve months of a
+    // neighbour (month-major columns cost one scattered 8-byte load -- one cache line -- per (neighbour, month, field):
+    // the selection was bound by the texture addresser, not by arithmetic)
+    const double *optim_s, *optim_anom_s;                       // [n][12]
+    const double *vario_s;                                      // [n][12][4] = nug, psill, rng, 0
     const double *coslat;                                       // cos(lat * TWX_DEG2RAD) [n] (k_stn_coslat; k_tile_cand's fp32 bound)
     const float *obs;                                           // [n][ndays_mm] month-major days, or null
 };

@@ -515,8 +515,9 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     HIPCHK(hipSetDevice(ctx->device));
     VarData &vd = ctx->var[var];
     const size_t n = (size_t)t->n;
-    // one allocation: 4 static + 7 monthly + 4 trig columns + cos(lat) (filled on the device)
-    const size_t ncol = 4 + 7 * 12 + 4 + 1;
+    // one allocation: 4 static + 7 monthly + 4 trig columns + cos(lat) (filled on the device) + the station-major
+    // copies of optim_nnghs / optim_nnghs_anom ([n][12]) and of the variogram parameters ([n][12][4])
+    const size_t ncol = 4 + 7 * 12 + 4 + 1 + 12 + 12 + 48;
     std::vector<double> host(ncol * n);
     double *h = host.data();
     auto put = [&](const double *srcp, size_t cnt) { std::memcpy(h, srcp, cnt * 8); h += cnt; };
@@ -528,6 +529,16 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     for (size_t i = 0; i < n; ++i) h[n + i] = std::cos(t->lat[i] * r / 2.0);
     for (size_t i = 0; i < n; ++i) h[2 * n + i] = std::sin(t->lon[i] * r / 2.0);
     for (size_t i = 0; i < n; ++i) h[3 * n + i] = std::cos(t->lon[i] * r / 2.0);
+    {
+        double *os = h + 5 * n, *oa = os + 12 * n, *vs = oa + 12 * n;      // (h[4n .. 5n) is cos(lat), filled on the device)
+        for (size_t i = 0; i < n; ++i)
+            for (size_t m = 0; m < 12; ++m) {
+                os[i * 12 + m] = t->optim_nnghs[m * n + i];
+                oa[i * 12 + m] = t->optim_nnghs_anom[m * n + i];
+                double *v = vs + (i * 12 + m) * 4;
+                v[0] = t->vario_nug[m * n + i]; v[1] = t->vario_psill[m * n + i]; v[2] = t->vario_rng[m * n + i]; v[3] = 0.0;
+            }
+    }
     double km = 0;
     for (size_t i = 0; i < 12 * n; ++i) {
         if (std::isfinite(t->optim_nnghs[i])) km = std::max(km, t->optim_nnghs[i]);
@@ -545,6 +556,7 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     const double *tcol = mcol + 84 * n;
     s.sph = tcol; s.cph = tcol + n; s.slh = tcol + 2 * n; s.clh = tcol + 3 * n;
     s.coslat = tcol + 4 * n;
+    s.optim_s = tcol + 5 * n; s.optim_anom_s = s.optim_s + 12 * n; s.vario_s = s.optim_anom_s + 12 * n;
     hipLaunchKernelGGL(k_stn_coslat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.lat, const_cast<double *>(s.coslat), (int)n);
     HIPCHK(hipGetLastError());
     s.obs = nullptr;

@@ -206,6 +206,26 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
 #define TWX_CAND_MAX 2048    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS)
 struct SmoothOut { int status; int k; };
 
+// v with lane L (wave-uniform index) replaced by the wave-uniform value x; lane L of v as a uniform value.  An fp64
+// division is ~30 instructions whether one lane needs it or 64: k_select parks the twelve months' numerators and
+// denominators in twelve lanes and divides ONCE (same operands, same IEEE quotient as month-by-month).
+__device__ __forceinline__ double put_lane(double v, double x, int L)
+{
+    return (int)(threadIdx.x & 63) == L ? x : v;
+}
+__device__ __forceinline__ double get_lane(double v, int L)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
+
+// bisquare weight with the bandwidth's reciprocal (the variogram smoothing: fp64 means, no integer behind them)
+__device__ __forceinline__ double bisq_r(double d, double inv_dbw)
+{
+    const double r = d * inv_dbw;
+    const double u = 1.0 - r * r;
+    return u * u;
+}
+
 __device__ __forceinline__ double bisq(double d, double dbw)
 {
     double r = d / dbw;
@@ -286,7 +306,11 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     int nv = 0;
     for (int j = lane; j < ncand; j += 64) {
         int s = cand[j];
+#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 3
+        double d = 1.0 + 1e-3 * (double)j + fabs(st.lon[s] - cv.lon);          // timing experiment only: no trigonometry
+#else
         double d = hav_km(cv.lon, cv.lat, st.lon[s], st.lat[s]);
+#endif
         if (s == excl || (src.rm_zero && d == 0.0)) d = INFINITY; else ++nv;
         sd[j] = d;
     }
@@ -328,6 +352,10 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
         m += __popcll(mask);
     }
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
+#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 1
+    for (int p = lane; p < m; p += 64) if (p < ws.ksel) snp[p] = p;            // timing experiment only: no ranking
+    if (false)
+#endif
     for (int p = lane; p < m; p += 64) {
         const double dj = sd[p];
         int rank = 0, eq = 0;                                // two compares + two adds per pair; equal distances are rare
@@ -366,6 +394,12 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;
     const bool given_vario = src.mode == 1 && src.vario_in && finite_d(src.vario_in[c * 3]);
+#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 2
+    if (only == 0 && k_in <= 0 && !given_vario) {                              // timing experiment only: no smoothing
+        if (lane < 12) { ws.kk[lc * 12 + lane] = 60 + lane; ws.ka[lc * 12 + lane] = 0; }
+        if (lane < 36) ws.vario[lc * 36 + lane] = (lane % 3 == 2) ? 40.0 : 0.5;
+    } else
+#endif
     if (only == 0 && k_in <= 0 && !given_vario) {
         // All twelve months at once (the grid path and whole-year point requests).  The month-by-month form below
         // runs 24-36 dependent rounds of gathers + wave reductions per cell; here the bandwidth smoothing of all
@@ -389,40 +423,62 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
         }
         // weighted mean of one field per month over Select(init_nnghs) -> rounded bandwidth, smooth3's status
         auto bandwidths = [&](const double *field, int (&kq)[12], int (&rq)[12]) __attribute__((always_inline)) {
+            double numv = 0.0, denv = 1.0;                   // lane m: month m's weighted sum / sum of weights
+            // the sum of weights runs over the neighbours whose value is finite: the same neighbours month after
+            // month in practice (a station outside the mask has no value in any month), so its wave reduction is
+            // repeated only when the pattern of finite neighbours changes (same addends, same order: same bits)
+            unsigned long long mprev[NS];
+            double den_prev = 0.0;
+            bool have_prev = false;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) mprev[u] = 0;
 #pragma unroll
             for (int g = 0; g < 12; g += GA) {               // GA months of gathers in flight
                 double v[GA][NS];
 #pragma unroll
                 for (int q = 0; q < GA; ++q)
 #pragma unroll
-                    for (int u = 0; u < NS; ++u)
-                        v[q][u] = (jn[u] >= 0 && lane + 64 * u < kinit) ? field[(g + q) * n + jn[u]] : NAN;
+                    for (int u = 0; u < NS; ++u)      // station-major: the GA months of a neighbour are 8 GA contiguous bytes
+                        v[q][u] = (jn[u] >= 0 && lane + 64 * u < kinit) ? field[(size_t)jn[u] * 12 + (g + q)] : NAN;
 #pragma unroll
                 for (int q = 0; q < GA; ++q) {
                     double n0 = 0, den = 0;
                     int cnt = 0;
+                    bool same = have_prev;
 #pragma unroll
                     for (int u = 0; u < NS; ++u) {
                         const bool fin = finite_d(v[q][u]);
-                        cnt += __popcll(__ballot(fin));
+                        const unsigned long long mk = __ballot(fin);
+                        cnt += __popcll(mk);
+                        same = same && mk == mprev[u];
+                        mprev[u] = mk;
                         if (fin) { n0 += v[q][u] * wi[u]; den += wi[u]; }
                     }
-                    n0 = wave_sum_dpp(n0); den = wave_sum_dpp(den);
-                    int rc = rc_init, kk = 0;
+                    n0 = wave_sum_dpp(n0);
+                    den = same ? den_prev : wave_sum_dpp(den);   // (uniform branch)
+                    den_prev = den; have_prev = true;
+                    int rc = rc_init;
                     if (!rc && cnt == 0) rc = TWX_CELL_NNGHS;
                     if (!rc && !(den != 0.0)) rc = TWX_CELL_NUMERIC;
-                    if (!rc) { kk = (int)rint(n0 / den); if (kk < 1 || kk > TWX_MAX_NNGHS) rc = TWX_CELL_RANGE; }
-                    kq[g + q] = __builtin_amdgcn_readfirstlane(kk); rq[g + q] = __builtin_amdgcn_readfirstlane(rc);   // scalars: SGPRs
+                    rq[g + q] = __builtin_amdgcn_readfirstlane(rc);   // scalars: SGPRs
+                    if (!rc) { numv = put_lane(numv, n0, g + q); denv = put_lane(denv, den, g + q); }
                 }
+            }
+            const double quot = rint(numv / denv);           // all twelve months at once (lanes 0..11)
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                int kk = 0, rc = rq[m];
+                if (!rc) { kk = (int)get_lane(quot, m); if (kk < 1 || kk > TWX_MAX_NNGHS) rc = TWX_CELL_RANGE; }
+                kq[m] = __builtin_amdgcn_readfirstlane(kk); rq[m] = __builtin_amdgcn_readfirstlane(rc);
             }
         };
         int kq[12], rq[12], kaq[12], raq[12], rvq[12];
 #pragma unroll
         for (int m = 0; m < 12; ++m) { kq[m] = kaq[m] = 0; rq[m] = raq[m] = rvq[m] = TWX_CELL_OK; }
         if (!(src.do_krig && src.do_vario) && lane < 36) ws.vario[lc * 36 + lane] = 0.0;
-        if (src.do_krig) bandwidths(st.optim, kq, rq);
+        if (src.do_krig) bandwidths(st.optim_s, kq, rq);
         if (src.do_anom) {
-            bandwidths(st.optim_anom, kaq, raq);
+            bandwidths(st.optim_anom_s, kaq, raq);
 #pragma unroll
             for (int m = 0; m < 12; ++m) {                   // GwrTairAnom.__get_nnghs (interp_tair.py:245-259)
                 if (!raq[m] && kaq[m] >= nnear) raq[m] = TWX_CELL_FEW_STATIONS;
@@ -431,7 +487,9 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
             }
         }
         if (src.do_krig) {
-            // KrigTair.__get_vario_params (interp_tair.py:837-851): weights of Select(k_m), GB months per round
+            // KrigTair.__get_vario_params (interp_tair.py:837-851): weights of Select(k_m), GB months per round;
+            // lane 3 m + f collects month m's numerator f and denominator: one division and one coalesced store
+            double vnum = 0.0, vden = 1.0;
 #pragma unroll
             for (int g = 0; g < 12; g += GB) {
                 double w[GB][NS], f[GB][3][NS];
@@ -442,14 +500,15 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
                     rc[q] = rq[m];
                     if (!rc[q] && k >= nnear) rc[q] = TWX_CELL_FEW_STATIONS;
                     if (!rc[q] && !(snd[k] > 0.0)) rc[q] = TWX_CELL_NUMERIC;
-                    const double dbw = rc[q] ? 1.0 : snd[k];
+                    const double inv_dbw = 1.0 / (rc[q] ? 1.0 : snd[k]);   // (one division per month instead of one per neighbour)
 #pragma unroll
                     for (int u = 0; u < NS; ++u) {
                         const bool act = !rc[q] && src.do_vario && lane + 64 * u < k;
-                        w[q][u] = act ? bisq(dn[u], dbw) : 0.0;
-                        f[q][0][u] = act ? st.nug[m * n + jn[u]] : NAN;
-                        f[q][1][u] = act ? st.psill[m * n + jn[u]] : 0.0;
-                        f[q][2][u] = act ? st.rng[m * n + jn[u]] : 0.0;
+                        w[q][u] = act ? bisq_r(dn[u], inv_dbw) : 0.0;
+                        const double *vs = st.vario_s + ((size_t)(act ? jn[u] : 0) * 12 + m) * 4;   // nug, psill, rng: 24 contiguous bytes
+                        f[q][0][u] = act ? vs[0] : NAN;
+                        f[q][1][u] = act ? vs[1] : 0.0;
+                        f[q][2][u] = act ? vs[2] : 0.0;
                     }
                 }
 #pragma unroll
@@ -468,15 +527,13 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
                         if (!rc[q] && cnt == 0) rc[q] = TWX_CELL_VARIO;
                         if (!rc[q] && !(den != 0.0)) rc[q] = TWX_CELL_NUMERIC;
                         if (rc[q]) n0 = n1 = n2 = 0.0, den = 1.0;
-                        if (lane == 0) {
-                            ws.vario[(lc * 12 + m) * 3 + 0] = n0 / den;
-                            ws.vario[(lc * 12 + m) * 3 + 1] = n1 / den;
-                            ws.vario[(lc * 12 + m) * 3 + 2] = n2 / den;
-                        }
+                        vnum = put_lane(vnum, n0, 3 * m); vnum = put_lane(vnum, n1, 3 * m + 1); vnum = put_lane(vnum, n2, 3 * m + 2);
+                        vden = put_lane(vden, den, 3 * m); vden = put_lane(vden, den, 3 * m + 1); vden = put_lane(vden, den, 3 * m + 2);
                     }
                     rvq[m] = __builtin_amdgcn_readfirstlane(rc[q]);   // (without do_vario: only Select(k) must exist)
                 }
             }
+            if (src.do_vario && lane < 36) ws.vario[lc * 36 + lane] = vnum / vden;
         }
         // resolve month by month: the first failure sticks (the reference abandons the point)
 #pragma unroll
