@@ -522,9 +522,10 @@ def main():
     kpos = ks[ks > 0]
     flops_per_solve = float(uk_flops(kpos).mean())
     flops_exec = float(uk_flops_executed(kpos).mean())
-    # systems per kriging launch: matrix rows (k + 8, rounded up to the kernel's size) -> count
-    edges = np.array([40, 48, 56, 64, 72, 80, 88, 96, 112, 128, 144, 160])
-    rows_hist = np.bincount(np.searchsorted(edges, kpos + 8), minlength=edges.size + 1)
+    # systems per kriging launch (twx_krig_bucket, twx_select.h): largest k of the bucket -> count
+    edges = np.array([40, 48, 56, 64, 72, 80, 88, 96, 104, 120, 136, 152])
+    bidx = np.searchsorted(edges, kpos)
+    rows_hist = np.bincount(bidx, minlength=edges.size + 1)
     ach_tflops = flops_per_solve * solves / (uk_ms * 1e-3) / 1e12
     ach_tflops_exec = flops_exec * solves / (uk_ms * 1e-3) / 1e12
     # PMC counters cannot be read from inside the process: the committed measurement of THIS workload is quoted
@@ -560,7 +561,14 @@ def main():
                  "distance_flops_share": float(uk_flops_distance(kpos).mean()) / flops_per_solve,
                  "note": "frac = SURVEY 8d's nominal flops (k^3/3 + 7k^2 + 30k(k-1)) / kernel time / peak; frac_executed counts "
                          "k^3/3 + 7k^2 only (Cholesky + border rows)",
-                 "systems_by_matrix_rows": {str(int(e)): int(c) for e, c in zip(edges, rows_hist) if c}},
+                 "systems_by_bucket_kmax": {str(int(e)): int(c) for e, c in zip(edges, rows_hist) if c},
+                 # executed flops (k^3/3 + 7k^2) of a step's systems per bucket: tests/tools/reduce_sq.py divides the fp64
+                 # FMAs a kernel ISSUED (SQ counters) by the FMAs these flops NEED (128 flops per wave instruction)
+                 "executed_flops_by_bucket_kmax": {str(int(e)): float(uk_flops_executed(kpos[bidx == i]).sum())
+                                                   for i, e in enumerate(edges) if (bidx == i).any()},
+                 "kernels_by_bucket_kmax": {"40": "k_ukw<3,0>", "48": "k_ukwz<3>", "56": "k_ukw<4,0>", "64": "k_ukwz<4>", "72": "k_ukw<5,0>",
+                                            "80": "k_ukwz<5>", "88": "k_ukw<6,0>", "96": "k_ukwz<6>", "104": "k_uk<7,2>", "120": "k_uk<8,4>",
+                                            "136": "k_uk<9,2>", "152": "k_uk<10,2>"}},
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},
     }

@@ -131,6 +131,24 @@ def test_pack(orc, golden):
     assert np.array_equal(orc.pack_i16(golden["pk_in"]), golden["pk_out"])
 
 
+def test_pack_identity(orc):
+    """The GPU packs a value as (int16) rint(100 x) (twx_daily.h: pack_i16); the reference's expression
+    np.round(x, 2) / np.float32(0.01) truncated on assignment (step25:163-164) -- which the oracle keeps literally --
+    is the same integer for EVERY n = rint(100 x) an int16 product can hold (and twice that range): exhaustive."""
+    n = np.arange(-70000, 70001).astype(np.float64)
+    c = np.float64(np.float32(0.01))
+    assert np.array_equal(np.trunc((n / 100.0) / c), n)
+    # through the oracle's own packing, on values straddling every rounding boundary of the int16 range
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-327.6, 327.6, 200000), (np.arange(-32760, 32760) + 0.5) / 100.0,
+                        np.nextafter((np.arange(-32760, 32760) + 0.5) / 100.0, 1e9), golden_like_values()])
+    assert np.array_equal(orc.pack_i16(x), np.rint(x * 100.0).astype(np.int64).astype(np.int16))
+
+
+def golden_like_values():
+    return np.array([12.345, -12.345, -0.015, 25.675, 0.0, -0.0, 0.005, -0.005, 327.67, -327.67, 1e-300])
+
+
 def test_ladder(golden):
     from topowx_amd.synth import NNGH_LADDER
     assert np.array_equal(golden["ladder"], NNGH_LADDER)

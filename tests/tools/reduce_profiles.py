@@ -9,9 +9,9 @@ import os
 import sys
 
 out = sys.argv[1]
-KRIG = ("k_uk<", "k_ukw<", "k_cell_dist", "k_tile_dist")   # the kernels behind bench.py's uk_ms
+KRIG = ("k_uk<", "k_ukw<", "k_ukwz<", "k_cell_dist", "k_tile_dist")   # the kernels behind bench.py's uk_ms
 DAILY = ("k_daily_tile", "k_tile_union", "k_row_offsets", "k_daily_ok", "k_daily_grid")   # ... daily_ms
-DAILY_ONLY = DAILY + ("k_gwr_z", "k_fix_cells", "k_compact_flags")
+DAILY_ONLY = DAILY + ("k_gwr_z", "k_gwr_z_cell", "k_fix_cells", "k_compact_flags")
 
 
 def short(name):
@@ -48,7 +48,7 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
             fh.write('"%s",%d,%.1f\n' % (k, n, v))
     n, kb = group(per, KRIG)
     res[key] = {"k_uk_launches": n, "k_uk_total_KB": kb, "k_uk_per_launch_bytes": kb * 1024.0 / max(n, 1),
-                "kernels": "k_tile_dist + k_ukw<..> + k_uk<..> (headline workload only)"}
+                "kernels": "k_tile_dist + k_ukw<..> + k_ukwz<..> + k_uk<..> (headline workload only)"}
     dper = pmc(dsub, pre, key)
     if dper:
         with open(os.path.join(out, "pmc_daily_%s.csv" % key), "w") as fh:
@@ -56,13 +56,13 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
             for k, (n, v) in sorted(dper.items(), key=lambda kv: -kv[1][1]):
                 if k.startswith(DAILY_ONLY):
                     fh.write('"%s",%d,%.1f\n' % (k, n, v))
-        for o in ("k_daily_tile", "k_daily_tile_gather", "k_tile_union", "k_gwr_z", "k_fix_cells"):
+        for o in ("k_daily_tile", "k_daily_tile_gather", "k_tile_union", "k_gwr_z", "k_gwr_z_cell", "k_fix_cells"):
             n, kb = group(dper, (o,), exact=True)
             res[key][o] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
         # the launches behind bench.py's daily.timing_ms.daily_ms + gwr_ms, per daily step (Tmin + Tmax): the record's
         # measured traffic (steps = dispatches of k_daily_tile)
         steps = max(1, group(dper, ("k_daily_tile",), exact=True)[0])
-        n, kb = group(dper, DAILY + ("k_gwr_z",))
+        n, kb = group(dper, DAILY + ("k_gwr_z",))            # (prefix: k_gwr_z_cell too)
         res[key]["daily_path_per_step_bytes"] = kb * 1024.0 / steps
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 

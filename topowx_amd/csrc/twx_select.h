@@ -306,11 +306,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     int nv = 0;
     for (int j = lane; j < ncand; j += 64) {
         int s = cand[j];
-#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 3
-        double d = 1.0 + 1e-3 * (double)j + fabs(st.lon[s] - cv.lon);          // timing experiment only: no trigonometry
-#else
         double d = hav_km(cv.lon, cv.lat, st.lon[s], st.lat[s]);
-#endif
         if (s == excl || (src.rm_zero && d == 0.0)) d = INFINITY; else ++nv;
         sd[j] = d;
     }
@@ -352,10 +348,6 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
         m += __popcll(mask);
     }
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
-#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 1
-    for (int p = lane; p < m; p += 64) if (p < ws.ksel) snp[p] = p;            // timing experiment only: no ranking
-    if (false)
-#endif
     for (int p = lane; p < m; p += 64) {
         const double dj = sd[p];
         int rank = 0, eq = 0;                                // two compares + two adds per pair; equal distances are rare
@@ -394,12 +386,6 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     const int k_in = (src.mode == 1 && src.nnghs_in) ? src.nnghs_in[c] : 0;
     const size_t n = (size_t)st.n;
     const bool given_vario = src.mode == 1 && src.vario_in && finite_d(src.vario_in[c * 3]);
-#if defined(TWX_SEL_ABLATE) && TWX_SEL_ABLATE == 2
-    if (only == 0 && k_in <= 0 && !given_vario) {                              // timing experiment only: no smoothing
-        if (lane < 12) { ws.kk[lc * 12 + lane] = 60 + lane; ws.ka[lc * 12 + lane] = 0; }
-        if (lane < 36) ws.vario[lc * 36 + lane] = (lane % 3 == 2) ? 40.0 : 0.5;
-    } else
-#endif
     if (only == 0 && k_in <= 0 && !given_vario) {
         // All twelve months at once (the grid path and whole-year point requests).  The month-by-month form below
         // runs 24-36 dependent rounds of gathers + wave reductions per cell; here the bandwidth smoothing of all
