@@ -58,6 +58,16 @@ struct GwrWs {
 // ---------------------------------------------------------------------------------
 #define TWX_GZ_SLOTS ((TWX_MAX_NNGHS + 15) / 16)   // neighbours per lane
 
+// 1 / sqrt(d): hardware seed + two Newton steps (relative error ~1e-16; NaN / inf for d <= 0 as sqrt + division gave)
+__device__ __forceinline__ double gz_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
 // sum over the 16 lanes of a DPP row, returned in all of them
 __device__ __forceinline__ double row16_sum(double v)
 {
@@ -88,7 +98,9 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
     const size_t n = (size_t)st.n;
     const CellVals cv = cell_load(src, c);
     const double plst = cell_lst(src, c, m0);
-    const double dbw = ka > 0 ? ws.near_dist[lc * ws.ksel + ka] : 1.0;
+    // (one reciprocal per item instead of one fp64 division per neighbour: z moves in its last bit, every consumer
+    // reads the stored z)
+    const double inv_dbw = 1.0 / (ka > 0 ? ws.near_dist[lc * ws.ksel + ka] : 1.0);
     const int32_t *ni = ws.near_idx + lc * ws.ksel;
     const double *nd = ws.near_dist + lc * ws.ksel;
     int kamax = ka;                                          // slots this wave walks (uniform)
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             const int r = tr + 16 * s;
             if (r < ka) {
                 const int j = ni[r];
-                const double wj = bisq(nd[r], dbw);
+                const double wj = bisq_r(nd[r], inv_dbw);
                 w[s] = wj;
                 const double raw[5] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j], st.lst[m0 * n + j]};
                 const double x[6] = {1.0, raw[0] - cv.lon, raw[1] - cv.lat, raw[2] - cv.elev, raw[3] - cv.tdi, raw[4] - plst};
@@ -148,7 +160,9 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
             double s = M[i][j];
 #pragma unroll
             for (int p = 0; p < j; ++p) s -= M[i][p] * M[j][p];
-            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); inv[i] = 1.0 / M[i][i]; }
+            // pivot: 1 / sqrt(s) from v_rsq_f64 + two Newton steps (full precision; a square root and a division are
+            // ~45 instructions), sqrt(s) = s * rsqrt(s)
+            if (i == j) { if (!(s > 0.0)) bad = true; inv[i] = gz_rsqrt(s); M[i][i] = s * inv[i]; }
             else M[i][j] = s * inv[j];
         }
     }
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
         }
     }
     __syncthreads();
-    const double dbw = ka > 0 ? s_d[ka] : 1.0;
+    const double inv_dbw = 1.0 / (ka > 0 ? s_d[ka] : 1.0);
     const int nslot = (kamax + 15) >> 4;                     // (uniform: every row walks the largest month's slots)
 
     double M[6][6], v[6];
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
             if (r < ka) {
                 const int j = s_j[r];
                 const double lraw = st.lst[m0 * n + j], nrm = st.norm[m0 * n + j];
-                const double wj = bisq(s_d[r], dbw);
+                const double wj = bisq_r(s_d[r], inv_dbw);
                 w[s] = wj;
                 xl[s] = lraw - plst;
                 nzl = nzl || lraw != 0.0;
@@ -298,7 +312,9 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
             double s = M[i][j];
 #pragma unroll
             for (int p = 0; p < j; ++p) s -= M[i][p] * M[j][p];
-            if (i == j) { if (!(s > 0.0)) bad = true; M[i][i] = sqrt(s); inv[i] = 1.0 / M[i][i]; }
+            // pivot: 1 / sqrt(s) from v_rsq_f64 + two Newton steps (full precision; a square root and a division are
+            // ~45 instructions), sqrt(s) = s * rsqrt(s)
+            if (i == j) { if (!(s > 0.0)) bad = true; inv[i] = gz_rsqrt(s); M[i][i] = s * inv[i]; }
             else M[i][j] = s * inv[j];
         }
     }
