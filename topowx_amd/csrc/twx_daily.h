@@ -248,7 +248,8 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
         s_j[r] = j;
         s_d[r] = ws.near_dist[lc * ws.ksel + r];
         if (r < kamax) {
-            const double raw[4] = {st.lon[j], st.lat[j], st.elev[j], st.tdi[j]};
+            const double4 sr = st.stat_s[j];
+            const double raw[4] = {sr.x, sr.y, sr.z, sr.w};
             s_x[r][0] = raw[0] - cv.lon; s_x[r][1] = raw[1] - cv.lat; s_x[r][2] = raw[2] - cv.elev; s_x[r][3] = raw[3] - cv.tdi;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
             const int r = tr + 16 * s;
             if (r < ka) {
                 const int j = s_j[r];
-                const double lraw = st.lst[m0 * n + j], nrm = st.norm[m0 * n + j];
+                const double2 mr = st.mon_s[(size_t)j * 12 + m0];      // (lst, norm): one 16-byte load
+                const double lraw = mr.x, nrm = mr.y;
                 const double wj = bisq_r(s_d[r], inv_dbw);
                 w[s] = wj;
                 xl[s] = lraw - plst;

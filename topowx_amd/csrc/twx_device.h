@@ -24,6 +24,8 @@ struct StnDev {
     // the selection was bound by the texture addresser, not by arithmetic)
     const double *optim_s, *optim_anom_s;                       // [n][12]
     const double *vario_s;                                      // [n][12][4] = nug, psill, rng, 0
+    const double4 *stat_s;                                      // [n] station record (lon, lat, elev, tdi)
+    const double2 *mon_s;                                       // [n][12] (lst, norm)
     const double *coslat;                                       // cos(lat * TWX_DEG2RAD) [n] (k_stn_coslat; k_tile_cand's fp32 bound)
     const float *obs;                                           // [n][ndays_mm] month-major days, or null
 };

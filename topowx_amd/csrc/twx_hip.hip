@@ -518,7 +518,10 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     // one allocation: 4 static + 7 monthly + 4 trig columns + cos(lat) (filled on the device) + the station-major
     // copies of optim_nnghs / optim_nnghs_anom ([n][12]) and of the variogram parameters ([n][12][4])
     const size_t ncol = 4 + 7 * 12 + 4 + 1 + 12 + 12 + 48;
-    std::vector<double> host(ncol * n);
+    // ... + station records: (lon, lat, elev, tdi)[n] and (lst, norm)[n][12], 32-byte aligned behind the columns: what
+    // the kriging / GWR staging reads of a neighbour comes with two or three 16-byte loads instead of five gathers
+    const size_t rec0 = (ncol * n + 3) / 4 * 4;              // (in doubles)
+    std::vector<double> host(rec0 + 4 * n + 24 * n);
     double *h = host.data();
     auto put = [&](const double *srcp, size_t cnt) { std::memcpy(h, srcp, cnt * 8); h += cnt; };
     put(t->lon, n); put(t->lat, n); put(t->elev, n); put(t->tdi, n);
@@ -544,6 +547,13 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
         if (std::isfinite(t->optim_nnghs[i])) km = std::max(km, t->optim_nnghs[i]);
         if (std::isfinite(t->optim_nnghs_anom[i])) km = std::max(km, t->optim_nnghs_anom[i]);
     }
+    {
+        double *ss = host.data() + rec0, *ms = ss + 4 * n;
+        for (size_t i = 0; i < n; ++i) {
+            ss[4 * i + 0] = t->lon[i]; ss[4 * i + 1] = t->lat[i]; ss[4 * i + 2] = t->elev[i]; ss[4 * i + 3] = t->tdi[i];
+            for (size_t m = 0; m < 12; ++m) { ms[(i * 12 + m) * 2] = t->lst[m * n + i]; ms[(i * 12 + m) * 2 + 1] = t->norm[m * n + i]; }
+        }
+    }
     HIPCHK(vd.cols.ensure(host.size() * 8));
     HIPCHK(hipMemcpy(vd.cols.p, host.data(), host.size() * 8, hipMemcpyHostToDevice));
     const double *d = vd.cols.as<double>();
@@ -557,6 +567,7 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     s.sph = tcol; s.cph = tcol + n; s.slh = tcol + 2 * n; s.clh = tcol + 3 * n;
     s.coslat = tcol + 4 * n;
     s.optim_s = tcol + 5 * n; s.optim_anom_s = s.optim_s + 12 * n; s.vario_s = s.optim_anom_s + 12 * n;
+    s.stat_s = reinterpret_cast<const double4 *>(d + rec0); s.mon_s = reinterpret_cast<const double2 *>(d + rec0 + 4 * n);
     hipLaunchKernelGGL(k_stn_coslat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.lat, const_cast<double *>(s.coslat), (int)n);
     HIPCHK(hipGetLastError());
     s.obs = nullptr;

@@ -459,9 +459,11 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
         if (q < k) {
             const int j = jq[u];
-            const double lo = st.lon[j], la = st.lat[j];
-            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev; x3 = st.lst[m0 * n + j] - plst;
-            yv = st.norm[m0 * n + j];
+            const double4 sr = st.stat_s[j];                 // station record: two 16-byte loads + one for (lst, norm)
+            const double2 mr = st.mon_s[(size_t)j * 12 + m0];
+            const double lo = sr.x, la = sr.y;
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = sr.z - cv.elev; x3 = mr.x - plst;
+            yv = mr.y;
             // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;

@@ -95,10 +95,12 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
         if (t < k) {
             const int j = jq[u];
-            const double lo = st.lon[j], la = st.lat[j];
-            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev;
-            x3 = st.lst[m0 * n + j] - plst;
-            yv = st.norm[m0 * n + j];
+            const double4 sr = st.stat_s[j];                 // station record (see k_uk)
+            const double2 mr = st.mon_s[(size_t)j * 12 + m0];
+            const double lo = sr.x, la = sr.y;
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = sr.z - cv.elev;
+            x3 = mr.x - plst;
+            yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
@@ -323,10 +325,12 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
         double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
         if (t < k) {
             const int j = jq[u];
-            const double lo = st.lon[j], la = st.lat[j];
-            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = st.elev[j] - cv.elev;
-            x3 = st.lst[m0 * n + j] - plst;
-            yv = st.norm[m0 * n + j];
+            const double4 sr = st.stat_s[j];                 // station record (see k_uk)
+            const double2 mr = st.mon_s[(size_t)j * 12 + m0];
+            const double lo = sr.x, la = sr.y;
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = sr.z - cv.elev;
+            x3 = mr.x - plst;
+            yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
