@@ -53,6 +53,64 @@ def test_sampled_cells_vs_oracle(c2, orc):
     assert worst < 1e-4, worst                                           # north_star tolerance (degC)
 
 
+def test_c2_every_cell_vs_oracle(c2, orc):
+    """BASELINE.json configs[1] exhaustively: all 62 500 cells x 12 months of the C2 tile (normals + SE) against the oracle
+    (status equal, <= 1e-4 degC).  The oracle does ~6e4 cell-months/s on the GPU box's host cores (13 s for the tile); on
+    a small host (< 32 threads) every fifth row is compared instead."""
+    import os
+    full, grid, stn = c2["full"], c2["grid"], c2["stn"]
+    ncpu = os.cpu_count() or 1
+    bands = [slice(r0, r0 + 50) for r0 in range(0, 250, 50)] if ncpu >= 32 else [slice(r, r + 1) for r in range(0, 250, 5)]
+    db, prm = orc.Db(stn), orc.params()
+    worst = {"norm_tmin": 0.0, "se_tmin": 0.0}
+    ncell = 0
+    for r in bands:                                                      # (bands: bounded oracle memory)
+        want = orc.interp_grid(db, None, prm, grid, nthreads=ncpu, rows=r, cols=slice(0, 250))
+        assert np.array_equal(want["status"], full["status"][r, :])
+        for k in worst:
+            worst[k] = max(worst[k], float(np.abs(full[k][:, r, :].astype(np.float64) - want[k]).max()))
+        ncell += want["status"].size
+    print("C2 tile: %d cells x 12 months vs the oracle: max |d| norm %.3g, se %.3g degC" % (ncell, worst["norm_tmin"], worst["se_tmin"]))
+    assert ncell >= 12500 and worst["norm_tmin"] < 1e-4 and worst["se_tmin"] < 1e-4
+
+
+def test_daily_tile_every_cell_vs_oracle(orc):
+    """The daily path on the full C2 tile (three years of days), EVERY cell against the oracle when the host has the
+    cores for it (>= 32 threads: ~10 s): statuses and ninvalid equal, normals <= 1e-4 degC, packed days within 1 LSB;
+    prints the tile-scale int16 flip rate (137 M values)."""
+    import datetime as dt
+    import os
+    from topowx_amd import _lib, synth
+    from topowx_amd.dates import get_days_metadata
+    ncpu = os.cpu_count() or 1
+    if ncpu < 32:
+        pytest.skip("exhaustive daily comparison needs a many-core host (the sampled test below covers small hosts)")
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1983, 12, 31))
+    grid = synth.make_grid("C2")
+    tmin = synth.make_stations(grid["bbox"], 10000, 1, "tmin", days, with_obs=True)
+    tmax = synth.make_stations(grid["bbox"], 10000, 1, "tmax", days, with_obs=True)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    full = ctx.interp_grid(grid, daily=True)
+    ctx.close()
+    dbn, dbx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
+    flips = total = 0
+    worst = 0.0
+    for r0 in range(0, 250, 25):                                         # ten bands: bounded oracle memory
+        rs = slice(r0, r0 + 25)
+        want = orc.interp_grid(dbn, dbx, prm, grid, daily=True, nthreads=ncpu, rows=rs, cols=slice(0, 250))
+        assert np.array_equal(want["status"], full["status"][rs, :]) and np.array_equal(want["ninvalid"], full["ninvalid"][rs, :])
+        for k in ("daily_tmin", "daily_tmax"):
+            dd = np.abs(full[k][:, rs, :].astype(np.int32) - want[k].astype(np.int32))
+            assert dd.max() <= 1, (k, r0)
+            flips += int((dd != 0).sum()); total += dd.size
+        for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+            worst = max(worst, float(np.abs(full[k][:, rs, :].astype(np.float64) - want[k]).max()))
+    print("C2 daily tile, every cell: int16 flip rate %.3g (%d of %d values), normals max |d| %.3g degC" % (flips / total, flips, total, worst))
+    assert worst < 1e-4 and flips / total < 1e-3
+
+
 def test_daily_tile_windows_and_sampled_cells(orc):
     """The daily path on the full 250 x 250 tile with 10 000 stations (three years of days to keep the oracle side
     short): every cell done, a window equals the full tile bit for bit (int16 days, ninvalid), sampled cells match
