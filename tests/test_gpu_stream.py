@@ -138,3 +138,48 @@ def test_driver_streamed_tiles_equal_synchronous(golden_case, tmp_path):
         got = np.load(str(tmp_path / ("t%d.npz" % k)))
         for name in want[k]:
             assert np.array_equal(got[name], want[k][name]), (k, name)
+
+
+def test_stream_outlives_context_close(golden_case):
+    """twx_destroy closes a context's open streams (they hold device images and pinned blocks of that context); the
+    Python TileStream then only forgets its handle -- in either order of close() / garbage collection nothing is freed
+    twice or through a dead context."""
+    import gc
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
+    ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
+    st = ctx.stream(16, 16, daily=False, nslots=2)
+    st.submit(0, grid, slice(0, 16), slice(0, 16))
+    out = st.wait(0)
+    assert np.all(out["status"] == 0)
+    ctx.close()                      # destroys the stream too
+    st.close()                       # must be a no-op now
+    del st
+    gc.collect()
+    # the other order
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
+    ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
+    st = ctx.stream(16, 16, daily=False, nslots=2)
+    st.close()
+    ctx.close()
+
+
+def test_non_finite_observations_are_rejected(golden_case):
+    """The database is serially complete (station_data.py:547-616); a NaN observation would poison every cell of a tile in
+    the table walk of k_daily_tile (0 * NaN), so twx_set_stations refuses the table (include/twx.h)."""
+    from topowx_amd import _lib, stationdb as sdb
+    _, tmin, _ = golden_case
+    obs = np.array(tmin.var, np.float32, copy=True)
+    obs[17, 5] = np.nan
+    bad = sdb.StationDataWrkChk(tmin.stns.copy(), "tmin", tmin.days, obs)
+    ctx = _lib.Context()
+    with pytest.raises(_lib.TwxError, match="NaN"):
+        ctx.set_stations(_lib.TMIN, bad)
+    obs[17, 5] = np.inf
+    with pytest.raises(_lib.TwxError, match="NaN"):
+        ctx.set_stations(_lib.TMIN, sdb.StationDataWrkChk(tmin.stns.copy(), "tmin", tmin.days, obs))
+    ctx.set_stations(_lib.TMIN, tmin)             # the context is still usable
+    ctx.close()
