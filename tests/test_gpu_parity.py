@@ -301,12 +301,13 @@ def test_api_misuse_is_reported_not_crashed(env):
 
 
 def test_krig_every_matrix_size_bucket(env, orc):
-    """Explicit bandwidths on both sides of every kernel / template boundary (one-wave kernel: 8-row steps up
-    to 96 rows; four-wave kernel: 16-row steps up to 160 rows), with full and partial 4-column panels, a
-    pure-nugget model and a long-range one."""
+    """Explicit bandwidths on both sides of every kernel / template boundary (twx_krig_bucket: one-wave kernels in
+    steps of 8 neighbours up to 96 -- bordered form k_ukw<m, 0> for k <= 16 m - 8, border-as-columns form k_ukwz<m>
+    above --, two- / four-wave kernels k_uk<7..10> beyond), with full and partial 4-column panels, a pure-nugget
+    model and a long-range one."""
     ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
     ks = [7, 8, 9, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63, 64, 65, 71, 72, 73, 79, 80, 81, 87, 88, 89,
-          95, 96, 97, 103, 104, 105, 110, 119, 120, 121, 135, 136, 137, 147, 150, 152]
+          95, 96, 97, 103, 104, 105, 110, 111, 112, 113, 119, 120, 121, 127, 128, 129, 135, 136, 137, 143, 144, 145, 147, 150, 152]
     cells = np.argwhere(np.asarray(grid["mask"]) != 0)[::37][:len(ks)]
     assert len(cells) == len(ks)
     pts = _pts(ctx, grid, cells, "tmin")

@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 // A tile whose union is larger evaluates the formula per element from the union's trigonometry staged in the same
 // LDS space.  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
 // ---------------------------------------------------------------------------------
+#ifndef TWX_TD_U
 #define TWX_TD_U 256
+#endif
 #define TWX_TD_WAVES 16
 #ifndef TWX_TD_PARTS
 #define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
