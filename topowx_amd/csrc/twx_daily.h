@@ -527,6 +527,7 @@ __global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
 __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs gw)
 {
     __shared__ uint16_t s_slot[TWX_CAND_MAX];
+    __shared__ double s_zrow[4][TWX_UROWS];
     __shared__ int s_cnt[4], s_base;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t tl = blockIdx.x / 12;                  // local tile
@@ -578,16 +579,19 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
         const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
         if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
         const int ka = ws.ka[lc * 12 + m0];
-        // the hat row in table-row order, zero where the cell does not use the row (k_daily_tile walks the TABLE, four
-        // cells at a time): rows up to the next multiple of 16
-        double *zd = gw.zd + twx_zd_index(tl * 12 + m0, ci);
-        for (int u = lane; u < ((nu + 15) & ~15); u += 64) zd[twx_zd_row(u)] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros are out (s_waitcnt vmcnt(0)) before the scatter
+        // the hat row in table-row order, zero where the cell does not use the row (k_daily_tile walks the TABLE, eight
+        // cells at a time): rows up to the next multiple of 16.  Scattered in LDS, written ONCE and coalesced (zero-filling
+        // global memory and scattering into it wrote every used entry twice, the second time as partial lines)
+        double *zrow = s_zrow[wv];
+        const int nu16 = (nu + 15) & ~15;
+        for (int u = lane; u < nu16; u += 64) zrow[u] = 0.0;
+        __builtin_amdgcn_wave_barrier();                     // (LDS operations of one wave execute in order)
+        for (int r = lane; r < ka; r += 64)
+            zrow[s_slot[ws.near_pos[lc * ws.ksel + r]]] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
         __builtin_amdgcn_wave_barrier();
-        for (int r = lane; r < ka; r += 64) {
-            const uint32_t u = s_slot[ws.near_pos[lc * ws.ksel + r]];
-            zd[twx_zd_row(u)] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
-        }
+        double *zd = gw.zd + twx_zd_index(tl * 12 + m0, ci);
+        for (int u = lane; u < nu16; u += 64) zd[twx_zd_row(u)] = zrow[u];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
