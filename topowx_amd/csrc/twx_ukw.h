@@ -1,5 +1,7 @@
-// twx_ukw.h -- universal-kriging kernel for SMALL systems (k + 8 <= 96 rows): one wavefront per
-// (cell, month) item, no work-group barrier anywhere.
+// twx_ukw.h -- universal-kriging kernels for SMALL systems (k <= 96 neighbours): one wavefront per
+// (cell, month) item, no work-group barrier anywhere.  Two forms (k_bucket_items picks per 8 neighbours):
+//   k_ukw<NBR, 0>   bordered, k + 8 <= 16 NBR rows        (k in the lower half of a block row of 16)
+//   k_ukwz<NBR>     border rows held as columns, k <= 16 NBR  (upper half; below in this file)
 //
 // Same algorithm and the same three-step panel scheme as k_uk (twx_uk.h): bordered matrix
 // [[C, B], [B', 0]] held negated in registers, right-looking Cholesky in 4-column panels, Schur
@@ -27,8 +29,9 @@ __host__ __device__ constexpr int twx_ukw_waves(int nbr)
 
 __device__ __forceinline__ constexpr int widx(int a, int b) { return 2 * a * (a + 1) + b; }   // blocks of rows < a: 4a' + 4 each
 
-// HALF = 1: the system has only 16 NBR - 8 rows; the seven RHS rows then sit in the upper half of the last block
-// row (rows RHS0 = NP-15 .. NP-9) and what lies below / to the right of them is padding that is never touched.
+// HALF = 1 (round 2's 8-row buckets; no longer launched: k_ukwz<NBR - 1> takes those sizes): the system has only
+// 16 NBR - 8 rows; the seven RHS rows then sit in the upper half of the last block row (rows RHS0 = NP-15 .. NP-9)
+// and what lies below / to the right of them is padding that is never touched.
 template <int NBR, int HALF>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukw_waves(NBR), twx_ukw_waves(NBR))))
