@@ -70,6 +70,11 @@ struct EvPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+#ifndef TWX_UKW2
+#define TWX_UKW2 1      // two systems per wave (k_ukw2, twx_ukw.h): 1 = the bucket of <= 40 neighbours (-6..8 % there), 2 = also
+                        // 49..56 neighbours (same-box A/B: 518 vs 509 us -- the shared chain is paid back by 2 instead of 4 waves
+                        // per SIMD), 0 = nowhere
+#endif
 #ifndef TWX_FIX_THREADS
 #define TWX_FIX_THREADS 512
 #endif
@@ -268,6 +273,16 @@ void launch_ukwz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const
     hipLaunchKernelGGL((k_ukwz<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
+template <int NBR>
+void launch_ukw2(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+{
+    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
+    if (cnt && cnt[bucket] <= 0) return;
+    // two systems per wave: half as many work-groups (a multiple of 8, krig_grid)
+    const unsigned grid = (unsigned)(((std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items) + 1) / 2 + 7) / 8 * 8);
+    hipLaunchKernelGGL((k_ukw2<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+}
+
 template <int NBR, int HALF>
 void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
@@ -329,9 +344,17 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
         launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
         launch_ukw<6, 0>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
+#if TWX_UKW2
+        launch_ukw2<3>(cnt, st, src, w.ws, 0, mi, stream);      //      k <= 40  (two systems per wave)
+#else
         launch_ukw<3, 0>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
+#endif
         launch_ukwz<3>(cnt, st, src, w.ws, 1, mi, stream);      // 40 < k <= 48
+#if TWX_UKW2 >= 2
+        launch_ukw2<4>(cnt, st, src, w.ws, 2, mi, stream);      // 48 < k <= 56  (two systems per wave: measured, no gain)
+#else
         launch_ukw<4, 0>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
+#endif
         launch_ukwz<4>(cnt, st, src, w.ws, 3, mi, stream);      // 56 < k <= 64
         launch_ukw<5, 0>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
         launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80

@@ -471,3 +471,240 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
     }
     if (lane == 0) ws.uk_S[(lc * 12 + m0) * TWX_UK_SLEN + 28] = (-nmax > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
 }
+
+// ---------------------------------------------------------------------------------
+// k_ukw2<NBR>: TWO systems per wave (bordered form, k + 8 <= 16 NBR, NBR = 3, 4).
+//
+// In the one-wave kernels the uniform part of a panel step -- the 4x4 Cholesky chain (~40 instructions whose 64 lanes
+// all compute the same ten numbers) and the addressing around it -- costs as much issue time as the fmacs of a 64-row
+// system.  Here a wave holds two systems, lanes 0..31 one, lanes 32..63 the other: the chain is issued once for both
+// (each half on its own diagonal block), the row solve takes 32 rows per round and system, every LDS instruction serves
+// both.  Per system a 16 x 2 lane grid: lane (tr, tc2) holds elements (16a + tr, 4b + 2q + tc2), q = 0, 1, of every
+// 16-row x 4-column block -- a DPP row of 16 lanes still shares its column, so the column factor of the update stays a
+// row_newbcast operand.  Twice the matrix registers per lane: 2 waves per SIMD = 4 systems per SIMD as before for 64 rows.
+// What is per system (item, bandwidth, variogram, cell) lives in vector registers, uniform within a half.
+// Measured (same-box A/B, C2 step): 48 rows 112.6 vs 120 us (-6 %: used), 64 rows 518 vs 509 us (203 VGPRs: two waves per
+// SIMD instead of four; what the shared chain saves in issue slots the lost occupancy takes back: NOT used, TWX_UKW2 = 2
+// in twx_hip.hip reproduces it).  80 rows and more do not fit the register file twice.
+// ---------------------------------------------------------------------------------
+#ifndef TWX_UKW2_WV
+#define TWX_UKW2_WV 2, 3        // NBR = 4, 3
+#endif
+__host__ __device__ constexpr int twx_ukw2_waves(int nbr)
+{
+    constexpr int w[2] = {TWX_UKW2_WV};
+    return w[4 - nbr];
+}
+
+template <int NBR>
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(twx_ukw2_waves(NBR), twx_ukw2_waves(NBR))))
+void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
+{
+    constexpr int NP = NBR * 16, NC = NP / 4, NT = 2 * NBR * (NBR + 1);
+    constexpr int R0 = 9, RHS0 = 16 * (NBR - 1) + R0;       // first RHS row / column
+    constexpr int PS = 6;                                    // slab row stride (doubles)
+    constexpr int NPS = NP + 2;                              // column stride of the panel image (the two systems' images in different banks)
+    __shared__ __attribute__((aligned(16))) double s_pan[2][NP * PS + 2];
+    __shared__ __attribute__((aligned(16))) double s_raw[2][NPS * 4];
+    __shared__ double s_B[2][7][NP];
+
+    const int lane = threadIdx.x, tr = lane & 15, tc2 = (lane >> 4) & 1, l32 = lane & 31, sys = lane >> 5;
+    const int nitems = *nitems_dev;
+    const int pr = xcd_contig(blockIdx.x, (nitems + 1) >> 1);
+    if (pr < 0) return;
+    const bool active = 2 * pr + sys < nitems;               // (an odd list: the last wave's second half repeats the first)
+    const int item = item_list[min(2 * pr + sys, nitems - 1)];
+    const int lc = item / 12;
+    const int m0 = item - 12 * lc;
+    const int k = ws.kk[(int64_t)lc * 12 + m0];
+    const size_t n = (size_t)st.n;
+    // the cell's predictors: per system through the scalar path, then selected per half
+    CellVals cv;
+    double plst;
+    {
+        const int lc0 = __builtin_amdgcn_readlane(lc, 0), lc1 = __builtin_amdgcn_readlane(lc, 32);
+        const int ma = __builtin_amdgcn_readlane(m0, 0), mb = __builtin_amdgcn_readlane(m0, 32);
+        const CellVals ca = cell_load(src, ws.cell0 + lc0), cb = cell_load(src, ws.cell0 + lc1);
+        const double pa = cell_lst(src, ws.cell0 + lc0, ma), pb = cell_lst(src, ws.cell0 + lc1, mb);
+        cv.lon = sys ? cb.lon : ca.lon; cv.lat = sys ? cb.lat : ca.lat; cv.elev = sys ? cb.elev : ca.elev; cv.tdi = 0.0;
+        plst = sys ? pb : pa;
+    }
+    const double *vp = ws.vario + ((int64_t)lc * 12 + m0) * 3;
+    const double nug = vp[0], psill = vp[1], rng = vp[2];
+    const double c00 = nug + psill;
+    const double c2 = rng == 0.0 ? 0.0 : -1.4426950408889634 / rng;   // -log2(e) / range
+    const float chi = (float)c2;
+    const double psill_e = rng == 0.0 ? 0.0 : psill;                  // pure nugget (interp.R:223-231): c(h > 0) = 0
+    const float lgp = __builtin_amdgcn_logf((float)psill_e);          // log2 psill (-inf for a pure nugget)
+    const int kdup = ws.cdup[lc];
+    const int kmx = max(__builtin_amdgcn_readlane(k, 0), __builtin_amdgcn_readlane(k, 32));   // panels the wave walks
+
+    int jq[2];
+    float h0q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = min(l32 + 32 * u, ws.ksel - 1);
+        jq[u] = __hip_atomic_load(&ws.near_idx[(int64_t)lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        h0q[u] = __hip_atomic_load(&ws.h0[(int64_t)lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    float hd[2 * NT];
+    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr);
+    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            hd[2 * widx(a, b) + 0] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 0) * 16]);
+            hd[2 * widx(a, b) + 1] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2) * 16]);
+        });
+    });
+
+    // ---- staging: neighbours l32, l32 + 32 of this half's system (NP <= 64) ------------------------------------
+    double (*sB)[NP] = s_B[sys];
+    double *span = s_pan[sys], *sraw = s_raw[sys];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = l32 + 32 * u;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, yv = 0.0, c0v = 0.0;
+        if (t < k) {
+            const int j = jq[u];
+            const double4 sr = st.stat_s[j];
+            const double2 mr = st.mon_s[(size_t)j * 12 + m0];
+            const double lo = sr.x, la = sr.y;
+            x0 = lo - cv.lon; x1 = la - cv.lat; x2 = sr.z - cv.elev; x3 = mr.x - plst;
+            yv = mr.y;
+            const float h0 = h0q[u];
+            const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
+            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+        }
+        if (t < NP) {
+            sB[0][t] = t < k ? 1.0 : 0.0;
+            sB[1][t] = x0; sB[2][t] = x1; sB[3][t] = x2; sB[4][t] = x3;
+            sB[5][t] = yv; sB[6][t] = c0v;
+        }
+    }
+    for (int q = l32; q < NP * PS; q += 32) span[q] = 0.0;   // finished rows are never written: keep them finite
+    __syncthreads();
+
+    // ---- build (negated) ----------------------------------------------------------------------------------------
+    double A[2 * NT];
+    const bool rhs_row = tr >= R0 && tr < R0 + 7;
+    const double *rhs = &sB[rhs_row ? tr - R0 : 0][tc2];
+    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_)::value;
+        const int i = 16 * a + tr;
+        const float ca = i < k ? chi : -__builtin_inff();
+        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_)::value;
+            sfor<0, 2>([&](auto q_) __attribute__((always_inline)) {
+                constexpr int q = decltype(q_)::value;
+                constexpr int e = 2 * widx(a, b) + q;
+                const int j = 4 * b + 2 * q + tc2;
+                double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
+                if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
+                if (a == NBR - 1) v = rhs_row ? rhs[4 * b + 2 * q] : v;
+                A[e] = -v;
+            });
+        });
+    });
+    // ---- elimination: one panel per block column, both systems at once -------------------------------------------
+    double nmax = -1.0;
+    sfor<0, NC>([&](auto b_) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_)::value;
+        constexpr int a0 = b / 4;
+        if (kmx - 4 * b > 0) {                               // uniform: one of the two systems still has a C column here
+            sfor<a0, NBR>([&](auto a_) __attribute__((always_inline)) {
+                constexpr int a = decltype(a_)::value;
+                sraw[tc2 * NPS + 16 * a + tr] = A[2 * widx(a, b)];
+                sraw[(2 + tc2) * NPS + 16 * a + tr] = A[2 * widx(a, b) + 1];
+            });
+            __builtin_amdgcn_wave_barrier();
+            const double *dg = &sraw[4 * b];
+            const double g00 = dg[0];
+            const double2 g1 = double2{dg[1], dg[NPS + 1]};
+            const double2 g2 = double2{dg[2], dg[NPS + 2]};
+            const double g22 = dg[2 * NPS + 2];
+            const double2 g3 = double2{dg[3], dg[NPS + 3]};
+            const double2 g3b = double2{dg[2 * NPS + 3], dg[3 * NPS + 3]};
+            auto pivot = [&](double nd) __attribute__((always_inline)) {
+                nmax = max_raw(nmax, nd);
+                return -rsqrt_nr(-nd);
+            };
+            const double r0 = pivot(g00);
+            const double l10 = g1.x * r0, l20 = g2.x * r0, l30 = g3.x * r0;
+            const double r1 = pivot(fma(l10, l10, g1.y));
+            const double l21 = fma(l20, l10, g2.y) * r1, l31 = fma(l30, l10, g3.y) * r1;
+            const double r2 = pivot(fma(l21, l21, fma(l20, l20, g22)));
+            const double l32v = fma(l31, l21, fma(l30, l20, g3b.x)) * r2;
+            const double r3 = pivot(fma(l32v, l32v, fma(l31, l31, fma(l30, l30, g3b.y))));
+            constexpr int ROW0 = 4 * b + 4, NROW = NP - ROW0;
+#pragma unroll
+            for (int u = 0; u < (NROW + 31) / 32; ++u) {
+                if (u) __builtin_amdgcn_wave_barrier();
+                const int row = ROW0 + l32 + 32 * u;
+                if (row < NP) {
+                    const double2 n01 = double2{sraw[row], sraw[NPS + row]};
+                    const double2 n23 = double2{sraw[2 * NPS + row], sraw[3 * NPS + row]};
+                    const double L0 = n01.x * r0;
+                    const double L1 = fma(L0, l10, n01.y) * r1;
+                    const double L2 = fma(L1, l21, fma(L0, l20, n23.x)) * r2;
+                    const double L3 = fma(L2, l32v, fma(L1, l31, fma(L0, l30, n23.y))) * r3;
+                    *reinterpret_cast<double2 *>(&span[row * PS]) = double2{L0, L1};
+                    *reinterpret_cast<double2 *>(&span[row * PS + 2]) = double2{L2, L3};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (b + 1 < NC) {
+                // column factors of this lane's two columns per block column: entry e = 4 (bb - b - 1) + factor
+                constexpr int NE = 4 * (NC - b - 1), NR = (NE + 15) / 16;
+                double P0[NR], P1[NR];
+                sfor<0, NR>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    const int e = min(16 * r + tr, NE - 1);
+                    P0[r] = span[(4 * (b + 1 + (e >> 2)) + tc2) * PS + (e & 3)];
+                    P1[r] = span[(4 * (b + 1 + (e >> 2)) + 2 + tc2) * PS + (e & 3)];
+                });
+                constexpr int a1 = (b + 1) / 4;
+                sfor<a1, NBR>([&](auto a_) __attribute__((always_inline)) {
+                    constexpr int a = decltype(a_)::value;
+                    const double2 u0 = *reinterpret_cast<const double2 *>(&span[(16 * a + tr) * PS]);
+                    const double2 u1 = *reinterpret_cast<const double2 *>(&span[(16 * a + tr) * PS + 2]);
+                    constexpr int BHI = (RHS0 + 6) / 4 + 1;
+                    sfor<b + 1, (4 * a + 4 < BHI ? 4 * a + 4 : BHI)>([&](auto bb_) __attribute__((always_inline)) {
+                        constexpr int bb = decltype(bb_)::value;
+                        constexpr int e = 4 * (bb - b - 1);
+                        double acc = A[2 * widx(a, bb)];
+                        fmac_rowbcast<(e + 0) % 16>(acc, P0[(e + 0) / 16], u0.x);
+                        fmac_rowbcast<(e + 1) % 16>(acc, P0[(e + 1) / 16], u0.y);
+                        fmac_rowbcast<(e + 2) % 16>(acc, P0[(e + 2) / 16], u1.x);
+                        fmac_rowbcast<(e + 3) % 16>(acc, P0[(e + 3) / 16], u1.y);
+                        A[2 * widx(a, bb)] = acc;
+                        double acd = A[2 * widx(a, bb) + 1];
+                        fmac_rowbcast<(e + 0) % 16>(acd, P1[(e + 0) / 16], u0.x);
+                        fmac_rowbcast<(e + 1) % 16>(acd, P1[(e + 1) / 16], u0.y);
+                        fmac_rowbcast<(e + 2) % 16>(acd, P1[(e + 2) / 16], u1.x);
+                        fmac_rowbcast<(e + 3) % 16>(acd, P1[(e + 3) / 16], u1.y);
+                        A[2 * widx(a, bb) + 1] = acd;
+                    });
+                });
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    });
+
+    // ---- Schur complement out: rows / columns RHS0 .. RHS0+6 --------------------------------------------------------
+    double *Sout = ws.uk_S + ((int64_t)lc * 12 + m0) * TWX_UK_SLEN;
+    if (active && tr >= R0 && tr < R0 + 7) {
+        const int r = tr - R0;
+        constexpr int B0 = RHS0 / 4;
+        sfor<B0, B0 + 2>([&](auto bb_) __attribute__((always_inline)) {
+            constexpr int bb = decltype(bb_)::value;
+            sfor<0, 2>([&](auto q_) __attribute__((always_inline)) {
+                constexpr int q = decltype(q_)::value;
+                const int cq = 4 * bb + 2 * q + tc2 - RHS0;
+                if (cq >= 0 && cq < 7 && r >= cq) Sout[r * (r + 1) / 2 + cq] = A[2 * widx(NBR - 1, bb) + q];
+            });
+        });
+    }
+    if (active && l32 == 0) Sout[28] = (-nmax > 1e-9 * c00 && k <= kdup) ? 0.0 : 1.0;   // singular / indefinite
+}
