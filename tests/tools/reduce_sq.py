@@ -49,5 +49,10 @@ for k in kern:
     if nk and v.get("SQ_INSTS_VALU_FMA_F64"):
         print("  -- fp64 FMA wave-instructions issued / needed (k^3/3 + 7k^2 of the bucket's systems, 128 flops each): %.0f / %.0f = %.2f"
               % (v["SQ_INSTS_VALU_FMA_F64"], nk, v["SQ_INSTS_VALU_FMA_F64"] / nk))
+    if v.get("SQ_ACTIVE_INST_LDS") and v.get("SQ_ACTIVE_INST_VALU"):
+        # one LDS pipe per CU against four SIMDs: busy time of the LDS pipe relative to the busy time of ONE SIMD's VALU
+        print("  -- LDS pipe busy / per-SIMD VALU busy: %.2f  (4 x ACTIVE_INST_LDS / ACTIVE_INST_VALU; bank-conflict share of LDS time %.2f)"
+              % (4.0 * v["SQ_ACTIVE_INST_LDS"] / v["SQ_ACTIVE_INST_VALU"],
+                 v.get("SQ_LDS_BANK_CONFLICT", 0) / (4.0 * v["SQ_ACTIVE_INST_LDS"])))
     if v.get("SQ_BUSY_CYCLES"):
         print("  -- VALU active / busy cycles %.3f" % (v.get("SQ_ACTIVE_INST_VALU", 0) / v["SQ_BUSY_CYCLES"]))
