@@ -117,3 +117,51 @@ def test_gather_mosaic_with_edge_tiles():
     local = {k: {"norm_tmin": truth[:, i:i + T, j:j + T]} for k, i, j, _ in a[0]}
     mos = driver.gather_mosaic(local, a, (Y, X), T, T, ("norm_tmin",), 0, 1)
     assert np.array_equal(mos["norm_tmin"], truth)
+
+
+def _worker_device_gather(rank, world, port, outdir):
+    """gather_mosaic_device on CPU tensors over gloo: the buffer interp_tiles_device would have filled is synthesised
+    from a known field (slot s of rank r = the tile assign_tiles gave it)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from topowx_amd import driver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Y, X, T = 22, 30, 8                                   # edge tiles in both directions
+    rng = np.random.default_rng(4)
+    mask = (rng.random((Y, X)) < 0.8).astype(np.uint8)
+    mask[:8, 8:16] = 0                                    # an empty tile: skipped in the numbering
+    truth = rng.random((4, 12, Y, X)).astype(np.float32)
+    tiles = driver.tile_list(mask, T, T)
+    assignment = driver.assign_tiles(tiles, world)
+    nmax = max(len(a) for a in assignment)
+    buf = torch.full((nmax, 4, 12, T, T), float(driver.FILL_F4), dtype=torch.float32)
+    for s, (_, i, j, _) in enumerate(assignment[rank]):
+        y, x = min(T, Y - i), min(T, X - j)
+        buf[s, :, :, :y, :x] = torch.from_numpy(truth[:, :, i:i + y, j:j + x])
+    mosaic = driver.gather_mosaic_device(buf, assignment, (Y, X), T, T, rank, world, backend="gloo")
+    if rank == 0:
+        np.savez(os.path.join(outdir, "dev_mosaic.npz"), truth=truth, mask=mask, **{k: v.numpy() for k, v in mosaic.items()})
+    else:
+        assert mosaic is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_device_gather(tmp_path):
+    """The collective of the strong-scaling bench mode (bench.py --scaling strong): every tile lands where its (row, col)
+    says, tiles nobody owns stay at fill, edge tiles are clipped."""
+    from topowx_amd import driver
+    port = _free_port()
+    mp.spawn(_worker_device_gather, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "dev_mosaic.npz"))
+    truth, mask = z["truth"], z["mask"]
+    covered = np.zeros(mask.shape, bool)
+    for _, i, j, _ in driver.tile_list(mask, 8, 8):
+        covered[i:i + 8, j:j + 8] = True
+    assert covered.any() and (~covered).any()
+    for q, key in enumerate(driver.NORMAL_KEYS):
+        assert np.array_equal(z[key][:, covered], truth[q][:, covered])
+        assert np.all(z[key][:, ~covered] == driver.FILL_F4)
