@@ -95,6 +95,14 @@ typedef struct {
  * multiplies every row of a tile-month by every cell's weight (0 for rows a cell does not use: 0 * NaN = NaN would
  * reach all 64 cells of the tile). */
 #define TWX_FLAG_DAILY_GATHER 4
+/* kriging: never route a system to the fp64 covariance build (diagnostic switch; tests/tools/gpu_closepair_scan.py
+ * measures the fast build's error with it).  Default (flag clear): a system whose amplification
+ * psill / (2 (nug + psill (1 - exp(-hmin / range)))) -- hmin = smallest distance between two of its neighbours --
+ * exceeds 8 has its covariance matrix built from fp64 distances and fp64 exponentials (k_uk<NB, 2, 1>) instead of the
+ * fp32 pair-distance cache + v_exp_f32: station pairs a few hundred metres apart with a nugget near 0 are legal
+ * inputs of interp.R:223-231,256 (nugget = min gamma, interp.R:304-359) and amplify the fp32 rounding of an entry
+ * beyond the 1e-4 degC parity bar (measured: tests/test_gpu_closepairs.py). */
+#define TWX_FLAG_UK_FAST_ONLY 8
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
  * StationSelect's isnan(bad) mask: station_data.py:126-183,609,

@@ -16,10 +16,12 @@ RES = os.path.join(ROOT, "topowx_amd", "libtwxhip.resources.txt")
 EXPECT = {
     "k_ukw<4, 0>": (4, 0), "k_ukw<5, 0>": (3, 0), "k_ukw<6, 0>": (2, 0),
     "k_ukw2<3>": (3, 0), "k_ukwz<3>": (4, 0), "k_ukwz<4>": (3, 0), "k_ukwz<5>": (2, 0), "k_ukwz<6>": (2, 0),
-    "k_uk<7, 2>": (3, 0), "k_uk<8, 4>": (4, 0), "k_uk<9, 2>": (2, 0),
+    "k_uk<7, 2, 0>": (3, 0), "k_uk<8, 4, 0>": (4, 0), "k_uk<9, 2, 0>": (2, 0),
     # 160 rows on two waves: 220 VGPRs of matrix alone; measured faster with 4 systems per CU and a few spilled
     # registers of the build phase than with 3 (profiles/README.md, round 2): a bounded allowance, not a free pass
-    "k_uk<10, 2>": (2, 128),
+    "k_uk<10, 2, 0>": (2, 128),
+    # fp64-build variants (ill-conditioned systems only, not tuned): call frames of the out-of-line covariance function
+    "k_uk<7, 2, 1>": (2, 64), "k_uk<10, 2, 1>": (1, 64),
     "k_tile_dist": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4>": (4, 0), "k_select<1>": (4, 0), "k_tile_cand": (4, 0),
     "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_union": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
@@ -34,11 +36,15 @@ def budget(waves):
 
 @pytest.fixture(scope="module")
 def table():
-    import subprocess
+    """Never builds: a rebuild in the middle of a pytest session would replace a library other tests have dlopen'ed
+    (and tests/tools/ab_stats.sh swaps A/B builds in on purpose).  Both files are git-ignored build products."""
     import isa_resources
     so = os.path.join(ROOT, "topowx_amd", "libtwxhip.so")
-    if not os.path.exists(RES) or not os.path.exists(so) or os.path.getmtime(RES) < os.path.getmtime(so) - 120:
-        subprocess.check_call([os.path.join(ROOT, "build.sh")])      # (hipcc cross-compiles without a GPU: ~1 min)
+    if not os.path.exists(RES) or not os.path.exists(so):
+        pytest.skip("no build in this checkout (run ./build.sh: it writes libtwxhip.so and libtwxhip.resources.txt)")
+    if os.path.getmtime(RES) < os.path.getmtime(so) - 120:
+        pytest.fail("libtwxhip.resources.txt is older than libtwxhip.so: the library was not built by ./build.sh "
+                    "(an A/B copy?) -- run ./build.sh")
     return isa_resources.parse(RES)
 
 
@@ -66,4 +72,4 @@ def test_daily_tile_keeps_two_workgroups_per_cu(table):
 
 def test_no_kernel_uses_dynamic_scratch_unexpectedly(table):
     spilled = {k: r["scratch"] for k, r in table.items() if r["scratch"] > 0}
-    assert set(spilled) <= {"k_uk<10, 2>"}, spilled
+    assert set(spilled) <= {"k_uk<10, 2, 0>", "k_uk<7, 2, 1>", "k_uk<10, 2, 1>"}, spilled

@@ -25,6 +25,7 @@ FILL_I4 = np.int32(-2147483647)
 FLAG_OBS_ADDR64 = 1
 FLAG_NO_HOST_SYNC = 2
 FLAG_DAILY_GATHER = 4
+FLAG_UK_FAST_ONLY = 8     # diagnostic: never use the fp64 covariance build (include/twx.h)
 
 CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)",
                2: "Cannot determine the optimal # of neighbors to use!",

@@ -50,7 +50,7 @@ struct VarData {
 
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
-        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, noff, near_pos, urow,
+        bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, hminp, noff, near_pos, urow,
         nurow, zd;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
@@ -58,7 +58,7 @@ struct Work {
     void release()
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
-                          &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &noff,
+                          &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &hminp, &noff,
                           &near_pos, &urow, &nurow, &zd})
             b->release();
     }
@@ -183,6 +183,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.uk_S.ensure((size_t)ncell * 12 * TWX_UK_SLEN * 8));
     HIPCHK(w.dist.ensure((size_t)ncell * TWX_DIST_BLOCKS * 256 * 4));   // pair distances shared by a cell's 12 systems
     HIPCHK(w.h0.ensure((size_t)ncell * ksel * 4));
+    HIPCHK(w.hminp.ensure((size_t)ncell * ksel * 4));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
@@ -215,7 +216,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.bucket_cells = w.bucket_cells.as<int32_t>();
     s.uk_mean = w.uk_mean.as<double>(); s.uk_var = w.uk_var.as<double>(); s.uk_stat = w.uk_stat.as<int32_t>();
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
-    s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>();
+    s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>(); s.hminp = w.hminp.as<float>();
+    s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
     s.near_pos = grid ? w.near_pos.as<uint16_t>() : nullptr;
@@ -236,7 +238,7 @@ inline unsigned krig_grid(const int32_t *cnt, int bucket, int64_t max_items)
     return (unsigned)((std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items) + 7) / 8 * 8);
 }
 
-template <int NB>
+template <int NB, int PREC = 0>
 void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
@@ -252,7 +254,7 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
         (void)hipMemsetAsync(dbg, 0, nb, s);
         w2.dbg = dbg;
     }
-    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB)>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, w2, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB), PREC>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, w2, cells, ws.bucket_cnt + bucket);
     if (NB == 7) {
         std::vector<unsigned long long> h(nb / 8);
         (void)hipStreamSynchronize(s);
@@ -260,7 +262,7 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
         if (FILE *f = fopen("gpurun_out/uk_stamps.bin", "wb")) { fwrite(h.data(), 1, nb, f); fclose(f); }
     }
 #else
-    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB)>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_uk<NB, twx_uk_nw(NB), PREC>), dim3(grid), dim3(64 * twx_uk_nw(NB)), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 #endif
 }
 
@@ -322,6 +324,15 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     if (!src.do_krig) return 0;
     if (fit_vario)   // model 1: OLS-residual variogram -> ws.vario, then the kriging kernels give the GLS trend
         hipLaunchKernelGGL(k_vario<0>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
+    {
+        // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems -- and the smallest
+        // pair distance by rank, which k_bucket_items needs to route ill-conditioned systems to the fp64 build
+        EvScope ev(ctx, stream, EV_UK);
+        if (w.ws.near_pos)       // grid mode: per tile, from a table of the tile's station pairs
+            hipLaunchKernelGGL(k_tile_dist, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
+        else
+            hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
+    }
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     HIPCHK(ctx->stats.ensure(64));
     hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
@@ -334,11 +345,6 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     }
     {
         EvScope ev(ctx, stream, EV_UK);
-        // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
-        if (w.ws.near_pos)       // grid mode: per tile, from a table of the tile's station pairs
-            hipLaunchKernelGGL(k_tile_dist, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
-        else
-            hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
         const int64_t mi = ncell * 12;
         // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
         // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
@@ -362,6 +368,8 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         launch_uk<8>(cnt, st, src, w.ws, 9, mi, stream);        // 104 < k <= 120
         launch_uk<9>(cnt, st, src, w.ws, 10, mi, stream);       // 120 < k <= 136
         launch_uk<10>(cnt, st, src, w.ws, 11, mi, stream);      // 136 < k <= 152
+        launch_uk<7, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);        // ill-conditioned systems (uk_needs_f64): fp64
+        launch_uk<10, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);   // covariance build, k <= 104 / k <= 152
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit

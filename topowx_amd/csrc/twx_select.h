@@ -39,18 +39,22 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *cdup;       // [ncell] lowest rank i whose neighbour coincides with an earlier one (k_cell_dist): systems with k > i are singular
-    int32_t *bucket_cnt; // [16]: systems per bucket of twx_krig_bucket: 0..7 one-wave kernels (steps of 8 neighbours up to 96), 8..11 k_uk<7..10>
+    int32_t *bucket_cnt; // [16]: systems per bucket of twx_krig_bucket: 0..7 one-wave kernels (steps of 8 neighbours up to 96), 8..11 k_uk<7..10>,
+                         // 12..13 ill-conditioned systems (uk_needs_f64): k_uk<7 / 10, 2, 1> with the fp64 covariance build
     int32_t *bucket_cells; // [TWX_NBUCKET][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
     int32_t *uk_stat;    // [ncell]
     double *uk_S;        // [ncell][12][TWX_UK_SLEN] lower triangle of B'C^-1B + error flag
-    double *uk_beta;     // [ncell][12][5] GLS trend coefficients (shifted / scaled basis of k_uk)
+    double *uk_beta;     // [ncell][12][5] GLS trend coefficients (basis of k_uk: columns shifted to the cell, unscaled)
     double *vfit;        // [ncell][12][3] fitted variogram (8f-1)
     double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
     float *dist;         // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr] station-pair distances (km) of the cell's kriging
                          // neighbourhood in rank order, 16x16 blocks (a >= b) -- shared by the cell's 12 monthly systems
     float *h0;           // [ncell][ksel] cell -> neighbour distance (km, sp/gstat formula)
+    float *hminp;        // [ncell][ksel] smallest pair distance among the neighbours of ranks <= r (k_cell_dist / k_tile_dist;
+                         // +inf at rank 0): what decides whether a system needs the fp64 covariance build (uk_needs_f64)
+    int fast_only;       // TWX_FLAG_UK_FAST_ONLY: never route a system to the fp64 build (diagnostic)
 #ifdef TWX_UK_STAMP      // diagnostic build only (tests/tools/uk_stamps.sh): s_memtime stamps of the panel loop
     unsigned long long *dbg;
 #endif
@@ -605,13 +609,36 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 //                   (twx_ukw.h) up to m = 6; larger systems take the bordered form with m + 1 block rows
 // LDS counters per workgroup, one global atomic per (workgroup, bucket).  Order inside a bucket is irrelevant.
 // ---------------------------------------------------------------------------------
-#define TWX_NBUCKET 12
+#define TWX_NBUCKET 14
+#define TWX_BUCKET_F64 12                                    // first of the two fp64-build buckets (k <= 104, k <= 152)
 __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 {
     const int e = (k + 7) / 8;                               // eighths: 5 (k <= 40) .. 19 (k <= 152)
     const int b = (e < 5 ? 5 : (e > 19 ? 19 : e)) - 5;      // 0 .. 14
     return b < 9 ? b : 9 + (b - 9) / 2;                      // from 105 neighbours on in steps of 16 (one kernel each)
 }
+
+// Which systems need the fp64 covariance build.  The fast build forms every off-diagonal entry psill exp(-h / range)
+// from an fp32 pair distance (relative error ~3e-7) with one fp32 fma + v_exp_f32 (~1.5e-7): an absolute perturbation
+// of ~2e-7 psill per entry.  Two neighbours hmin apart have nearly equal rows; the difference of their kriging weights
+// is governed by 2 (nug + psill (1 - exp(-hmin / range))) on the diagonal of the rotated system, so the perturbation
+// reaches the prediction multiplied by
+//     amp = psill / (2 (nug + psill (1 - exp(-hmin / range))))
+// (measured on the GPU, tests/tools/gpu_closepair_scan.py with the fast build forced: error <= ~8e-7 amp degC on ten
+// disagreeing pairs 50-300 m apart: 7.6e-6 at amp 10, 5e-5 at amp 100, 2.4e-3 at amp 9 000).  The reference's nugget is
+// min(gamma) of an empirical variogram (interp.R:304-359): nothing bounds it away from 0, and step20 removes only exact
+// duplicates (step20:51-57).  Systems with amp > TWX_F64_AMP are routed to k_uk<NB, 2, 1>: fp64 distances from the
+// stations' half-angle trigonometry, fp64 exp.  A pure-nugget model has no off-diagonal entries to perturb.
+#ifndef TWX_F64_AMP
+#define TWX_F64_AMP 8.0
+#endif
+__device__ __forceinline__ bool uk_needs_f64(double nug, double psill, double rng, float hmin)
+{
+    if (!(rng > 0.0) || !(psill > 0.0)) return false;
+    const double t = -expm1(-(double)hmin / rng);            // hmin = +inf (a single neighbour): t = 1
+    return (2.0 * TWX_F64_AMP) * (nug + psill * t) < psill;
+}
+
 __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 {
     __shared__ int s_cnt[16], s_base[16];
@@ -625,6 +652,9 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
         if (k > 0) {
             id = twx_krig_bucket(k);
+            if (!ws.fast_only && uk_needs_f64(ws.vario[item * 3], ws.vario[item * 3 + 1], ws.vario[item * 3 + 2],
+                                              ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))
+                id = TWX_BUCKET_F64 + (k > 104 ? 1 : 0);
             rank = atomicAdd(&s_cnt[id], 1);
         }
     }

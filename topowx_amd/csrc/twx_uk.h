@@ -94,6 +94,14 @@ __device__ __attribute__((noinline)) float ellip_pair_far(double Sd, double cc, 
     return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
 }
 
+// inclusive running minimum over the 16 lanes of a DPP row (lane n: min of lanes 0..n of its row)
+__device__ __forceinline__ float row_scan_min(float v)
+{
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = fminf(v, __shfl_up(v, o, 16));   // (lanes < o get their own value back)
+    return v;
+}
+
 // WGS84 great-circle distance (sp / gstat) of two points from the
 // sines / cosines of their half latitudes and half longitudes plus cos(lat).
 // With F = (p1+p2)/2, G = (p1-p2)/2, L = (l1-l2)/2:
@@ -126,6 +134,40 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
     return (2.f * (float)TWX_WGS84_A) * (rs * P) * (1.f + corr);
 }
 
+// ---- fp64 covariance build of the ill-conditioned systems (uk_needs_f64, twx_select.h) -------------------------------
+// The same sp / gstat formula from the same half-angle trigonometry, every step in fp64: sin G and sin L come from
+// angle-addition products of per-station values that are each good to an ulp, so a pair 100 m apart (sin G ~ 8e-6)
+// still has its distance to ~5e-12 relative -- three orders inside what the worst system of the close-pair tests
+// needs.  Out of line: these kernels run rarely, their unrolled builds would otherwise hold ~110 copies of it.
+__device__ __attribute__((noinline)) double ellip_far_f64(double Sd, double cc, double sG2)
+{
+    const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
+    double w = atan(sqrt(Sd / Cd));
+    double R = sqrt(Sd * Cd) / w;
+    double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
+    return 2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2);
+}
+
+// a, b: {sin, cos of the half latitude, sin, cos of the half longitude, cos(latitude)}
+__device__ __forceinline__ double ellip_pair_f64(const double *a, const double *b)
+{
+    if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]) return 0.0;   // same location (see ellip_pair_fast)
+    const double sG = fma(a[0], b[1], -(a[1] * b[0]));
+    const double sL = fma(a[2], b[3], -(a[3] * b[2]));
+    const double cc = a[4] * b[4];
+    const double sG2 = sG * sG, sL2 = sL * sL;
+    const double Sd = fma(cc, sL2, sG2);
+    if (!(Sd > 0.0)) return 0.0;
+    return ellip_far_f64(Sd, cc, sG2);
+}
+
+// psill exp(-h / range) with ninv = -1 / range (0 with psill = 0 for a pure nugget); coincident points give psill,
+// as the fast build does (their systems are singular and flagged through SelWs.cdup)
+__device__ __attribute__((noinline)) double cov_pair_f64(const double *a, const double *b, double ninv, double psill)
+{
+    return psill * exp(ellip_pair_f64(a, b) * ninv);
+}
+
 // waves per SIMD the register budget is sized for (min == max so that the compiler
 // does not spill the register-resident matrix to chase a higher occupancy)
 // (measured per bucket on the C2 bench: more resident work-groups beat the few spilled registers)
@@ -141,9 +183,11 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
     __shared__ double s_trig[TWX_KSEL_MAX * 4];
     __shared__ double s_cphi[TWX_KSEL_MAX];
     __shared__ int s_dup;                                    // lowest rank whose neighbour coincides with an earlier one
+    __shared__ int s_rmin[TWX_KSEL_MAX];                     // per rank i: min over j < i of h(i, j), as float bits (h >= 0)
     const int64_t lc = blockIdx.x;
     if (lc >= ws.ncell || ws.cstat[lc] != 0) return;
     const int t = threadIdx.x, tr = t & 15, tc = t >> 4;
+    if (t < TWX_KSEL_MAX) s_rmin[t] = 0x7f800000;
     int kmax = 0;
 #pragma unroll
     for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
@@ -167,12 +211,14 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
         const bool iv = i < kmax;
         const double spi = iv ? s_trig[i * 4] : 0.0, cpi = iv ? s_trig[i * 4 + 1] : 1.0;
         const double sli = iv ? s_trig[i * 4 + 2] : 0.0, cli = iv ? s_trig[i * 4 + 3] : 1.0, cphi = iv ? s_cphi[i] : 1.0;
+        float rm = __builtin_inff();
         for (int b = 0; b <= a; ++b) {
             const int j = 16 * b + tc;
             float h = 1.f;                                   // diagonal / outside the neighbourhood: any h > 0 (masked by the build)
             if (iv && j < kmax && i != j) {
                 h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1], s_trig[j * 4 + 2],
                                     s_trig[j * 4 + 3], s_cphi[j]);
+                if (j < i) rm = fminf(rm, h);
                 // coincident neighbours: c(0) = full sill in both rows, i.e. every system holding both is singular
                 // (gstat fails there).  Such systems are flagged by rank (k > cdup) instead of through their pivots,
                 // and the cached distance stays positive so that the build's masks (-inf * h) never see 0.
@@ -180,9 +226,23 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
             }
             __builtin_nontemporal_store(h, &out[(a * (a + 1) / 2 + b) * 256 + t]);   // t = tc * 16 + tr
         }
+        if (iv) atomicMin(&s_rmin[i], __float_as_int(rm));
     }
     __syncthreads();
     if (t == 0) ws.cdup[lc] = s_dup;
+    // smallest pair distance among the neighbours of ranks <= r (uk_needs_f64 reads entry k - 1 of a system of k)
+    if (t < 64) {
+        float run = __builtin_inff();
+        for (int r0 = 0; r0 < kmax; r0 += 64) {
+            const int r = r0 + t;
+            float v = r < kmax ? __int_as_float(s_rmin[r]) : __builtin_inff();
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v = fminf(v, __shfl_up(v, o, 64));
+            v = fminf(v, run);
+            if (r < kmax) ws.hminp[lc * ws.ksel + r] = v;
+            run = __shfl(v, 63, 64);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -299,11 +359,13 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
         const int nbk = (kmax + 15) >> 4;
         float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
         const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
+        float run = __builtin_inff();                        // smallest pair distance among the rows above this block row
         for (int a = 0; a < nbk; ++a) {
             const int i = 16 * a + tr;
             const bool iv = i < kmax;
             const int ui = iv ? ur[i] : 0, ti = ui * (ui + 1) / 2;
             const double *pa = &trig[ui * 5];
+            float rm = __builtin_inff();                     // min over j < i of h(i, j) (this lane's columns)
             for (int b = 0; b <= a; ++b) {
                 float *ob = out + (a * (a + 1) / 2 + b) * 256 + lane;
 #pragma unroll
@@ -317,12 +379,19 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
                             const double *pb = &trig[uj * 5];
                             h = ellip_pair_fast(pa[0], pa[1], pa[2], pa[3], pa[4], pb[0], pb[1], pb[2], pb[3], pb[4]);
                         }
+                        if (j < i) rm = fminf(rm, h);
                         // coincident neighbours: see k_cell_dist
                         if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
                     __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
                 }
             }
+            // hminp (see k_cell_dist): row minimum over the four lane columns, running minimum down the rows
+            rm = fminf(rm, __shfl_xor(rm, 16, 64));
+            rm = fminf(rm, __shfl_xor(rm, 32, 64));
+            rm = fminf(row_scan_min(rm), run);
+            if (lane < 16 && iv) ws.hminp[lc * ws.ksel + i] = rm;
+            run = __shfl(rm, 15, 64);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ws.cdup[lc] = s_dup[wv];
@@ -376,9 +445,12 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 template <int NW> __device__ __forceinline__ constexpr int uk_nbc(int a) { return 16 * (a + 1) / (4 * NW); }
 template <int NW> __device__ __forceinline__ constexpr int uk_eidx(int a, int b) { return (4 / NW) * (a * (a + 1) / 2) + b; }
 
-template <int NB, int NW>
+// PREC = 1: the fp64 covariance build (ill-conditioned systems, uk_needs_f64): pair and cell -> station distances from
+// the neighbours' half-angle trigonometry staged in LDS, fp64 exp, nothing read from the fp32 distance cache.  Same
+// elimination.  Instantiated for NB = 7 (k <= 104) and NB = 10; not tuned: few systems take it.
+template <int NB, int NW, int PREC = 0>
 __global__ __launch_bounds__(64 * NW)
-__attribute__((amdgpu_waves_per_eu(twx_uk_waves(NB), twx_uk_waves(NB))))
+__attribute__((amdgpu_waves_per_eu(PREC ? 1 : twx_uk_waves(NB), twx_uk_waves(NB))))
 void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
     constexpr int NP = NB * 16, CB = 4 * NW, NBC = NP / CB, NT = uk_eidx<NW>(NB, 0), NTH = 64 * NW;
@@ -389,6 +461,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                                                                               // the next panel is factorised while this one is still being applied
     __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
+    __shared__ double s_trig[PREC ? NP * 5 : 1];             // PREC: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by rank
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
@@ -436,8 +509,9 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
         jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    float hd[NT];
-    {
+    float hd[PREC ? 1 : NT];
+    const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
+    if constexpr (!PREC) {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
             constexpr int a = decltype(a_)::value;
@@ -469,7 +543,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             // cell -> station distance (B.1, from k_cell_dist); a coincident point gets the full sill (exact interpolator)
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+            if constexpr (PREC) {
+                const double sp = st.sph[j], cp = st.cph[j];
+                double *tq = &s_trig[q * 5];
+                tq[0] = sp; tq[1] = cp; tq[2] = st.slh[j]; tq[3] = st.clh[j]; tq[4] = fma(cp, cp, -(sp * sp));
+                const double *ct = ws.ctrig + lc * 4;
+                const double ctr[5] = {ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0]))};
+                c0v = same ? c00 : cov_pair_f64(ctr, tq, ninv, psill_e);
+            } else
+                c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (q < NP) {
             s_B[0][q] = q < k ? 1.0 : 0.0;
@@ -498,7 +580,9 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             const int j = CB * b + tc;
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
-            double v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
+            double v;
+            if constexpr (PREC) v = (i < k && j < i) ? cov_pair_f64(&s_trig[i * 5], &s_trig[j * 5], ninv, psill_e) : 0.0;
+            else v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
             if (CB * b / 16 == a && i == j) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
