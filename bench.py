@@ -566,8 +566,8 @@ def main():
                  # FMAs a kernel ISSUED (SQ counters) by the FMAs these flops NEED (128 flops per wave instruction)
                  "executed_flops_by_bucket_kmax": {str(int(e)): float(uk_flops_executed(kpos[bidx == i]).sum())
                                                    for i, e in enumerate(edges) if (bidx == i).any()},
-                 "kernels_by_bucket_kmax": {"40": "k_ukw2<3>", "48": "k_ukwz<3>", "56": "k_ukw<4,0>", "64": "k_ukwz<4>", "72": "k_ukw<5,0>",
-                                            "80": "k_ukwz<5>", "88": "k_ukw<6,0>", "96": "k_ukwz<6>", "104": "k_uk<7,2>", "120": "k_uk<8,4>",
+                 "kernels_by_bucket_kmax": {"40": "k_ukw2<3>", "48": "k_ukwz<3>", "56": "k_ukw<4>", "64": "k_ukwz<4>", "72": "k_ukw<5>",
+                                            "80": "k_ukwz<5>", "88": "k_ukw<6>", "96": "k_ukwz<6>", "104": "k_uk<7,2>", "120": "k_uk<8,4>",
                                             "136": "k_uk<9,2>", "152": "k_uk<10,2>"}},
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},

@@ -6,12 +6,20 @@
 set -e
 cd "$(dirname "$0")"
 LOG=$(mktemp /tmp/twx_build.XXXXXX)
+# stderr without the resource-usage remark blocks: a remark line and the source-context lines that follow IT are dropped;
+# the context lines of genuine warnings / errors stay
+show_diagnostics() {
+    awk '/^In file included from/ { hold = hold $0 "\n"; next }
+         /: remark: .*\[-Rpass-analysis=kernel-resource-usage\]/ { skip = 1; hold = ""; next }
+         skip && (/^ *[0-9]+ \| / || /^ *\| /) { next }
+         { skip = 0; printf "%s", hold; hold = ""; print }' "$1" >&2
+}
 if ! hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Iinclude -Itopowx_amd/csrc \
     -Rpass-analysis=kernel-resource-usage "$@" -o topowx_amd/libtwxhip.so topowx_amd/csrc/twx_hip.hip 2> "$LOG"; then
-    grep -v "Rpass-analysis=kernel-resource-usage\|^ *[0-9]* | \|^ *| \|^In file included from" "$LOG" >&2 || true
+    show_diagnostics "$LOG"
     rm -f "$LOG"
     exit 1
 fi
-grep -v "Rpass-analysis=kernel-resource-usage\|^ *[0-9]* | \|^ *| \|^In file included from" "$LOG" >&2 || true
+show_diagnostics "$LOG"
 python3 tests/tools/isa_resources.py "$LOG" > topowx_amd/libtwxhip.resources.txt
 rm -f "$LOG"

@@ -14,7 +14,7 @@ RES = os.path.join(ROOT, "topowx_amd", "libtwxhip.resources.txt")
 # kernel -> (resident waves per SIMD the tuning assumes, scratch bytes per lane tolerated)
 # gfx950: 512 VGPRs per SIMD lane, allocated in granules of 8: waves w fit when VGPRs + AGPRs <= (512 / w) & ~7.
 EXPECT = {
-    "k_ukw<4, 0>": (4, 0), "k_ukw<5, 0>": (3, 0), "k_ukw<6, 0>": (2, 0),
+    "k_ukw<4>": (4, 0), "k_ukw<5>": (3, 0), "k_ukw<6>": (2, 0),
     "k_ukw2<3>": (3, 0), "k_ukwz<3>": (4, 0), "k_ukwz<4>": (3, 0), "k_ukwz<5>": (2, 0), "k_ukwz<6>": (2, 0),
     "k_uk<7, 2, 0>": (3, 0), "k_uk<8, 4, 0>": (4, 0), "k_uk<9, 2, 0>": (2, 0),
     # 160 rows on two waves: 220 VGPRs of matrix alone; measured faster with 4 systems per CU and a few spilled

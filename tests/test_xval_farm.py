@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -96,6 +97,14 @@ def test_set_optim_nstns_from_mae_files_matches_executed_reference(golden_xval, 
     b = xval.set_optim_nstns_from_files(sdb.StationSerialDataDb(stns_b, "tmin", tmin.days), d2, sdb.get_optim_varname)
     for dv in a:
         np.testing.assert_array_equal(a[dv], b[dv])
+    # a division whose file is missing: the reference fails opening it (optimize.py:302-304) -- so does this, by default
+    os.remove(os.path.join(d2, "optim_nstns_tmin_climdiv102.nc"))
+    da3 = sdb.StationSerialDataDb(stns.copy(), "tmin", tmin.days)
+    with pytest.raises(IOError, match="climate division 102"):
+        xval.set_optim_nstns_from_files(da3, d2, sdb.get_optim_varname)
+    lax = xval.set_optim_nstns_from_files(da3, d2, sdb.get_optim_varname, strict=False)
+    assert lax["missing"] == [102.0] and sorted(k for k in lax if k != "missing") == [101.0, 4407.0]
+
 
 def test_shard_unshard_roundtrip():
     from topowx_amd import xval

@@ -285,13 +285,13 @@ void launch_ukw2(const int32_t *cnt, const StnDev &st, const CellSrc &src, const
     hipLaunchKernelGGL((k_ukw2<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
-template <int NBR, int HALF>
+template <int NBR>
 void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
     if (cnt && cnt[bucket] <= 0) return;
     const unsigned grid = krig_grid(cnt, bucket, max_items);
-    hipLaunchKernelGGL((k_ukw<NBR, HALF>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_ukw<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
@@ -349,20 +349,20 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
         // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
         launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
-        launch_ukw<6, 0>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
+        launch_ukw<6>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
 #if TWX_UKW2
         launch_ukw2<3>(cnt, st, src, w.ws, 0, mi, stream);      //      k <= 40  (two systems per wave)
 #else
-        launch_ukw<3, 0>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
+        launch_ukw<3>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
 #endif
         launch_ukwz<3>(cnt, st, src, w.ws, 1, mi, stream);      // 40 < k <= 48
 #if TWX_UKW2 >= 2
         launch_ukw2<4>(cnt, st, src, w.ws, 2, mi, stream);      // 48 < k <= 56  (two systems per wave: measured, no gain)
 #else
-        launch_ukw<4, 0>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
+        launch_ukw<4>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
 #endif
         launch_ukwz<4>(cnt, st, src, w.ws, 3, mi, stream);      // 56 < k <= 64
-        launch_ukw<5, 0>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
+        launch_ukw<5>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
         launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80
         launch_uk<7>(cnt, st, src, w.ws, 8, mi, stream);        // 96 < k <= 104
         launch_uk<8>(cnt, st, src, w.ws, 9, mi, stream);        // 104 < k <= 120
@@ -601,6 +601,10 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     s.stat_s = reinterpret_cast<const double4 *>(d + rec0); s.mon_s = reinterpret_cast<const double2 *>(d + rec0 + 4 * n);
     hipLaunchKernelGGL(k_stn_coslat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.lat, const_cast<double *>(s.coslat), (int)n);
     HIPCHK(hipGetLastError());
+    // a setup call: wait here, so that no later launch on a non-blocking stream (twx_stream_*, a caller's stream in
+    // twx_interp_grid_dev) can read cos(lat) -- k_tile_cand's conservative radius -- before it is written, and so
+    // that an asynchronous fault of this kernel is reported by this call
+    HIPCHK(hipStreamSynchronize(nullptr));
     s.obs = nullptr;
     vd.n = (int)n; vd.kmax = s.kmax; vd.has_obs = false;
     if (t->obs) {

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 // k_bucket_items: counting sort of the (cell, month) kriging items by matrix size, in steps of 8 neighbours.
 // With m = ceil(k / 16) block rows of 16:
 //   k <= 16 m - 8   bordered form: k C rows + 7 border rows at the fixed rows NP-7..NP-1 of NP = 16 m rows (the last C
-//                   column stays out of the 4-column panel that holds the first border column): k_ukw<m, 0> / k_uk<m>
+//                   column stays out of the 4-column panel that holds the first border column): k_ukw<m> / k_uk<m>
 //   k >  16 m - 8   the border would open a block row of its own: k_ukwz<m> keeps it as columns beside NP = 16 m C rows
 //                   (twx_ukw.h) up to m = 6; larger systems take the bordered form with m + 1 block rows
 // LDS counters per workgroup, one global atomic per (workgroup, bucket).  Order inside a bucket is irrelevant.

@@ -1,6 +1,6 @@
 // twx_ukw.h -- universal-kriging kernels for SMALL systems (k <= 96 neighbours): one wavefront per
 // (cell, month) item, no work-group barrier anywhere.  Two forms (k_bucket_items picks per 8 neighbours):
-//   k_ukw<NBR, 0>   bordered, k + 8 <= 16 NBR rows        (k in the lower half of a block row of 16)
+//   k_ukw<NBR>      bordered, k + 8 <= 16 NBR rows        (k in the lower half of a block row of 16)
 //   k_ukwz<NBR>     border rows held as columns, k <= 16 NBR  (upper half; below in this file)
 //
 // Same algorithm and the same three-step panel scheme as k_uk (twx_uk.h): bordered matrix
@@ -29,16 +29,13 @@ __host__ __device__ constexpr int twx_ukw_waves(int nbr)
 
 __device__ __forceinline__ constexpr int widx(int a, int b) { return 2 * a * (a + 1) + b; }   // blocks of rows < a: 4a' + 4 each
 
-// HALF = 1 (round 2's 8-row buckets; no longer launched: k_ukwz<NBR - 1> takes those sizes): the system has only
-// 16 NBR - 8 rows; the seven RHS rows then sit in the upper half of the last block row (rows RHS0 = NP-15 .. NP-9)
-// and what lies below / to the right of them is padding that is never touched.
-template <int NBR, int HALF>
+template <int NBR>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukw_waves(NBR), twx_ukw_waves(NBR))))
 void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
     constexpr int NP = NBR * 16, NC = NP / 4, NT = 2 * NBR * (NBR + 1);
-    constexpr int R0 = HALF ? 1 : 9, RHS0 = 16 * (NBR - 1) + R0;       // first RHS row / column
+    constexpr int R0 = 9, RHS0 = 16 * (NBR - 1) + R0;                  // first RHS row / column
     constexpr int PS = 6;       // slab row stride (doubles): 48-byte rows, 16-B aligned
     __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];
     __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];
@@ -211,9 +208,8 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
                     constexpr int a = decltype(a_)::value;
                     const double2 u0 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS]);
                     const double2 u1 = *reinterpret_cast<const double2 *>(&s_pan[(16 * a + tr) * PS + 2]);
-                    // block columns right of the RHS columns (HALF) are padding; the (at most two) padding block
-                    // columns between the last C column and the RHS columns are updated like the rest -- a run-time
-                    // test per block would cost more issue slots than their four fmacs
+                    // the (at most two) padding block columns between the last C column and the RHS columns are
+                    // updated like the rest -- a run-time test per block would cost more issue slots than their four fmacs
                     constexpr int BHI = (RHS0 + 6) / 4 + 1;
                     sfor<b + 1, (4 * a + 4 < BHI ? 4 * a + 4 : BHI)>([&](auto bb_) __attribute__((always_inline)) {
                         constexpr int bb = decltype(bb_)::value;
@@ -262,7 +258,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
 // accumulated from the solved border factors in two registers of the lanes (tr = c', tc = c mod 4).
 // ---------------------------------------------------------------------------------
 #ifndef TWX_UKWZ_WV
-#define TWX_UKWZ_WV 2, 2, 3, 4   // NBR = 6, 5, 4, 3 (the budgets of the bordered kernels they replace: k_ukw<NBR + 1, 1>)
+#define TWX_UKWZ_WV 2, 2, 3, 4   // NBR = 6, 5, 4, 3 (measured on the C2 bench)
 #endif
 __host__ __device__ constexpr int twx_ukwz_waves(int nbr)
 {

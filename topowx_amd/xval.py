@@ -202,10 +202,13 @@ def write_optim_nstns_files(path_out, stn_da, stn_ids, mae, ladder=DFLT_LADDER):
     return paths
 
 
-def set_optim_nstns_from_files(stn_da, path_xval_ds, namer):
+def set_optim_nstns_from_files(stn_da, path_xval_ds, namer, strict=True):
     """``set_optim_nstns_tair_norm / _anom`` as the reference runs them (optimize.py:285-316, :339-370): from the
-    per-division MAE files under ``path_xval_ds``.  A division without a file is skipped (the reference would fail
-    opening it).  Same arithmetic as ``set_optim_nstns`` (masked mean over the division's stations, first minimum)."""
+    per-division MAE files under ``path_xval_ds``.  A division without a file raises ``IOError`` -- the reference
+    fails at ``Dataset(fpath)`` (optimize.py:302-304), and stations left with stale / NaN ``optim_nnghs`` would only
+    surface later as TWX_CELL_NNGHS failures far from the cause; ``strict=False`` skips such divisions and returns
+    them under the key ``"missing"``.  Same arithmetic as ``set_optim_nstns`` (masked mean over the division's
+    stations, first minimum)."""
     import os
     from . import ncio
     stns = stn_da.stns
@@ -214,6 +217,9 @@ def set_optim_nstns_from_files(stn_da, path_xval_ds, namer):
     for clim_div in np.unique(climdiv_stns[np.isfinite(climdiv_stns)]):       # :300
         fpath = ncio.climdiv_optim_nstns_path(path_xval_ds, stn_da.var_name, clim_div)
         if not os.path.exists(fpath):
+            if strict:
+                raise IOError("no cross-validation file for climate division %g: %s" % (clim_div, fpath))
+            chosen.setdefault("missing", []).append(float(clim_div))
             continue
         mae_climdiv, nnghs_climdiv, _ = ncio.read_climdiv_optim_nstns_db(fpath)  # :304-307
         climdiv_mask = np.nonzero(climdiv_stns == clim_div)[0]                   # :308
