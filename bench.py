@@ -17,11 +17,13 @@ Rank 0 prints ONE JSON line (contract in the task description) carrying
   daily         (N = 1) the cell-DAY producing path, timed the same way: the same tile, Tmin + Tmax, normals +
                 GWR + 10 years of daily int16 values + Tmin>=Tmax fixer, outputs resident in HBM
   configs       (N = 1) the other BASELINE.json configurations, driver-timed in the same run: ``c4_tile`` (the
-                25 203-day tile of configs[3]), ``c5`` (configs[4]: the three cross-validation farms over all
-                stations), ``c3_strip`` (a 750x7000 strip of configs[2]'s masked grid through topowx_amd.driver)
-  strong        (N > 1) the tile farm of topowx_amd.driver on ONE fixed masked grid (the c3_strip workload):
-                LPT tile deal, per-rank device-resident tiles, RCCL gather of the normals mosaic on device
-                tensors; ``--scaling strong`` makes it the top-level line
+                25 203-day tile of configs[3]), ``c5`` (configs[4]: step21 -> 22 -> 23 -> 24 over all stations of the
+                12 000-station seed-2 database), ``c3`` (configs[2]: the FULL 3250x7000 masked grid, Tmin + Tmax
+                normals, through topowx_amd.driver on one GPU)
+  strong        (N > 1) the tile farm of topowx_amd.driver on ONE fixed masked grid (a 750x7000 strip of configs[2]'s
+                grid): LPT tile deal, per-rank device-resident tiles, RCCL gather of the normals mosaic on device
+                tensors; ``--scaling strong`` makes it the top-level line.  ``strong.daily``: the same deal on the
+                daily (streamed) path -- every rank streams its tiles' int16 days to pinned host memory, no gather
   cpu_baseline  (N = 1) the CPU oracle on bounded samples of the headline workload: all host cores (>= 64 cells
                 per thread) and one core
 """
@@ -44,6 +46,11 @@ ALG_BYTES_PER_CELL_MONTH_2V = 12.7   # Tmin + Tmax normals: 305 B / 24 cell-mont
 ALG_BYTES_PER_CELL_DAY = 2.03     # int16 out + amortised inputs / observation matrix
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VEC_PEAK_TFLOPS = 78.6       # vendor fp64 vector peak
+DTYPE = "f64 (f32 pair distances)"
+DTYPE_NOTE = ("everything that accumulates -- selection, Cholesky, solves, GWR, daily sums -- is fp64; the off-diagonal covariance "
+              "entries of well-conditioned kriging systems come from an fp32 pair-distance cache and v_exp_f32 (~2e-7 psill "
+              "per entry); systems that would amplify that beyond 1e-5 degC (amplification > 8, twx_select.h: uk_needs_f64) "
+              "are built in fp64 (k_uk<NB, 2, 1>)")
 
 
 def uk_flops(k):
@@ -79,8 +86,9 @@ def parse():
     ap.add_argument("--stream-tiles", type=int, default=4, help="tiles of the streamed (PCIe-inclusive) daily record; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
     ap.add_argument("--int16-window", type=int, default=24, help="edge of the cell window whose packed int16 days are compared with the oracle")
-    ap.add_argument("--no-configs", action="store_true", help="skip the c4_tile / c5 / c3_strip records (N = 1)")
-    ap.add_argument("--configs", default="c4_tile,c5,c3_strip", help="which of the other configurations to time")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c4_tile / c5 / c3 records (N = 1)")
+    ap.add_argument("--configs", default="c4_tile,c5,c3", help="which of the other configurations to time (c3 = the full "
+                                                               "configs[2] grid; c3_strip = the 750x7000 strip of the strong record)")
     ap.add_argument("--force-configs", action="store_true", help="time them also on a reduced --size (tests)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
                     help="auto: N = 1 headline (+ configs); N > 1 weak headline + a 'strong' record.  strong: the tile farm "
@@ -91,6 +99,11 @@ def parse():
     ap.add_argument("--strip-tile", type=int, default=250)
     ap.add_argument("--strong-steps", type=int, default=3, help="timed passes of the strong record when it is not the top-level line")
     ap.add_argument("--c5-years", type=int, default=3)
+    ap.add_argument("--c5-nstns", type=int, default=12000, help="stations of the configs[4] database (SURVEY 8d: 12 000, seed 2)")
+    ap.add_argument("--c3-steps", type=int, default=2, help="timed passes over the full configs[2] grid")
+    ap.add_argument("--strong-daily-rows", type=int, default=500, help="rows of the strong daily record's grid (0 = skip)")
+    ap.add_argument("--strong-daily-cols", type=int, default=1000)
+    ap.add_argument("--strong-daily-years", type=int, default=3)
     ap.add_argument("--dump-mosaic", default=None, help="strong mode: rank 0 writes the gathered mosaic here (.npz)")
     return ap.parse_args()
 
@@ -129,6 +142,14 @@ def latest_traffic():
     src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this workload, KB units x "
            "1024; 4-byte loads of the fp32 pair-distance cache: the guide's x2 correction for "
            "16-B/lane streaming reads does not apply)" % os.path.basename(paths[-1]))
+    # do the committed counters belong to the kernels in the tree?  (tests/test_profiles_fresh.py fails when they do not)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    try:
+        import kernel_hash
+        if tj.get("kernel_sources_sha16") != kernel_hash.kernel_sources_sha16():
+            src += " -- STALE: collected on other kernel sources than this tree's (re-run tests/tools/collect_round.sh)"
+    except ImportError:
+        pass
     return traffic, daily, src
 
 
@@ -258,7 +279,7 @@ def daily_record(env, args, base, grid, g, d_ninv, d_stat, day0, day1, label, st
         # measured HBM bytes of the launches behind daily_ms + gwr_ms (k_tile_union, k_daily_tile, k_gwr_z, ...) per step
         alg = ALG_BYTES_PER_CELL_DAY * cell_days
         rec["traffic"] = {"bytes_per_step": traffic_bytes, "algorithmic_bytes_per_step": alg, "ratio": traffic_bytes / alg,
-                          "source": traffic_src}
+                          "measured_in_this_run": False, "source": traffic_src}
     # packed int16 days against the oracle on a window of cells (integer output: identical except isolated +-1 LSB
     # where the fp64 value sits on a 0.005 rounding boundary and the summation order decides)
     if not args.no_cpu_baseline and int16_window > 0:
@@ -312,10 +333,31 @@ def daily_record(env, args, base, grid, g, d_ninv, d_stat, day0, day1, label, st
     return rec
 
 
+def shared_stations(env, key, build):
+    """A synthetic station database every rank needs: rank 0 builds it ONCE and saves it (uncompressed .npz in /dev/shm),
+    the others load it after a barrier -- N-rank setup is one build + N loads, not N builds on the same host cores."""
+    from topowx_amd import stationdb as sdb
+    if env.world == 1:
+        return build()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(base, "twx_bench_%s_%s.npz" % (os.environ.get("MASTER_PORT", "0"), key))
+    db = None
+    if env.rank == 0:
+        db = build()
+        db.save(path, compress=False)
+    env.dist.barrier()
+    if env.rank != 0:
+        db = sdb.StationDataWrkChk.load(path)
+    env.dist.barrier()
+    if env.rank == 0:
+        os.remove(path)
+    return db
+
+
 # =====================================================================================================================
-# the tile farm of topowx_amd.driver on ONE fixed masked grid (strong scaling; at N = 1 the c3_strip record)
+# the tile farm of topowx_amd.driver on ONE fixed masked grid (strong scaling; at N = 1 the c3 / c3_strip records)
 # =====================================================================================================================
-def strip_run(env, args, steps, warmup, spot_check):
+def strip_run(env, args, steps, warmup, spot_check, full=False):
     """BASELINE.json configs[2] shape on a strip of the seed-7 masked CONUS-shaped grid: Tmin + Tmax normals + SE of
     every valid cell, tiles dealt to the ranks with driver.assign_tiles (LPT), every rank's tiles computed device-
     resident into the send buffer of ONE dist.gather (RCCL over xGMI) that assembles the four mosaics on rank 0.
@@ -324,10 +366,12 @@ def strip_run(env, args, steps, warmup, spot_check):
     from topowx_amd import _lib, driver, synth
     T = args.strip_tile
     t_s = time.perf_counter()
-    # rows of configs[2]'s grid south of 45 N (the C3 grid starts at 51.6 N): same generator, same mask seed
-    grid = synth.make_grid("C3", nrows=args.strip_rows, ncols=args.strip_cols, lat_north=45.0, full_mask=False)
-    tmin = synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmin")
-    tmax = synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmax")
+    if full:       # BASELINE.json configs[2] itself: the whole 3250x7000 grid (fits one GPU: ~13 GB of HBM)
+        grid = synth.make_grid("C3")
+    else:          # rows of configs[2]'s grid south of 45 N (the C3 grid starts at 51.6 N): same generator, same mask seed
+        grid = synth.make_grid("C3", nrows=args.strip_rows, ncols=args.strip_cols, lat_north=45.0, full_mask=False)
+    tmin = shared_stations(env, "strip_tmin", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmin"))
+    tmax = shared_stations(env, "strip_tmax", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmax"))
     ctx = _lib.Context(device=env.local)
     ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
     ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
@@ -366,9 +410,11 @@ def strip_run(env, args, steps, warmup, spot_check):
     units = cells_ok * 24
     rec = {
         "value": units * steps / elapsed, "unit": "cell-months/s (Tmin + Tmax normals, mean + SE each)",
-        "workload": "c3_strip: %dx%d cells of the seed-7 masked CONUS-shaped 30-arcsec grid (rows south of 45 N of "
-                    "BASELINE.json configs[2]), %d synthetic stations per variable, 12 monthly Tmin + Tmax normals + SE; "
-                    "%dx%d tiles dealt by topowx_amd.driver.assign_tiles" % (shape[0], shape[1], args.strip_nstns, T, T),
+        "workload": ("c3: BASELINE.json configs[2] -- the FULL %dx%d seed-7 masked CONUS-shaped 30-arcsec grid, " % shape if full else
+                     "c3_strip: %dx%d cells of the seed-7 masked CONUS-shaped 30-arcsec grid (rows south of 45 N of "
+                     "BASELINE.json configs[2]), " % shape) +
+                    "%d synthetic stations per variable, 12 monthly Tmin + Tmax normals + SE; %dx%d tiles dealt by "
+                    "topowx_amd.driver.assign_tiles" % (args.strip_nstns, T, T),
         "n_gpus": env.world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "cells_valid": int((grid["mask"] != 0).sum()), "cells_ok": cells_ok, "tiles": len(tiles),
         "tiles_per_rank": [len(a) for a in assignment], "valid_cells_per_rank": per_rank_cells,
@@ -407,14 +453,66 @@ def strip_run(env, args, steps, warmup, spot_check):
     return rec
 
 
+def strong_daily_run(env, args):
+    """The daily (streamed) path under the same tile deal: every rank pushes its tiles through a TileStream
+    (twx_stream_*: kernels of tile t + 1 overlap the copy-out of tile t) into pinned host memory; NO gather -- the daily
+    int16 output (1.3 TB for configs[3]) is never assembled on a device: each rank's writer owns
+    its tiles, as the reference's workers write their own chunks (step25:177-185).  One pass = every tile of a fixed
+    masked grid; value = cell-days of all ranks / the slowest rank's wall."""
+    import datetime as dt
+    from topowx_amd import _lib, driver, synth
+    from topowx_amd.dates import get_days_metadata
+    T = args.strip_tile
+    R, Cc = args.strong_daily_rows // T * T, args.strong_daily_cols // T * T
+    grid = synth.make_grid("C3", nrows=R, ncols=Cc, lat_north=45.0, full_mask=False)
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + args.strong_daily_years, 12, 31))
+    nd = int(days.size)
+    seed = synth.CONFIGS["C3"][5]
+    t_s = time.perf_counter()
+    tmin = shared_stations(env, "sd_tmin", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, seed, "tmin", days, with_obs=True))
+    tmax = shared_stations(env, "sd_tmax", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, seed, "tmax", days, with_obs=True))
+    ctx = _lib.Context(device=env.local)
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    setup_s = time.perf_counter() - t_s
+    tiles = driver.tile_list(grid["mask"], T, T)
+    assignment = driver.assign_tiles(tiles, env.world)
+    mine = assignment[env.rank]
+    acc = {"bytes": 0, "ok": 0}
+
+    def sink(k, arrays):
+        acc["bytes"] += sum(v.nbytes for v in arrays.values() if hasattr(v, "nbytes"))
+        acc["ok"] += int((arrays["status"] == 0).sum())
+
+    driver.interp_tiles_streamed(ctx, grid, mine[:1], T, T, daily=True, sink=lambda k, a: None)     # warm-up: workspace, pinned slots
+    env.barrier()
+    t0 = time.perf_counter()
+    _, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, mine, T, T, daily=True, sink=sink) if mine else (None, 0.0, 0.0)
+    wall_local = time.perf_counter() - t0
+    env.barrier()
+    wall = env.max_over_ranks(wall_local)
+    ok = env.sum_over_ranks(acc["ok"])
+    rec = {"value": ok * nd * 2 / wall, "unit": "cell-days/s (Tmin + Tmax daily int16 + normals + SE, streamed to pinned host memory; PCIe-inclusive)",
+           "workload": "%dx%d cells of the seed-7 masked grid, %d stations per variable, %d days, %dx%d tiles dealt by assign_tiles; "
+                       "every rank streams its own tiles (interp_tiles_streamed), no gather" % (R, Cc, args.strip_nstns, nd, T, T),
+           "n_gpus": env.world, "scaling": "strong", "wall_s": wall, "cells_ok": int(ok), "days": nd,
+           "tiles_per_rank": [len(a) for a in assignment],
+           "wall_s_per_rank": env.all_gather_scalar(wall_local), "device_ms_per_rank": env.all_gather_scalar(dev_ms),
+           "d2h_bytes_per_rank": [int(b) for b in env.all_gather_scalar(acc["bytes"])], "setup_s": setup_s}
+    ctx.close()
+    return rec
+
+
 def config5_record(env, args):
     """BASELINE.json configs[4]: leave-one-out cross-validation + bandwidth optimisation over all stations."""
     from topowx_amd import xval
-    res, arr = xval.run_config5(args.nstns, args.c5_years, "tmin", 0, 0, 1, env.local, "cpu")
+    res, arr = xval.run_config5(args.c5_nstns, args.c5_years, "tmin", 0, 0, 1, env.local, "cpu", db="c5")
     rec = dict(res)
-    rec["workload"] = ("c5: step21 (variogram fit + kriging), step23 (GWR series + statistics), step24 (normals + daily) over all "
-                       "%d cross-validated stations of the %d-station C2 database x 16 bandwidths x 12 months, %d years of days; "
-                       "bandwidth optimisation (optimize.py:268-374) between the steps" % (res["stations"], args.nstns, args.c5_years))
+    rec["workload"] = ("c5: step21 (variogram fit + kriging x 16 bandwidths), step22 (every station's variogram with the optimised "
+                       "bandwidths), step23 (GWR series + statistics x 16 bandwidths), step24 (normals + daily) over all %d "
+                       "cross-validated stations of the %d-station seed-2 database drawn over the configs[2] grid (SURVEY 8d), "
+                       "12 months, %d years of days; bandwidth optimisation (optimize.py:268-374) after step21 / step23"
+                       % (res["stations"], res["stations_in_db"], args.c5_years))
     if not args.no_cpu_baseline:
         # step21's leave-one-out errors of three stations x three bandwidths against the oracle
         from oracle import pyoracle as orc
@@ -458,7 +556,7 @@ def main():
             res = {"metric": "grid-cell-days interpolated/sec", "value": rec["value"],
                    "unit": "cell-months/s (normals config: one time step = one calendar month, mean + SE)",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
-                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                    "config": {"workload": rec["workload"], "cells_ok": rec["cells_ok"],
                               "parallelism": "tiles of ONE grid dealt over %d GPU(s) (LPT), station table replicated, "
                                              "normals mosaic gathered on rank 0" % world},
@@ -516,6 +614,7 @@ def main():
     uk_ms = float(np.mean([t["uk_ms"] for t in kern]))
     launches = max(1, int(kern[-1]["uk_launches"]))
     solves = int(kern[-1]["uk_solves"])
+    f64_solves = int(kern[-1]["uk_f64_solves"])
     ach_gbs = ALG_BYTES_PER_CELL_MONTH * solves / (uk_ms * 1e-3) / 1e9
     # bandwidths actually used by the timed steps (diagnostic accessor, no extra launches)
     ks = ctx.last_bandwidths(_lib.TMIN).ravel()
@@ -540,17 +639,18 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": DTYPE, "dtype_note": DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": "C2: one %dx%d 30-arcsec tile per GPU, %d synthetic stations, 12 monthly Tmin "
                                "normals + SE (BASELINE.json configs[1])" % (Y, X, ctx.nstn[_lib.TMIN]),
                    "cells_ok": ncell_ok, "mean_nnghs": float(kpos.mean()),
                    "parallelism": "tiles partitioned over %d GPU(s), station table replicated" % world},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                     "traffic_measured_in_this_run": False,   # PMC counters cannot be read from inside the process
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_MONTH * solves / launches,
                      "kernel": "universal kriging: k_tile_dist + k_ukw<..> + k_uk<..> (%d launches per step)" % launches,
-                     "kernel_ms_per_step": uk_ms,
+                     "kernel_ms_per_step": uk_ms, "systems_on_fp64_covariance_build": f64_solves,
                      "note": "path is fp64-VALU bound, not HBM bound (SURVEY.md 8d); see fp64"},
         "fp64": {"achieved": ach_tflops, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach_tflops / FP64_VEC_PEAK_TFLOPS, "flops_per_solve": flops_per_solve,
@@ -651,6 +751,10 @@ def main():
             t1 = time.perf_counter()
             cfg["c5"] = config5_record(env, args)
             cfg["c5"]["record_wall_s"] = time.perf_counter() - t1
+        if "c3" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c3"] = strip_run(env, args, args.c3_steps, 1, spot_check=True, full=True)
+            cfg["c3"]["record_wall_s"] = time.perf_counter() - t1
         if "c3_strip" in want_cfg:
             t1 = time.perf_counter()
             cfg["c3_strip"] = strip_run(env, args, args.strong_steps, 1, spot_check=True)
@@ -666,8 +770,10 @@ def main():
         torch.cuda.empty_cache()
         rec = strip_run(env, args, args.strong_steps, 1, spot_check=False)
         rec["scaling"] = "strong"
-        rec["note"] = ("total work fixed as N grows; the N = 1 counterpart is configs.c3_strip of the N = 1 line "
-                       "(same code path: topowx_amd.driver)")
+        rec["note"] = ("total work fixed as N grows; its N = 1 counterpart: python bench.py --configs c3_strip (same code "
+                       "path as configs.c3 of the N = 1 line: topowx_amd.driver)")
+        if args.strong_daily_rows > 0:
+            rec["daily"] = strong_daily_run(env, args)
         res["strong"] = rec
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -161,6 +161,7 @@ typedef struct {
     int64_t cells;        /* unmasked cells processed */
     int64_t uk_solves;    /* (cell, month, variable) kriging systems solved */
     int64_t uk_launches;  /* kernel launches of the kriging kernel */
+    int64_t uk_f64_solves; /* of uk_solves: ill-conditioned systems that took the fp64 covariance build (TWX_FLAG_UK_FAST_ONLY) */
 } twx_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

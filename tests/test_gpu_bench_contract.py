@@ -48,12 +48,17 @@ SMALL_STRIP = ("--strip-rows", "100", "--strip-cols", "400", "--strip-tile", "50
 
 
 def test_bench_spawns_ranks_itself():
-    d = _run("--gpus", "2", "--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1", "--strong-steps", "1", *SMALL_STRIP)
+    d = _run("--gpus", "2", "--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1", "--strong-steps", "1",
+             "--strong-daily-rows", "100", "--strong-daily-cols", "200", "--strong-daily-years", "1", *SMALL_STRIP)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "daily" not in d and "cpu_baseline" not in d          # rank-0, N = 1 records only
     s = d["strong"]                                              # ... and the tile farm on one fixed grid next to it
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["value"] > 0 and len(s["device_ms_per_rank"]) == 2
     assert sum(s["tiles_per_rank"]) == s["tiles"] and s["cells_ok"] == s["cells_valid"] and s["imbalance_max_over_mean"] >= 1.0
+    sd = s["daily"]                                              # the daily (streamed) path under the same deal: no gather
+    assert sd["scaling"] == "strong" and sd["value"] > 0 and sd["days"] == 365 and len(sd["d2h_bytes_per_rank"]) == 2
+    assert 1 <= sum(sd["tiles_per_rank"]) <= 8 and sd["cells_ok"] > 0, sd      # (tiles without a valid cell are not dealt)
+    assert sum(sd["d2h_bytes_per_rank"]) >= sd["cells_ok"] * 365 * 4, sd
 
 
 def test_bench_strong_two_ranks_equal_one_rank(tmp_path):
@@ -78,15 +83,20 @@ def test_bench_strong_two_ranks_equal_one_rank(tmp_path):
 
 
 def test_bench_other_configs_reduced():
-    """The c4_tile / c5 / c3_strip records of the default line, on reduced sizes (--force-configs)."""
+    """The c4_tile / c5 / c3 records of the default line, on reduced sizes (--force-configs; c3_strip = the code path of
+    c3 on a small strip instead of the full configs[2] grid)."""
     d = _run("--size", "64", "--nstns", "2500", "--steps", "1", "--warmup", "1", "--no-daily", "--cpu-sample", "16",
-             "--force-configs", "--c5-years", "1", "--strong-steps", "1", *SMALL_STRIP)
+             "--force-configs", "--configs", "c4_tile,c5,c3_strip", "--c5-years", "1", "--c5-nstns", "2500",
+             "--strong-steps", "1", *SMALL_STRIP)
+    assert d["dtype"].startswith("f64") and d["roofline"]["traffic_measured_in_this_run"] is False
+    assert d["roofline"]["systems_on_fp64_covariance_build"] == 0        # the synthetic nuggets are >= 0.1: fast build only
     c = d["configs"]
     t = c["c4_tile"]
     assert t["value"] > 0 and t["cell_days_per_step"] == t["cells_ok"] * 25203 * 2 and t["cells_ok"] == 64 * 64
     assert t["packed_int16_vs_oracle"]["max_abs_lsb"] <= 1 and t["packed_int16_vs_oracle"]["ninvalid_equal"]
     x = c["c5"]
-    assert x["step21_s"] > 0 and x["step23_s"] > 0 and x["step24_s"] > 0 and x["stations"] > 2000
+    assert x["step21_s"] > 0 and x["step22_s"] > 0 and x["step23_s"] > 0 and x["step24_s"] > 0 and x["stations"] > 2000
+    assert x["db"] == "c5" and x["step22_fitted_frac"] > 0.95
     assert x["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4 and x["spot_check_vs_oracle"]["step21_values"] > 0
     s = c["c3_strip"]
     assert s["value"] > 0 and s["cells_ok"] == s["cells_valid"] and s["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4

@@ -87,3 +87,41 @@ def test_step24_farm(golden_case, golden, orc):
         if rc == 0:
             assert np.abs(norms[q] - wn).max() < TOL and np.abs(se[q] - ws).max() < TOL
             assert np.abs(dly[q] - d).max() < 1e-3
+
+
+def test_step22_farm(golden_case, orc):
+    """step22 (step22:33-142): every cross-validated station's variogram for every month, fitted with its optimised
+    bandwidth and written into vario_*MM; sampled stations against the oracle's restatement of get_vario_params
+    (BuildKrigParams.get_krig_params: bandwidth smoothed, the station stays in its own neighbourhood)."""
+    from topowx_amd import stationdb as sdb, xval
+    _, tmin, _ = golden_case
+    stn = sdb.StationSerialDataDb(tmin.stns.copy(), "tmin", tmin.days, None)
+    before = stn.stns.copy()
+    ids, nug, psill, rng = xval.set_stn_variograms(stn, "tmin", batch=100)
+    good = np.isnan(before[sdb.BAD])
+    assert ids.size == int((np.isfinite(before[sdb.MASK]) & good).sum()) and nug.shape == (12, ids.size)
+    ok = np.isfinite(nug).all(axis=0)
+    assert ok.mean() > 0.95 and (nug[:, ok] >= 0).all() and (psill[:, ok] >= 0).all() and (rng[:, ok] >= 0).all()
+    # a failed station keeps NaN in all three parameters of all twelve months
+    assert np.isnan(psill[:, ~ok]).all() and np.isnan(rng[:, ~ok]).all()
+    # written into the table for exactly the cross-validated stations; everything else untouched
+    pos = {s: i for i, s in enumerate(stn.stns[sdb.STN_ID])}
+    rows = np.array([pos[s] for s in ids])
+    other = np.setdiff1d(np.arange(stn.stns.size), rows)
+    for m in range(1, 13):
+        for a, nm in ((nug, sdb.VARIO_NUG), (psill, sdb.VARIO_PSILL), (rng, sdb.VARIO_RNG)):
+            f = sdb.get_krigparam_varname(m, nm)
+            np.testing.assert_array_equal(stn.stns[f][rows], a[m - 1])
+            np.testing.assert_array_equal(stn.stns[f][other], before[f][other])
+    # against the oracle, which fits on the table as it was BEFORE the farm wrote into it
+    db, prm = orc.Db(sdb.StationSerialDataDb(before, "tmin", tmin.days, None)), orc.params()
+    c = db.cols
+    idx = {s: i for i, s in enumerate(before[sdb.STN_ID][good])}
+    for q in np.random.default_rng(22).choice(ids.size, 6, replace=False):
+        j = idx[ids[q]]
+        for m in (1, 6, 11):
+            rc, v, _ = orc.build_krig_params(db, prm, _pt(orc, c, j), m)
+            if rc:
+                assert not ok[q]
+                continue
+            np.testing.assert_allclose([nug[m - 1, q], psill[m - 1, q], rng[m - 1, q]], v, rtol=1e-6, atol=1e-9)

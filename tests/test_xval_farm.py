@@ -152,6 +152,32 @@ class _OracleXvalNorm(object):
         pass
 
 
+class _OracleKrigParams(object):
+    """Stand-in for interp.optimize.StationKrigParams (step22) computed by the oracle."""
+
+    def __init__(self, stn_da, tair_var, device=0):
+        from oracle import pyoracle as orc
+        from topowx_amd import stationdb as sdb
+        self.orc, self.db, self.prm = orc, orc.Db(stn_da), orc.params()
+        self.idx = {s: i for i, s in enumerate(stn_da.stns[sdb.STN_ID][np.isnan(stn_da.stns[sdb.BAD])])}
+
+    def get_krig_params_many(self, stn_ids, raise_on_error=True):
+        c = self.db.cols
+        out = np.zeros((3, len(stn_ids), 12))
+        ok = np.ones(len(stn_ids), bool)
+        for i, s in enumerate(stn_ids):
+            j = self.idx[s]
+            pt = self.orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+            for m in range(1, 13):
+                rc, v, _ = self.orc.build_krig_params(self.db, self.prm, pt, m)
+                ok[i] &= rc == 0
+                out[:, i, m - 1] = v
+        return out[0], out[1], out[2], ok
+
+    def close(self):
+        pass
+
+
 def _case():
     from topowx_amd import stationdb as sdb, synth
     grid = synth.make_grid("C1", nrows=20, ncols=20)
@@ -169,6 +195,10 @@ def _farm(rank, world):
     ids = xval.xval_station_ids(stn)[:23]
     ids_out, mae = xval.optim_nstns_norms(stn, "tmin", ladder=[35, 57], stn_ids=ids, rank=rank, world=world, batch=4)
     chosen = xval.set_optim_nstns_tair_norm(stn, ids_out, mae, [35, 57])
+    # step22 on the table step21's reduction has just written the bandwidths into
+    import topowx_amd.interp.optimize as opt
+    opt.StationKrigParams = _OracleKrigParams
+    xval.set_stn_variograms(stn, "tmin", stn_ids=ids[:9], rank=rank, world=world, batch=2)
     return ids_out, mae, chosen, stn
 
 
@@ -182,7 +212,9 @@ def _worker(rank, world, port, outdir):
     ids, mae, chosen, stn = _farm(rank, world)
     from topowx_amd import stationdb as sdb
     np.savez(os.path.join(outdir, "r%d.npz" % rank), ids=ids, mae=mae,
-             optim=np.stack([stn.stns[sdb.get_optim_varname(m)] for m in range(1, 13)]))
+             optim=np.stack([stn.stns[sdb.get_optim_varname(m)] for m in range(1, 13)]),
+             vario=np.stack([stn.stns[sdb.get_krigparam_varname(m, f)] for m in range(1, 13)
+                             for f in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -194,9 +226,16 @@ def test_two_rank_xval_farm_equals_single_process(tmp_path):
     ids, mae, chosen, stn = _farm(0, 1)
     assert mae.shape == (12, 2, 23) and np.isfinite(mae).all() and (mae > 0).all()
     want_optim = np.stack([stn.stns[sdb.get_optim_varname(m)] for m in range(1, 13)])
+    want_vario = np.stack([stn.stns[sdb.get_krigparam_varname(m, f)] for m in range(1, 13)
+                           for f in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG)])
+    orig = np.stack([_case()[0].stns[sdb.get_krigparam_varname(m, f)] for m in range(1, 13)
+                     for f in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG)])
+    changed = ~((want_vario == orig) | (np.isnan(want_vario) & np.isnan(orig)))
+    assert 0 < changed.any(axis=0).sum() <= 9                           # only the nine stations step22 was asked for
     for r in range(2):                                     # every rank ends with the full result
         got = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         np.testing.assert_array_equal(got["ids"], ids)
         np.testing.assert_array_equal(got["mae"], mae)
         np.testing.assert_array_equal(got["optim"], want_optim)
+        np.testing.assert_array_equal(got["vario"], want_vario)          # step22: every rank ends with the same table
     assert len(chosen) >= 1 and all(set(v) <= {35, 57} for v in chosen.values())

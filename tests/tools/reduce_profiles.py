@@ -64,6 +64,9 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
         steps = max(1, group(dper, ("k_daily_tile",), exact=True)[0])
         n, kb = group(dper, DAILY + ("k_gwr_z",))            # (prefix: k_gwr_z_cell too)
         res[key]["daily_path_per_step_bytes"] = kb * 1024.0 / steps
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_hash  # noqa: E402
+res["kernel_sources_sha16"] = kernel_hash.kernel_sources_sha16()     # the kernels these bytes were measured on
 json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
 
 

@@ -84,7 +84,7 @@ class TwxTiming(C.Structure):
     _fields_ = [("tile_cand_ms", C.c_float), ("select_ms", C.c_float), ("uk_ms", C.c_float),
                 ("gwr_ms", C.c_float), ("daily_ms", C.c_float), ("fix_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_int64), ("uk_solves", C.c_int64),
-                ("uk_launches", C.c_int64)]
+                ("uk_launches", C.c_int64), ("uk_f64_solves", C.c_int64)]
 
 
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",

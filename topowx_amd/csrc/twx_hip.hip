@@ -110,7 +110,7 @@ struct twx_ctx {
     size_t ev_used = 0;
     twx_timing timing{};
     int64_t t_cells = 0;
-    DevBuf stats;                 // [2] int64: kriging systems solved, kriging launches with work (device-side counters)
+    DevBuf stats;                 // [3] int64: kriging systems solved, kriging launches with work, systems on the fp64 build (device-side counters)
     int ncu = 256;                // compute units (sizes the fixed grids of the kriging launches)
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     bool have_total = false;
@@ -1459,9 +1459,9 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
         HIPCHK(hipEventSynchronize(ctx->ev_total_b));
         HIPCHK(hipEventElapsedTime(&r.total_ms, ctx->ev_total_a, ctx->ev_total_b));
     }
-    long long st[2] = {0, 0};
+    long long st[3] = {0, 0, 0};
     if (ctx->stats.p) HIPCHK(hipMemcpy(st, ctx->stats.p, sizeof st, hipMemcpyDeviceToHost));
-    r.cells = ctx->t_cells; r.uk_solves = st[0]; r.uk_launches = st[1];
+    r.cells = ctx->t_cells; r.uk_solves = st[0]; r.uk_launches = st[1]; r.uk_f64_solves = st[2];
     *t = r;
     return 0;
 }

@@ -665,11 +665,15 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 }
 
 // launch statistics for twx_get_timing without a host read-back on the launch path: stats[0] += systems solved,
-// stats[1] += kriging launches that had work (+ 1 for k_cell_dist)
+// stats[1] += kriging launches that had work (+ 1 for k_cell_dist), stats[2] += systems that took the fp64 build
 __global__ void k_bucket_stats(SelWs ws, long long *stats)
 {
     const int b = threadIdx.x;
     const int c = b < TWX_NBUCKET ? ws.bucket_cnt[b] : 0;
-    const int tot = wave_sum_i(c), nz = wave_sum_i(c > 0 ? 1 : 0);
-    if (b == 0) { atomicAdd((unsigned long long *)&stats[0], (unsigned long long)tot); atomicAdd((unsigned long long *)&stats[1], (unsigned long long)(nz + 1)); }
+    const int tot = wave_sum_i(c), nz = wave_sum_i(c > 0 ? 1 : 0), f64 = wave_sum_i(b >= TWX_BUCKET_F64 ? c : 0);
+    if (b == 0) {
+        atomicAdd((unsigned long long *)&stats[0], (unsigned long long)tot);
+        atomicAdd((unsigned long long *)&stats[1], (unsigned long long)(nz + 1));
+        atomicAdd((unsigned long long *)&stats[2], (unsigned long long)f64);
+    }
 }

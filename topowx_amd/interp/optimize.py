@@ -135,12 +135,18 @@ class StationKrigParams(_XvalBase):
         nug, psill, rng = self.get_krig_params_many([stn_id])
         return nug[0], psill[0], rng[0]
 
-    def get_krig_params_many(self, stn_ids):
+    def get_krig_params_many(self, stn_ids, raise_on_error=True):
+        """Batched form: (nug, psill, rng), each [n_stations, 12].  ``raise_on_error=False`` (the step22 worker,
+        step22:52-62: a station whose fit fails gets the f8 fill value for all twelve months) also returns
+        ok[n_stations]."""
         j, pt = self._pts(stn_ids)
         pts = np.repeat(pt, 12)
         mth = np.tile(np.arange(1, 13, dtype=np.int32), len(stn_ids))
         vario, _, st = self.ctx.fit_vario_points(self.var, pts, mth)
-        for q in st:
-            raise_for_status(q)
+        if raise_on_error:
+            for q in st:
+                raise_for_status(q)
         v = vario.reshape(len(stn_ids), 12, 3)
-        return v[:, :, 0], v[:, :, 1], v[:, :, 2]
+        if raise_on_error:
+            return v[:, :, 0], v[:, :, 1], v[:, :, 2]
+        return v[:, :, 0], v[:, :, 1], v[:, :, 2], (st == 0).reshape(len(stn_ids), 12).all(axis=1)

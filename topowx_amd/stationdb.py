@@ -117,8 +117,8 @@ class StationSerialDataDb(object):
         return obs
 
     # -- persistence (npz; the netCDF layout lives in topowx_amd/ncio.py) -----
-    def save(self, path):
-        np.savez_compressed(path, stns=self.stns, var_name=self.var_name,
+    def save(self, path, compress=True):
+        (np.savez_compressed if compress else np.savez)(path, stns=self.stns, var_name=self.var_name,
                             ymd0=int(self.days.YMD[0]), ymd1=int(self.days.YMD[-1]),
                             obs=self.var if self.var is not None else np.zeros((0, 0), np.float32))
 

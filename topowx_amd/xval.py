@@ -3,6 +3,7 @@
 Counterpart of the reference's three MPI farms and of the reduction their writer rank runs at the end:
 
   step21_mpi_optim_nstns_norms.py:34-169   XvalTairNorm.run_xval per station -> |err| -> 'mae'[12, 16, nstn]
+  step22_mpi_set_stn_variograms.py:33-142  StationKrigParams.get_krig_params per station -> vario_nug/psill/rngMM
   step23_mpi_optim_nstns_anoms.py:35-180   XvalTairAnom.run_xval per station -> mae / bias / r2
   step24_mpi_xval_interp.py:36-156         XvalTairOverall.run_interp per station -> daily + normals
   twx/interp/optimize.py:268-374           set_optim_nstns_tair_norm / _anom: mean MAE per climate division and
@@ -23,9 +24,10 @@ which is what ``set_optim_nstns_tair_*`` index (``mae_climdiv[mth - 1, :, :]``, 
 import numpy as np
 
 from .interp.optimize import XvalTairAnom, XvalTairNorm, XvalTairOverall, build_nstn_bandwidths
-from .stationdb import BAD, CLIMDIV, MASK, STN_ID, get_optim_anom_varname, get_optim_varname
+from .stationdb import (BAD, CLIMDIV, MASK, STN_ID, VARIO_NUG, VARIO_PSILL, VARIO_RNG, get_krigparam_varname,
+                        get_optim_anom_varname, get_optim_varname)
 
-__all__ = ["xval_station_ids", "shard", "optim_nstns_norms", "optim_nstns_anoms", "xval_interp", "set_optim_nstns",
+__all__ = ["xval_station_ids", "shard", "optim_nstns_norms", "set_stn_variograms", "optim_nstns_anoms", "xval_interp", "set_optim_nstns",
            "set_optim_nstns_tair_norm", "set_optim_nstns_tair_anom", "write_optim_nstns_files",
            "set_optim_nstns_from_files", "run_config5", "DFLT_LADDER"]
 
@@ -95,6 +97,40 @@ def optim_nstns_norms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0
     finally:
         xv.close()
     return ids, _all_gather(mae, len(ids), rank, world, gather_device)
+
+
+def set_stn_variograms(stn_da, tair_var, stn_ids=None, rank=0, world=1, batch=1024, device=0, gather_device="cpu"):
+    """step22: the variogram parameters of every station location for every month, fitted with the station's optimised
+    bandwidth (``optim_nnghsMM`` smoothed over its neighbours; the station stays inside its own neighbourhood,
+    interp_tair.py:667,681) and written into ``vario_nugMM / vario_psillMM / vario_rngMM`` of ``stn_da.stns`` for the
+    stations inside the mask that are not flagged bad (step22:33-66 worker, :68-118 writer, :119-121 station list).
+
+    Returns ``(stn_ids, nug[12, n], psill[12, n], rng[12, n])``; a station whose fit fails keeps NaN in all twelve
+    months (the reference writes the f8 fill value, which ``_build_stn_struct`` reads back as NaN,
+    station_data.py:159-164).  Every rank fits its strided share and all ranks end with the same table."""
+    from .interp.optimize import StationKrigParams
+    ids = xval_station_ids(stn_da) if stn_ids is None else np.asarray(stn_ids)
+    mine = shard(ids, rank, world)
+    out = np.full((3, 12, len(mine)), np.nan)
+    kp = StationKrigParams(stn_da, tair_var, device=device)
+    try:
+        for i, chunk in _batches(mine, batch):
+            nug, psill, rng, ok = kp.get_krig_params_many(chunk, raise_on_error=False)     # [ns, 12]
+            for q, a in enumerate((nug, psill, rng)):
+                blk = a.T.copy()
+                blk[:, ~ok] = np.nan
+                out[q, :, i:i + len(chunk)] = blk
+    finally:
+        kp.close()
+    out = _all_gather(out, len(ids), rank, world, gather_device)
+    stns = stn_da.stns
+    pos = {s: i for i, s in enumerate(stns[STN_ID])}
+    rows = np.array([pos[s] for s in ids], np.int64)
+    for m in range(1, 13):                                                                   # step22:104-110
+        stns[get_krigparam_varname(m, VARIO_NUG)][rows] = out[0, m - 1]
+        stns[get_krigparam_varname(m, VARIO_PSILL)][rows] = out[1, m - 1]
+        stns[get_krigparam_varname(m, VARIO_RNG)][rows] = out[2, m - 1]
+    return ids, out[0], out[1], out[2]
 
 
 def optim_nstns_anoms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0, world=1, batch=128, device=0,
@@ -243,42 +279,73 @@ def set_optim_nstns_tair_anom(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
     return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_anom_varname)[1]
 
 
-def run_config5(nstns=2000, years=3, var="tmin", max_stations=0, rank=0, world=1, device=0, gather_device="cpu"):
-    """BASELINE.json configs[4] end to end on a synthetic database, timed: step21 (variogram fit + kriging per
-    (station, bandwidth, month), step21:34-64), ``set_optim_nstns_tair_norm``, step23 (GWR series + statistics,
-    step23:35-70), ``set_optim_nstns_tair_anom``, step24 (normals + daily values with the optimised bandwidths,
-    step24:36-69).  Returns (timings / rates dict, arrays dict for spot checks)."""
+def config5_bbox(db):
+    """Bounding box the synthetic station database of ``run_config5`` is drawn over: "c5" = the CONUS-shaped grid of
+    BASELINE.json configs[2..4] (12 000 stations per variable, seed 2), "c2" = the C2 tile."""
+    from . import synth
+    nrows, ncols, lat_north, lon_west, _, seed = synth.CONFIGS["C3" if db == "c5" else "C2"]
+    lat = lat_north - (np.arange(nrows) + 0.5) * synth.CELL
+    lon = lon_west + (np.arange(ncols) + 0.5) * synth.CELL
+    return (lat.min(), lat.max(), lon.min(), lon.max()), seed
+
+
+def run_config5(nstns=2000, years=3, var="tmin", max_stations=0, rank=0, world=1, device=0, gather_device="cpu", db="c2",
+                stn_path=None):
+    """BASELINE.json configs[4] end to end on a synthetic database, timed, in the order the reference runs the farms:
+    step21 (variogram fit + kriging per (station, bandwidth, month), step21:34-64), ``set_optim_nstns_tair_norm``,
+    step22 (every station's variogram with the optimised bandwidths, step22:33-66), step23 (GWR series + statistics,
+    step23:35-70), ``set_optim_nstns_tair_anom``, step24 (normals + daily values with everything the previous steps
+    set, step24:36-69).  ``db="c5"``: SURVEY 8d's configs[4] database (stations over the CONUS-shaped grid, seed 2;
+    ``nstns`` = 12 000 there); ``db="c2"``: the C2 tile's.  ``stn_path``: with ``world`` > 1 rank 0 builds the
+    database once and saves it there, the other ranks load it after the barrier (N x setup otherwise).
+    Returns (timings / rates dict, arrays dict for spot checks)."""
     import time
     import datetime as dt
     from . import synth
     from .dates import get_days_metadata
+    from .stationdb import StationDataWrkChk
     days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + years, 12, 31))
-    grid = synth.make_grid("C2")
-    stn = synth.make_stations(grid["bbox"], nstns, 1, var, days, with_obs=True)
+    bbox, seed = config5_bbox(db)
+    t0 = time.perf_counter()
+    if stn_path and world > 1:
+        import torch.distributed as dist
+        if rank == 0:
+            synth.make_stations(bbox, nstns, seed, var, days, with_obs=True).save(stn_path)
+        dist.barrier()
+        stn = StationDataWrkChk.load(stn_path)
+    else:
+        stn = synth.make_stations(bbox, nstns, seed, var, days, with_obs=True)
     ids = xval_station_ids(stn)
     if max_stations:
         ids = ids[:max_stations]
-    res = {"stations": int(len(ids)), "ladder": int(DFLT_LADDER.size), "days": int(days.size), "n_gpus": world}
+    res = {"stations": int(len(ids)), "stations_in_db": int(stn.stns.size), "db": db, "ladder": int(DFLT_LADDER.size),
+           "days": int(days.size), "n_gpus": world, "setup_s": time.perf_counter() - t0}
+    kw = dict(stn_ids=ids, rank=rank, world=world, device=device, gather_device=gather_device)
     t0 = time.perf_counter()
-    _, mae_n = optim_nstns_norms(stn, var, stn_ids=ids, rank=rank, world=world, device=device, gather_device=gather_device)
+    _, mae_n = optim_nstns_norms(stn, var, **kw)
     res["step21_s"] = time.perf_counter() - t0
     stn_before = stn.stns.copy()                     # the table step21 cross-validated against (for spot checks)
     set_optim_nstns_tair_norm(stn, ids, mae_n)
     t0 = time.perf_counter()
-    _, mae_a, _, _ = optim_nstns_anoms(stn, var, stn_ids=ids, rank=rank, world=world, device=device, gather_device=gather_device)
+    _, nug, psill, rng = set_stn_variograms(stn, var, **kw)
+    res["step22_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, mae_a, _, _ = optim_nstns_anoms(stn, var, **kw)
     res["step23_s"] = time.perf_counter() - t0
     set_optim_nstns_tair_anom(stn, ids, mae_a)
     t0 = time.perf_counter()
-    _, norms, _, _, st = xval_interp(stn, var, stn_ids=ids, daily=True, rank=rank, world=world, device=device,
-                                     gather_device=gather_device)
+    _, norms, _, _, st = xval_interp(stn, var, daily=True, **kw)
     res["step24_s"] = time.perf_counter() - t0
     res["step21_systems_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step21_s"]
+    res["step22_fits_per_s"] = len(ids) * 12 / res["step22_s"]
     res["step23_series_per_s"] = len(ids) * DFLT_LADDER.size * 12 / res["step23_s"]
     res["step24_station_days_per_s"] = len(ids) * days.size / res["step24_s"]
     res["failed"] = int((st != 0).sum())
     res["step21_mae_finite_frac"] = float(np.isfinite(mae_n).mean())
+    res["step22_fitted_frac"] = float(np.isfinite(nug).mean())
+    res["step22_pure_nugget_frac"] = float((rng[np.isfinite(rng)] == 0).mean()) if np.isfinite(rng).any() else 0.0
     return res, {"ids": ids, "mae_norm": mae_n, "mae_anom": mae_a, "norms": norms, "status": st, "stn": stn,
-                 "stns_step21": stn_before}
+                 "stns_step21": stn_before, "vario": (nug, psill, rng)}
 
 
 def main():
@@ -292,6 +359,7 @@ def main():
     ap.add_argument("--years", type=int, default=3)
     ap.add_argument("--var", default="tmin")
     ap.add_argument("--max-stations", type=int, default=0, help="cross-validate only the first N stations (0 = all)")
+    ap.add_argument("--db", choices=("c2", "c5"), default="c2", help="c5: stations over the CONUS-shaped grid, seed 2 (use --nstns 12000)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +371,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         gdev = "cuda:%d" % local
-    res, _ = run_config5(args.nstns, args.years, args.var, args.max_stations, rank, world, local, gdev)
+    res, _ = run_config5(args.nstns, args.years, args.var, args.max_stations, rank, world, local, gdev, db=args.db)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
