@@ -49,9 +49,10 @@ extern "C" {
 #define TWX_CELL_RANGE 6        /* bandwidth above TWX_MAX_NNGHS */
 #define TWX_CELL_CAND_OVERFLOW 7 /* library limit, no reference counterpart: the candidate list of the cell's 8x8-cell tile
                                   * (stations that can be among the nearest TWX_MAX_NNGHS + 1 of any of its cells) holds
-                                  * more than 2 048 stations (512 per point in the point entries): the cell is failed
+                                  * more than 4 096 stations (512 per point in the point entries): the cell is failed
                                   * rather than ranked from a truncated list.  Only reached by station clusters far
-                                  * denser than the grid (> 2 048 stations within ~10 km). */
+                                  * denser than the grid (> 4 096 stations within ~10 km: a third of all CONUS stations
+                                  * in reach of one 8 km tile). */
 #define TWX_CELL_MASKED (-1)    /* cell outside the interpolation mask: nothing computed */
 
 /* netCDF4 default fill values the reference worker pre-fills with (step25:73-88) */

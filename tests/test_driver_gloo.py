@@ -165,3 +165,99 @@ def test_two_rank_device_gather(tmp_path):
     for q, key in enumerate(driver.NORMAL_KEYS):
         assert np.array_equal(z[key][:, covered], truth[q][:, covered])
         assert np.all(z[key][:, ~covered] == driver.FILL_F4)
+
+
+# ---- eight ranks on the tile structure of the full configs[2] grid ---------------------------------------------------
+C3_T = 250
+
+
+def _c3_tiles():
+    """Tiles of BASELINE.json configs[2]'s grid (3250x7000 cells, seed-7 land mask, 250x250 tiles) and the same tile
+    structure at 1/5 of the resolution (650x1400 cells, 50x50 tiles: tile k of one is tile k of the other as long as
+    both hold a valid cell), which is what the eight-rank gather below moves around."""
+    from topowx_amd import driver, synth
+    mask = synth.make_mask("C3")
+    tiles = driver.tile_list(mask, C3_T, C3_T)
+    small = np.zeros((650, 1400), np.uint8)
+    for _, i, j, _ in tiles:
+        small[i // 5:i // 5 + 50, j // 5:j // 5 + 50] = mask[i:i + C3_T:5, j:j + C3_T:5]
+        small[i // 5, j // 5] = 1                              # (keeps every tile of the full grid non-empty here)
+    return mask, tiles, small
+
+
+def test_c3_tile_deal_is_balanced_for_1_to_8_ranks():
+    """assign_tiles on the full configs[2] mask: every tile dealt exactly once, valid-cell imbalance (max / mean) <= 1.05
+    for N = 2, 4, 8 -- the deal bench.py --scaling strong and topowx_amd.driver use (reference shape: step25:266-314)."""
+    from topowx_amd import driver
+    mask, tiles, _ = _c3_tiles()
+    assert mask.shape == (3250, 7000) and abs(mask.mean() - 0.57) < 0.01 and 250 < len(tiles) <= 364
+    assert sum(t[3] for t in tiles) == int(mask.sum())
+    for world in (1, 2, 4, 8):
+        a = driver.assign_tiles(tiles, world)
+        assert sorted(t for part in a for t in part) == sorted(tiles)
+        loads = np.array([sum(t[3] for t in part) for part in a], np.float64)
+        assert loads.max() / loads.mean() <= 1.05, (world, loads)
+
+
+def _worker_c3_gather(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from topowx_amd import driver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(outdir, "c3_small.npz"))
+    small, T = z["small"], 50
+    Y, X = small.shape
+    tiles = driver.tile_list(small, T, T)
+    assignment = driver.assign_tiles([(k, i, j, int(n)) for k, i, j, n in z["tiles_full"]], world)   # the FULL grid's deal
+    small_of = {t[0]: t for t in tiles}
+    mine = [small_of[t[0]] for t in assignment[rank]]
+    nmax = max(len(a) for a in assignment)
+    # slot contents: a known field of the global cell index (what interp_tiles_device would have computed)
+    yy, xx = np.meshgrid(np.arange(Y, dtype=np.float32), np.arange(X, dtype=np.float32), indexing="ij")
+    truth = np.stack([np.stack([(q * 100 + m) + yy * 0.001 + xx * 1e-6 for m in range(12)]) for q in range(4)]).astype(np.float32)
+    buf = torch.full((nmax, 4, 12, T, T), float(driver.FILL_F4), dtype=torch.float32)
+    for s, (_, i, j, _) in enumerate(mine):
+        buf[s] = torch.from_numpy(truth[:, :, i:i + T, j:j + T])
+    small_assignment = [[small_of[t[0]] for t in part] for part in assignment]
+    mosaic = driver.gather_mosaic_device(buf, small_assignment, (Y, X), T, T, rank, world, backend="gloo")
+    if rank == 0:
+        np.savez(os.path.join(outdir, "c3_mosaic.npz"), **{k: v.numpy() for k, v in mosaic.items()})
+    else:
+        assert mosaic is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_device_gather_on_the_c3_tile_structure(tmp_path):
+    """Eight gloo ranks, the deal of the full configs[2] grid, gather_mosaic_device: the mosaic equals the one a single
+    process assembles (and the known field) on every dealt tile, fill elsewhere.  Unmeasured on hardware: RCCL has not
+    run this collective yet; this pins the slot / rank / tile bookkeeping at the production world size."""
+    import torch
+    from topowx_amd import driver
+    mask, tiles, small = _c3_tiles()
+    np.savez(os.path.join(str(tmp_path), "c3_small.npz"), small=small, tiles_full=np.array(tiles, np.int64))
+    port = _free_port()
+    mp.spawn(_worker_c3_gather, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    got = np.load(os.path.join(str(tmp_path), "c3_mosaic.npz"))
+    T = 50
+    Y, X = small.shape
+    stiles = driver.tile_list(small, T, T)
+    assert [t[:3] for t in stiles] == [(k, i // 5, j // 5) for k, i, j, _ in tiles]        # same tile structure
+    # single process: one rank owns every tile
+    yy, xx = np.meshgrid(np.arange(Y, dtype=np.float32), np.arange(X, dtype=np.float32), indexing="ij")
+    a1 = driver.assign_tiles(stiles, 1)
+    buf = torch.full((len(stiles), 4, 12, T, T), float(driver.FILL_F4), dtype=torch.float32)
+    truth = np.stack([np.stack([(q * 100 + m) + yy * 0.001 + xx * 1e-6 for m in range(12)]) for q in range(4)]).astype(np.float32)
+    for s, (_, i, j, _) in enumerate(a1[0]):
+        buf[s] = torch.from_numpy(truth[:, :, i:i + T, j:j + T])
+    want = driver.gather_mosaic_device(buf, a1, (Y, X), T, T, 0, 1)
+    covered = np.zeros((Y, X), bool)
+    for _, i, j, _ in stiles:
+        covered[i:i + T, j:j + T] = True
+    assert covered.any() and (~covered).any()
+    for q, key in enumerate(driver.NORMAL_KEYS):
+        assert np.array_equal(got[key], want[key].numpy()), key
+        assert np.array_equal(got[key][:, covered], truth[q][:, covered]) and np.all(got[key][:, ~covered] == driver.FILL_F4)

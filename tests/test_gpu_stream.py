@@ -40,10 +40,10 @@ def test_tile_stream_equals_synchronous_entry(golden_case):
     assert np.all(got[3]["status"] == -1) and np.all(got[3]["daily_tmin"] == _lib.FILL_I2)      # the fully masked tile
 
 
-@pytest.mark.parametrize("nclust,expect_range", [(1500, False), (6000, True)])
+@pytest.mark.parametrize("nclust,expect_range", [(1500, False), (6000, False), (14000, True)])
 def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
     """A cluster of stations far denser than the tile size: the candidate lists of its tiles outgrow the 512-slot LDS
-    path.  Up to 2 048 candidates the full-list kernel ranks them (results = oracle, which searches all stations);
+    path.  Up to 4 096 candidates the full-list kernel ranks them (results = oracle, which searches all stations);
     beyond that the cells fail with TWX_CELL_CAND_OVERFLOW instead of using a truncated list."""
     from topowx_amd import _lib, stationdb as sdb, synth
     grid, tmin, _ = golden_case

@@ -4,6 +4,7 @@
 import datetime as dt
 
 import numpy as np
+import pytest
 from scipy.io import netcdf_file
 
 from topowx_amd import ncio, synth
@@ -98,3 +99,42 @@ def test_station_db_roundtrip(tmp_path):
     assert ds.variables[sdb.STN_ID].dimensions[1].startswith("string")
     assert ds.variables["tmin"].dimensions == ("time", sdb.STN_ID)
     ds.close()
+
+
+def test_path_taking_constructors_and_field_coverage(tmp_path, capsys):
+    """``StationDataWrkChk(path, 'tmin')`` / ``StationSerialDataDb(path, 'tmin')`` exactly as the reference constructs
+    them (step25:53-54, optimize.py:229-234), on a NetCDF-3 database written by ``write_station_db``: every field
+    ``_build_stn_struct`` / ``StationSerialDataDb.__init__`` read (station_data.py:126-183,554-616) survives."""
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 2, 28))
+    grid = synth.make_grid("C1", nrows=20, ncols=20)
+    db = synth.make_stations(grid["bbox"], 80, 5, "tmax", days, with_obs=True)
+    db.stns[sdb.BAD][3] = 1.0
+    p = str(tmp_path / "serial_tmax.nc")
+    ncio.write_station_db(p, db)
+    for cls in (sdb.StationDataWrkChk, sdb.StationSerialDataDb):
+        a = cls(p, "tmax")
+        assert type(a) is cls and a.var_name == "tmax" and a.var.dtype == np.float32
+        want_fields = [sdb.LON, sdb.LAT, sdb.ELEV, sdb.TDI, sdb.MASK, sdb.BAD, sdb.CLIMDIV] + [
+            namer(m) for _, namer in sdb.MONTHLY_FIELDS for m in range(1, 13)]
+        assert len(want_fields) == 7 + 7 * 12
+        for f in want_fields:
+            np.testing.assert_array_equal(a.stns[f], db.stns[f])              # NaN (masked) entries included
+        np.testing.assert_array_equal(a.stn_ids, db.stn_ids)
+        np.testing.assert_array_equal(a.var, db.var)
+        np.testing.assert_array_equal(a.days.YMD, db.days.YMD)
+        assert a.stn_idxs[db.stn_ids[7]] == 7 and set(a.mth_idx) == set(db.mth_idx)
+    # pathlib paths, missing files, and a container that is not classic netCDF
+    import pathlib
+    assert sdb.StationDataWrkChk(pathlib.Path(p), "tmax").stns.size == 80
+    with pytest.raises(IOError, match="no such station database"):
+        sdb.StationDataWrkChk(str(tmp_path / "nope.nc"), "tmax")
+    h5 = tmp_path / "fake_hdf5.nc"
+    h5.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(IOError, match="convert-help"):
+        sdb.StationSerialDataDb(str(h5), "tmax")
+    # the command line: conversion recipe and a check of a converted file
+    assert ncio.main(["--convert-help"]) == 0
+    out = capsys.readouterr().out
+    assert "nccopy -k 64-bit-offset" in out and "string16" in out and "station_data.py" in out
+    assert ncio.main(["--check", p, "tmax"]) == 0
+    assert "missing fields: none" in capsys.readouterr().out

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
 #define TWX_SEL_GA 4
 #define TWX_SEL_GB 1
 #endif
-#define TWX_CAND_MAX 2048    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS)
+#define TWX_CAND_MAX 4096    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS; round 3: 2 048)
 struct SmoothOut { int status; int k; };
 
 // v with lane L (wave-uniform index) replaced by the wave-uniform value x; lane L of v as a uniform value.  An fp64

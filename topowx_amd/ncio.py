@@ -18,7 +18,7 @@ from scipy.io import netcdf_file
 from . import stationdb as sdb
 from .dates import DAY, MONTH, YEAR, get_days_metadata
 
-__all__ = ["TileWriter", "read_tile", "write_station_db", "read_station_db", "read_tile_stores",
+__all__ = ["TileWriter", "read_tile", "write_station_db", "read_station_db", "read_station_db_arrays", "read_tile_stores", "CONVERT_HELP",
            "climdiv_optim_nstns_path", "write_climdiv_optim_nstns_db", "read_climdiv_optim_nstns_db"]
 
 FILL_I2 = np.int16(-32767)
@@ -242,8 +242,22 @@ def write_station_db(path, stn_da):
 
 
 def read_station_db(path, var_name, cls=None):
-    """``StationSerialDataDb(nc_path, var_name)`` (station_data.py:554-616) on a classic netCDF file."""
+    """``StationSerialDataDb(nc_path, var_name)`` (station_data.py:554-616) on a classic netCDF file (the constructors
+    of ``stationdb`` take the path themselves: ``StationDataWrkChk(path, 'tmin')`` as in step25:53-54)."""
     cls = sdb.StationSerialDataDb if cls is None else cls
+    return cls(*read_station_db_arrays(path, var_name))
+
+
+def read_station_db_arrays(path, var_name):
+    """(stns, var_name, days, obs) of a classic-netCDF station database: what ``_build_stn_struct`` and
+    ``StationSerialDataDb.__init__`` read (station_data.py:126-183,554-616)."""
+    if not os.path.exists(path):
+        raise IOError("no such station database: %s" % path)
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+    if magic[:3] != b"CDF":
+        raise IOError("%s is not a classic / 64-bit-offset netCDF file (magic %r): a NetCDF-4 / HDF5 database must be "
+                      "converted once -- python -m topowx_amd.ncio --convert-help" % (path, magic))
     ds = netcdf_file(path, "r", mmap=False)
     try:
         tv = ds.variables["time"]
@@ -274,7 +288,7 @@ def read_station_db(path, var_name, cls=None):
         obs = np.asarray(ds.variables[var_name][:], np.float32).copy() if var_name in ds.variables else None
     finally:
         ds.close()
-    return cls(stns, var_name, days, obs)
+    return stns, var_name, days, obs
 
 
 # ---- per-climate-division cross-validation MAE files (optimize.py:39-82, step21:66-128) ------------------
@@ -342,3 +356,68 @@ def read_climdiv_optim_nstns_db(fpath):
     finally:
         ds.close()
     return mae, nghs, ids
+
+
+# ---- NetCDF-4 / HDF5 databases -------------------------------------------------------------------------------------------
+CONVERT_HELP = """\
+Converting a TopoWx station database (NetCDF-4 / HDF5) for topowx_amd
+====================================================================
+topowx_amd.ncio reads and writes the reference's layouts (station_data.py:126-183,547-616; tiling.py:304-537) as
+classic netCDF (NetCDF-3, 64-bit offset) through scipy.io.netcdf_file: this image has neither netCDF4-python nor
+h5py, and an HDF5 layer is out of scope (DESIGN.md section 7).  A serially-complete TopoWx database written by the
+reference (create_db_all_stations.py / infill: NetCDF-4, zlib-chunked, variable-length string ids) is converted ONCE,
+on any machine that has the netCDF tools:
+
+1. station ids: NetCDF-3 has no string type.  Rewrite the variable-length string variable `station_id(station_id)`
+   as a fixed-width char array `station_id(station_id, string16)` -- with NCO:
+
+       ncap2 -O -s 'sid_chr[$station_id,$string16]=" "; ' in.nc tmp.nc      # or, simpler, with Python + netCDF4:
+
+       import netCDF4, numpy as np
+       src = netCDF4.Dataset("in.nc"); dst = netCDF4.Dataset("tmp.nc", "w", format="NETCDF4_CLASSIC")
+       ids = np.array(src.variables["station_id"][:], "S16")
+       for name, d in src.dimensions.items(): dst.createDimension(name, None if d.isunlimited() else len(d))
+       dst.createDimension("string16", 16)
+       dst.createVariable("station_id", "S1", ("station_id", "string16"))[:] = netCDF4.stringtochar(ids)
+       for name, v in src.variables.items():
+           if name == "station_id" or v.dtype == str: continue          # other string columns (names, states) are not read
+           o = dst.createVariable(name, v.dtype, v.dimensions, fill_value=getattr(v, "_FillValue", None))
+           o.setncatts({k: v.getncattr(k) for k in v.ncattrs() if k != "_FillValue"}); o[:] = v[:]
+       dst.close()
+
+2. container:  nccopy -k 64-bit-offset tmp.nc stns_tmin.nc
+   (removes chunking / zlib; `nccopy -k classic` also works below 2 GiB per variable).
+
+What must survive the conversion (everything _build_stn_struct and StationSerialDataDb.__init__ read):
+  * dimension `station_id`, `time` (daily, gap-free; units "days since YYYY-MM-DD ...")
+  * every numeric variable shaped (station_id,): longitude, latitude, elevation, tdi, mask, bad, climdiv, and for
+    MM = 01..12: lstMM, normMM, optim_nnghsMM, optim_nnghs_anomMM, vario_nugMM, vario_psillMM, vario_rngMM -- with
+    their _FillValue / missing_value attributes (masked entries are read back as NaN, station_data.py:159-164)
+  * the observation variable tmin / tmax shaped (time, station_id), float32
+
+Then:  StationDataWrkChk("stns_tmin.nc", "tmin")   # step25:53-54, unchanged call site
+Check: python -m topowx_amd.ncio --check stns_tmin.nc tmin
+"""
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m topowx_amd.ncio", description="classic-netCDF containers of topowx_amd")
+    ap.add_argument("--convert-help", action="store_true", help="how to convert a NetCDF-4 / HDF5 TopoWx database once")
+    ap.add_argument("--check", nargs=2, metavar=("PATH", "VAR"), help="open a station database and list what was read")
+    args = ap.parse_args(argv)
+    if args.convert_help or not args.check:
+        print(CONVERT_HELP)
+        return 0
+    da = sdb.StationSerialDataDb(args.check[0], args.check[1])
+    want = [sdb.LON, sdb.LAT, sdb.ELEV, sdb.TDI, sdb.MASK, sdb.BAD, sdb.CLIMDIV] + [
+        namer(m) for _, namer in sdb.MONTHLY_FIELDS for m in range(1, 13)]
+    missing = [f for f in want if f not in da.stns.dtype.names]
+    print("stations %d, days %d (%s .. %s), obs %s, fields %d, missing fields: %s" % (
+        da.stns.size, da.days.size, da.days["YMD"][0], da.days["YMD"][-1],
+        "none" if da.var is None else str(da.var.shape), len(da.stns.dtype.names), missing or "none"))
+    return 1 if missing else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -8,6 +8,8 @@ fields are the per-station netCDF variables (missing -> NaN,
 netCDF I/O is out of scope for the hot path; a database
 is built from arrays (``topowx_amd.synth``) or loaded from ``.npz``.
 """
+import os
+
 import numpy as np
 
 from .dates import build_mth_idx, get_days_metadata
@@ -80,7 +82,14 @@ class StationSerialDataDb(object):
     (obs columns come back in DB order, metadata in id order -- SURVEY.md a2).
     """
 
-    def __init__(self, stns, var_name, days=None, obs=None):
+    def __init__(self, stns, var_name, days=None, obs=None, mode="r"):
+        """``stns``: the structured station table -- or, as in the reference (``StationSerialDataDb(nc_path, var_name)``,
+        station_data.py:554; step25:53-54, optimize.py:229), the PATH of a station database, read through
+        ``topowx_amd.ncio`` (classic / 64-bit-offset netCDF; ``mode`` is accepted for call-site parity, the table
+        lives in memory and is written back with ``ncio.write_station_db``)."""
+        if isinstance(stns, (str, os.PathLike)):
+            from . import ncio
+            stns, _, days, obs = ncio.read_station_db_arrays(os.fspath(stns), var_name)
         stns = np.asarray(stns)
         ids = stns[STN_ID]
         if ids.size > 1 and not np.all(ids[1:] > ids[:-1]):
@@ -143,8 +152,8 @@ class StationDataWrkChk(StationSerialDataDb):
     the bounds; ``load_obs`` returns the same columns the reference would.
     """
 
-    def __init__(self, stns, var_name, days=None, obs=None):
-        StationSerialDataDb.__init__(self, stns, var_name, days, obs)
+    def __init__(self, stns, var_name, days=None, obs=None, mode="r"):
+        StationSerialDataDb.__init__(self, stns, var_name, days, obs, mode)      # (a path works here too: step25:53-54)
         self.chk_bnds = None
         self.chk_deg_buf = None
 

@@ -134,6 +134,33 @@ def make_grid(config="C1", nrows=None, ncols=None, lat_north=None, lon_west=None
                 bbox=(lat.min(), lat.max(), lon.min(), lon.max()))
 
 
+def make_mask(config="C3", nrows=None, ncols=None, lat_north=None, lon_west=None):
+    """The land mask ``make_grid(config, ..., full_mask=False)`` would carry, without the predictor planes (the tile
+    deal of the full configs[2] grid needs only this: 3250x7000 cells in ~2 s)."""
+    c = CONFIGS[config]
+    nrows = c[0] if nrows is None else nrows
+    ncols = c[1] if ncols is None else ncols
+    lat = (c[2] if lat_north is None else lat_north) - (np.arange(nrows) + 0.5) * CELL
+    lon = (c[3] if lon_west is None else lon_west) + (np.arange(ncols) + 0.5) * CELL
+    blob = np.empty((nrows, ncols))
+
+    def band(sl):
+        lon2, lat2 = np.meshgrid(lon, lat[sl])
+        blob[sl] = _fbm(lon2 * 0.35, lat2 * 0.35, 50 + 7)
+
+    nthr = 1 if nrows * ncols < (1 << 20) else min(16, os.cpu_count() or 1)
+    step = -(-nrows // (4 * nthr)) if nthr > 1 else nrows
+    bands = [slice(i, min(nrows, i + step)) for i in range(0, nrows, step)]
+    if nthr == 1:
+        for sl in bands:
+            band(sl)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(band, bands))
+    return (blob > np.quantile(blob[::8, ::8], 0.43)).astype(np.uint8)
+
+
 def _km(lon, lat):
     return np.stack([lon * 78.6, lat * 111.2], axis=-1)
 
