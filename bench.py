@@ -266,7 +266,7 @@ def daily_record(env, args, base, grid, g, d_ninv, d_stat, day0, day1, label, st
         "ms_per_step": el2 / steps * 1e3, "cell_days_per_step": cell_days, "cells_ok": ok2,
         "cells_with_fixed_days": int((ninv[d_stat.cpu().numpy() == 0] > 0).sum()),
         "timing_ms": tm, "setup_s": setup_s,
-        "daily_kernel": {"kernel": "k_tile_union + k_daily_tile (+ k_row_offsets, k_daily_ok, k_daily_tile_gather)", "ms_per_step": tm["daily_ms"],
+        "daily_kernel": {"kernel": "k_daily_tile (+ k_row_offsets, k_daily_ok, k_daily_tile_gather)", "ms_per_step": tm["daily_ms"],
                          "cell_days_per_s": cell_days / (tm["daily_ms"] * 1e-3),
                          "roofline": {"bound": "hbm", "achieved": dgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": dgbs / HBM_PEAK_GBS,
@@ -276,7 +276,7 @@ def daily_record(env, args, base, grid, g, d_ninv, d_stat, day0, day1, label, st
         "mean_nnghs": float(kan[kan > 0].mean()),
     }
     if traffic_bytes is not None:
-        # measured HBM bytes of the launches behind daily_ms + gwr_ms (k_tile_union, k_daily_tile, k_gwr_z, ...) per step
+        # measured HBM bytes of the launches behind daily_ms + gwr_ms (k_perm, k_tile_uidx, k_gwr_z_cell, k_daily_tile, ...) per step
         alg = ALG_BYTES_PER_CELL_DAY * cell_days
         rec["traffic"] = {"bytes_per_step": traffic_bytes, "algorithmic_bytes_per_step": alg, "ratio": traffic_bytes / alg,
                           "measured_in_this_run": False, "source": traffic_src}

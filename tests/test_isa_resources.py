@@ -24,7 +24,7 @@ EXPECT = {
     "k_uk<7, 2, 1>": (2, 64), "k_uk<10, 2, 1>": (1, 64),
     "k_tile_dist": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4>": (4, 0), "k_select<1>": (4, 0), "k_tile_cand": (4, 0),
-    "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_union": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
+    "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
     "k_daily_grid": (4, 0), "k_fix_cells": (4, 0),
 }
 LDS_PER_CU = 160 * 1024

@@ -12,7 +12,7 @@ out = sys.argv[1]
 p = glob.glob(os.path.join(out, "stats", "**", "s_kernel_stats.csv"), recursive=True)
 for r in csv.DictReader(open(p[0])):
     k = r["Name"].split("(")[0].replace("void ", "")
-    if k.startswith(("k_daily", "k_tile_union", "k_gwr", "k_fix", "k_row", "k_compact")):
+    if k.startswith(("k_daily", "k_tile_u", "k_perm", "k_gwr", "k_fix", "k_row", "k_compact")):
         print("%10.1f us x %3d  %s" % (float(r["AverageNs"]) / 1e3, int(r["Calls"]), k))
 d = json.loads(open(os.path.join(out, "bench_profiled.json")).read())
 print("daily: %.4g cell-days/s, %.2f ms per step" % (d["daily"]["value"], d["daily"]["ms_per_step"]), d["daily"]["timing_ms"])

@@ -31,16 +31,29 @@ __host__ __device__ __forceinline__ int64_t twx_zd_index(int64_t tm, int ci)
 __host__ __device__ __forceinline__ int twx_zd_row(int u) { return (u >> 4) * (TWX_DT_CPW * 16) + (u & 15); }
 
 struct GwrWs {
-    double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank
+    double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank (point mode, and the tile-months of grid mode that do
+                      // not go through a table: see zd)
     double *zc;       // [ncell][12]          pt_norm - sum_j z_j norm_j
     int32_t *gstat;   // [ncell]
     uint32_t *noff;   // [ncell][ksel] byte offset of each ranked neighbour's observation row (k_row_offsets)
-    // k_tile_union -> k_daily_tile: the stations the cells of an 8x8 tile use in a month, as rows of an LDS table
+    // EVERY daily sum runs in ONE order: ascending station index of the cell's neighbours -- the order of the reference
+    // (station_select.py:179-182 sorts the neighbours by station id; the database is id-sorted) and of a table walk
+    // (table rows are numbered in candidate-list order = ascending station index; a row the cell does not use carries
+    // weight 0 and fma(0, x, acc) = acc exactly).  Table path, gather paths, fixer and point entries therefore agree bit
+    // for bit: which path a tile-month takes does not show in the packed int16 output.
+    int32_t *perm;    // [ncell][ksel] the ranks 0 .. kp - 1 of a cell in ascending station-index order (k_perm)
+    int32_t *kp;      // [ncell] largest GWR bandwidth of the cell's months = entries of perm
+    // k_tile_uidx -> k_gwr_z_cell -> k_daily_tile: the stations the cells of an 8x8 tile use in a month, as rows of an LDS table
     int32_t *urow;    // [ntile][12][TWX_UROWS] station index of table row u
     int32_t *nurow;   // [ntile][12] rows in the table; -1 = more than TWX_UROWS (the tile-month gathers from global memory)
-    double *zd;       // [ntile][12][64 / CPW groups][14 chunks][CPW cells][16] the hat rows scattered to table-row order (0 for
+    uint16_t *uslot;  // [ntile][12][cmax] table row of the candidate at list position p (valid where a cell uses it)
+    double *zd;       // [ntile][12][64 / CPW groups][14 chunks][CPW cells][16] the hat rows in table-row order (0 for
                       // rows a cell does not use), laid out as k_daily_tile's waves read them: one wave = one group of CPW
-                      // cells, one chunk of 16 table rows at a time = CPW x 128 contiguous bytes (twx_zd_index)
+                      // cells, one chunk of 16 table rows at a time = CPW x 128 contiguous bytes (twx_zd_index).  Written
+                      // ONCE, by k_gwr_z_cell (scattered in LDS, stored coalesced): a hat row of a table tile-month never
+                      // exists in rank order in HBM
+    const int32_t *nurow2;  // the OTHER variable's nurow (table mode): a (tile, month) uses the tables only when both unions fit
+    int use_table;    // grid mode, both variables, 8x8 tiles, no gather flag: tile-months with both nurow >= 0 use zd, not z
 };
 
 // ---------------------------------------------------------------------------------
@@ -220,12 +233,15 @@ __global__ __launch_bounds__(256) void k_gwr_z(StnDev st, CellSrc src, SelWs ws,
 // as a'(X'W norm) from six more sums of pass 1, so pass 2 reads no station column at all.
 // Same arithmetic per sum as k_gwr_z (lane = neighbour r mod 16, row_shr reduction) -- the two kernels give the same
 // z bit for bit; zc differs in the last bits (a'v instead of sum z_j norm_j).
+// With GwrWs.use_table the hat rows of a tile-month that has a table leave this kernel in table-row order (GwrWs.zd).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelWs ws, GwrWs gw)
 {
     __shared__ double s_x[TWX_KSEL_MAX][4];
     __shared__ double s_d[TWX_KSEL_MAX];
     __shared__ int s_j[TWX_KSEL_MAX];
+    __shared__ uint16_t s_pos[TWX_KSEL_MAX];                 // position of the ranked neighbour in the tile's candidate list
+    __shared__ double s_z[12][TWX_UROWS];                    // the twelve hat rows in table-row order (use_table)
     __shared__ int s_first[4];                               // lowest rank at which static column q is non-zero
     const int t = threadIdx.x, tr = t & 15, m0 = t >> 4, lane = t & 63, row = lane >> 4;
     const int lci = xcd_contig(blockIdx.x, (int)ws.ncell);
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
         const int j = ws.near_idx[lc * ws.ksel + r];
         s_j[r] = j;
         s_d[r] = ws.near_dist[lc * ws.ksel + r];
+        if (gw.use_table) s_pos[r] = ws.near_pos[lc * ws.ksel + r];
         if (r < kamax) {
             const double4 sr = st.stat_s[j];
             const double raw[4] = {sr.x, sr.y, sr.z, sr.w};
@@ -335,7 +352,26 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
         for (int p = i + 1; p < 6; ++p) s -= M[p][i] * a[p];
         a[i] = s * inv[i];
     }
+    // Where the hat row goes: a tile-month with a table (k_tile_uidx: nurow >= 0) gets it in TABLE-ROW order --
+    // scattered in LDS (zeros where the cell does not use a row, up to the next multiple of 16 rows), then stored once,
+    // coalesced, in the layout k_daily_tile's waves read (GwrWs.zd); any other in rank order (gw.z).
     double *zout = gw.z + (lc * 12 + m0) * TWX_KZ;
+    int nu = -1;
+    int64_t tm = 0;
+    int ci = 0;
+    if (gw.use_table) {
+        const int rr = (int)(c / src.X), qq = (int)(c % src.X);
+        const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - ws.tile0;
+        tm = tl * 12 + m0;
+        ci = (rr % src.ts) * src.ts + (qq % src.ts);
+        nu = gw.nurow2[tm] >= 0 ? gw.nurow[tm] : -1;
+    }
+    const bool tab = nu >= 0;                                // (uniform within the 16-lane row of a month)
+    const int nu16 = (nu + 15) & ~15;
+    const uint16_t *uslot = gw.uslot + tm * (int64_t)ws.cmax;
+    if (tab)
+        for (int u = tr; u < nu16; u += 16) s_z[m0][u] = 0.0;
+    __builtin_amdgcn_wave_barrier();                         // (LDS operations of one wave execute in order)
 #pragma unroll
     for (int s = 0; s < TWX_GZ_SLOTS; ++s) {
         if (s < nslot) {
@@ -346,10 +382,16 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
                 tt = fma(a[3], s_x[r][2], tt); tt = fma(a[4], s_x[r][3], tt);
                 tt = fma(a[5], xl[s], tt);
                 const double z = w[s] * tt;
-                zout[r] = z;
+                if (tab) s_z[m0][uslot[s_pos[r]]] = z;
+                else zout[r] = z;
                 if (!finite_d(z)) bad = true;
             }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (tab && ka > 0) {
+        double *zd = gw.zd + twx_zd_index(tm, ci);
+        for (int u = tr; u < nu16; u += 16) zd[twx_zd_row(u)] = s_z[m0][u];
     }
     double zn = 0.0;
 #pragma unroll
@@ -362,22 +404,28 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
     }
 }
 
-// value of one (cell, month-major day): sum_r z_r * obs[idx_r][dm] + zc, fixed
-// summation order (rank order, fma chain) so every kernel reproduces it bit for bit
+// value of one (cell, month-major day): sum_j z_j * obs[j][dm] + zc over the cell's neighbours in ASCENDING STATION
+// INDEX order (GwrWs.perm; see GwrWs), one fma chain: every kernel reproduces it bit for bit.  A rank outside the
+// month's bandwidth takes weight 0 (its observation is finite, so the term adds exactly nothing).
 __device__ __forceinline__ double daily_value(const StnDev &st, const SelWs &ws, const GwrWs &gw,
                                               int64_t lc, int m0, int ka, int ndays, int dm)
 {
     const double *z = gw.z + (lc * 12 + m0) * TWX_KZ;
     const int32_t *ni = ws.near_idx + lc * ws.ksel;
+    const int32_t *pm = gw.perm + lc * ws.ksel;
+    const int kp = gw.kp[lc];
     double acc = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < ka; ++r)
-        acc = fma(z[r], (double)st.obs[(size_t)ni[r] * ndays + dm], acc);
+#pragma unroll 4
+    for (int q = 0; q < kp; ++q) {
+        const int r = pm[q];
+        const double zr = r < ka ? z[r] : 0.0;
+        acc = fma(zr, (double)st.obs[(size_t)ni[r] * ndays + dm], acc);
+    }
     return acc + gw.zc[lc * 12 + m0];
 }
 
-// Tmin and Tmax of one (cell, month-major day) together: the two fma chains are independent, so twice as many
-// observation loads are in flight; each chain keeps daily_value's order, bit for bit.  When the observation
+// Tmin and Tmax of one (cell, month-major day) together (the gather kernels: cell wave-uniform, so perm, hat rows and
+// row offsets come through scalar loads; lanes = days).  Same order, same bits as daily_value.  When the observation
 // matrix is smaller than 4 GiB (OFF32) the element address is base + a 32-bit byte offset: the neighbours' row
 // offsets are precomputed per cell (k_row_offsets), so a step is one add, the load, one convert and the fma.
 template <bool OFF32>
@@ -388,6 +436,8 @@ __device__ __forceinline__ void daily_value2(const StnDev &sn, const SelWs &wn, 
     const int kn = wn.ka[lc * 12 + m0], kx = wx.ka[lc * 12 + m0];
     const double *zn = gn.z + (lc * 12 + m0) * TWX_KZ, *zx = gx.z + (lc * 12 + m0) * TWX_KZ;
     const int32_t *nn = wn.near_idx + lc * wn.ksel, *nx = wx.near_idx + lc * wx.ksel;
+    const int32_t *pn = gn.perm + lc * wn.ksel, *px = gx.perm + lc * wx.ksel;
+    const int kpn = gn.kp[lc], kpx = gx.kp[lc];
     const float *on = sn.obs + dm, *ox = sx.obs + dm;
     const char *bn = reinterpret_cast<const char *>(sn.obs), *bx = reinterpret_cast<const char *>(sx.obs);
     const uint32_t *fn = gn.noff + lc * wn.ksel, *fx = gx.noff + lc * wx.ksel;   // byte offsets of the neighbours' rows
@@ -401,17 +451,18 @@ __device__ __forceinline__ void daily_value2(const StnDev &sn, const SelWs &wn, 
         return ox[(size_t)nx[r] * ndays];
     };
     double an = 0.0, ax = 0.0;
-    const int kc = min(kn, kx);
-    int r = 0;
-#pragma unroll 8
-    for (; r < kc; ++r) {
-        an = fma(zn[r], (double)ldn(r), an);
-        ax = fma(zx[r], (double)ldx(r), ax);
+    const int kc = min(kpn, kpx);
+    int q = 0;
+#pragma unroll 4
+    for (; q < kc; ++q) {                                    // the two chains are independent: twice the loads in flight
+        const int rn = pn[q], rx = px[q];
+        an = fma(rn < kn ? zn[rn] : 0.0, (double)ldn(rn), an);
+        ax = fma(rx < kx ? zx[rx] : 0.0, (double)ldx(rx), ax);
     }
 #pragma unroll 4
-    for (int q = r; q < kn; ++q) an = fma(zn[q], (double)ldn(q), an);
+    for (int t = q; t < kpn; ++t) { const int r = pn[t]; an = fma(r < kn ? zn[r] : 0.0, (double)ldn(r), an); }
 #pragma unroll 4
-    for (int q = r; q < kx; ++q) ax = fma(zx[q], (double)ldx(q), ax);
+    for (int t = q; t < kpx; ++t) { const int r = px[t]; ax = fma(r < kx ? zx[r] : 0.0, (double)ldx(r), ax); }
     vn = an + gn.zc[lc * 12 + m0];
     vx = ax + gx.zc[lc * 12 + m0];
 }
@@ -517,17 +568,45 @@ __global__ void k_row_offsets(SelWs ws, GwrWs gw, int ndays)
     gw.noff[i] = j < 0 ? 0u : (uint32_t)j * (uint32_t)ndays * 4u;
 }
 
+// k_perm: one wave per cell.  perm = the ranks 0 .. kp - 1 (kp = the largest GWR bandwidth of the cell's months) in
+// ascending station-index order -- the one order every daily sum runs in (GwrWs).  Rank by counting: position of rank
+// r = number of ranks with a smaller station index (indices are distinct).
+__global__ __launch_bounds__(256) void k_perm(SelWs ws, GwrWs gw)
+{
+    __shared__ int s_idx[4][TWX_KSEL_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t lc = (int64_t)blockIdx.x * 4 + wv;
+    if (lc >= ws.ncell) return;
+    int kp = 0;
+    if (ws.cstat[lc] == 0) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) kp = max(kp, ws.ka[lc * 12 + m]);
+    }
+    kp = min(kp, ws.ksel);
+    if (lane == 0) gw.kp[lc] = kp;
+    int *idx = s_idx[wv];
+    for (int r = lane; r < kp; r += 64) idx[r] = ws.near_idx[lc * ws.ksel + r];
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < kp; r += 64) {
+        const int mine = idx[r];
+        int pos = 0;
+        for (int q = 0; q < kp; ++q) pos += idx[q] < mine ? 1 : 0;
+        gw.perm[lc * ws.ksel + pos] = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------
-// k_tile_union: one work-group per (8x8-cell tile, month).  The GWR neighbourhoods of a tile's cells overlap
-// almost completely: mark the candidates (positions in the tile's candidate list, k_select) that any cell of
-// the tile uses this month, number them, and give every (cell, rank) the byte offset of its station's row in a
-// table of 64-day f4 rows -- k_daily_tile stages that table in LDS once per 64 days instead of gathering every
-// (cell, neighbour) row through the vector L1.
+// k_tile_uidx: one work-group per (8x8-cell tile, month), BEFORE the hat rows are computed.  The GWR neighbourhoods of
+// a tile's cells overlap almost completely: mark the candidates (positions in the tile's candidate list, k_select)
+// that any cell of the tile uses this month and number them in list order (= ascending station index) -- the rows of
+// the tile-month's table of 64-day f4 observation rows that k_daily_tile stages in LDS.  Outputs: urow (station of a
+// row), nurow, and uslot (row of a candidate position), which k_gwr_z_cell uses to deliver every hat row directly
+// in table order.  (Rounds 2-3: k_tile_union ran after the hat rows, re-read them in rank order (0.43 GB per variable
+// and 10-year step) and wrote them again in table order.)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs gw)
+__global__ __launch_bounds__(256) void k_tile_uidx(CellSrc src, SelWs ws, GwrWs gw)
 {
     __shared__ uint16_t s_slot[TWX_CAND_MAX];
-    __shared__ double s_zrow[4][TWX_UROWS];
     __shared__ int s_cnt[4], s_base;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t tl = blockIdx.x / 12;                  // local tile
@@ -539,19 +618,19 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
     for (int p = t; p < ncand; p += 256) s_slot[p] = 0;
     if (t == 0) s_base = 0;
     __syncthreads();
-    // mark: thread pairs (cell, rank)
+    // mark: a wave per cell, lanes over ranks (a cell whose kriging / GWR fails later only adds rows nobody reads)
     const int ncl = src.ts * src.ts;                     // cells per tile (<= 64)
     for (int ci = wv; ci < ncl; ci += 4) {
         const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
         if (rr >= src.Y || qq >= src.X) continue;
         const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
-        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
+        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0) continue;
         const int ka = ws.ka[lc * 12 + m0];
         for (int r = lane; r < ka; r += 64) s_slot[ws.near_pos[lc * ws.ksel + r]] = 1;
     }
     __syncthreads();
     // number the used candidates in list order (= ascending station index)
-    int nu = 0;
+    uint16_t *uslot = gw.uslot + (tl * 12 + m0) * (int64_t)ws.cmax;
     for (int p0 = 0; p0 < ncand; p0 += 256) {
         const int p = p0 + t;
         const bool f = p < ncand && s_slot[p] != 0;
@@ -563,41 +642,19 @@ __global__ __launch_bounds__(256) void k_tile_union(CellSrc src, SelWs ws, GwrWs
         for (int w = 0; w < wv; ++w) off += s_cnt[w];
         if (f) {
             const int u = off + pre;
-            s_slot[p] = (uint16_t)u;
+            uslot[p] = (uint16_t)u;
             if (u < TWX_UROWS) gw.urow[(tl * 12 + m0) * TWX_UROWS + u] = ws.cand[tl * ws.cmax + p];
         }
         __syncthreads();
         if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         __syncthreads();
     }
-    nu = s_base;
-    if (t == 0) gw.nurow[tl * 12 + m0] = nu <= TWX_UROWS ? nu : -1;
-    if (nu > TWX_UROWS) return;
-    for (int ci = wv; ci < ncl; ci += 4) {
-        const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
-        if (rr >= src.Y || qq >= src.X) continue;
-        const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
-        if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0 || ws.uk_stat[lc] != 0 || gw.gstat[lc] != 0) continue;
-        const int ka = ws.ka[lc * 12 + m0];
-        // the hat row in table-row order, zero where the cell does not use the row (k_daily_tile walks the TABLE, eight
-        // cells at a time): rows up to the next multiple of 16.  Scattered in LDS, written ONCE and coalesced (zero-filling
-        // global memory and scattering into it wrote every used entry twice, the second time as partial lines)
-        double *zrow = s_zrow[wv];
-        const int nu16 = (nu + 15) & ~15;
-        for (int u = lane; u < nu16; u += 64) zrow[u] = 0.0;
-        __builtin_amdgcn_wave_barrier();                     // (LDS operations of one wave execute in order)
-        for (int r = lane; r < ka; r += 64)
-            zrow[s_slot[ws.near_pos[lc * ws.ksel + r]]] = gw.z[(lc * 12 + m0) * TWX_KZ + r];
-        __builtin_amdgcn_wave_barrier();
-        double *zd = gw.zd + twx_zd_index(tl * 12 + m0, ci);
-        for (int u = lane; u < nu16; u += 64) zd[twx_zd_row(u)] = zrow[u];
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (t == 0) gw.nurow[tl * 12 + m0] = s_base <= TWX_UROWS ? s_base : -1;
 }
 
 // ---------------------------------------------------------------------------------
 // k_daily_tile: (8x8-cell tile) x (month) x (64 month-major days), both variables.  Per variable: the tile-month's
-// station rows (k_tile_union) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave takes
+// station rows (k_tile_uidx) x 64 days are staged in LDS (f4, 256 B per row, coalesced loads), then every wave takes
 // TWX_DT_CPW = 8 cells, lane = day, and walks the TABLE: each row is read from LDS (conflict-free ds_read_b32 with immediate
 // offsets, lanes = consecutive days) and converted once and feeds one fmac per cell, weighted with the cell's hat row in
 // table order (zero where the cell does not use the row; a DPP row broadcast) -- dt_value4.  Tmin values wait in
@@ -656,7 +713,7 @@ __device__ __forceinline__ void dt_fmac(double &acc, double z, double x)
 
 // The same sums for the TWX_DT_CPW cells of a wave at once, walking the table's rows instead of each cell's own list:
 // every row is read from LDS and converted once per wave (immediate offsets: no address arithmetic) and feeds one
-// fmac per cell, whose weight -- the cell's hat row scattered to table order by k_tile_union, zero where the cell does
+// fmac per cell, whose weight -- the cell's hat row delivered in table order by k_gwr_z_cell, zero where the cell does
 // not use the row -- is again a DPP row broadcast.  ~2 VALU instructions per useful term instead of 3.9 (1.1 per table
 // term with 8 cells per wave; the table has ~1.8 x the rows a cell uses); the terms are
 // added in table order, not in rank order (the sum differs from daily_value's in the last bits, far below the int16
@@ -918,7 +975,7 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
 
 // ---------------------------------------------------------------------------------
 // k_fix_cells: tmin_tmax_fixer + normals recompute (interp_tair.py:143-197,579-590)
-// for the cells flagged by k_daily_grid.  One workgroup per flagged cell
+// for the cells flagged by k_daily_tile / k_daily_tile_gather.  One workgroup per flagged cell
 // (grid-stride): recompute both fp64 series chronologically into scratch, list the
 // invalid days (before any fix), fix them sequentially in day order (earlier fixes
 // feed later windows), recompute the normals, repack the changed days.
@@ -1007,20 +1064,63 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
 {
     __shared__ int s_n, s_err;
     __shared__ double s_norm[24];
+    __shared__ double s_zl[2][TWX_UROWS];                    // per variable: the month's weights / stations, ascending station index
+    __shared__ int s_jl[2][TWX_UROWS];
+    __shared__ int s_nl[2];
     double *tmin = fa.scratch + (size_t)blockIdx.x * 2 * da.ndays;
     double *tmax = tmin + da.ndays;
     int32_t *list = fa.lists + (size_t)blockIdx.x * da.ndays;
     const int64_t yx = (int64_t)src.Y * src.X;
     const int ncells = *fa.ncells_dev;
+    const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
         const int64_t c = wn.cell0 + lc;
-        for (int dm = threadIdx.x; dm < da.ndays; dm += blockDim.x) {
-            int m0 = 0;
-            while (dm >= da.moff[m0 + 1]) ++m0;
-            int d = da.mm2chron[dm];
-            tmin[d] = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
-            tmax[d] = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
+        const int rr = (int)(c / src.X), qq = (int)(c % src.X);
+        const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
+        const int ci = (rr % src.ts) * src.ts + (qq % src.ts);
+        // Recompute both series with the bits k_daily_tile / the gather kernels produced: per month the cell's
+        // (weight, station) list in ascending station-index order -- from the tile-month's table (GwrWs.zd: the rows
+        // with a non-zero weight; a zero weight adds exactly nothing) or from the rank-ordered hat row through perm --
+        // then one fma chain per day.  Waves 0 / 1 build the Tmin / Tmax list, every thread takes days.
+        for (int m0 = 0; m0 < 12; ++m0) {
+            if (wvi < 2) {
+                const SelWs &w = wvi ? wx : wn;
+                const GwrWs &g = wvi ? gx : gn;
+                const int ka = w.ka[lc * 12 + m0];
+                const int64_t tm = tl * 12 + m0;
+                const int nu = (g.use_table && g.nurow2[tm] >= 0) ? g.nurow[tm] : -1;
+                const int nrow = nu >= 0 ? nu : g.kp[lc];
+                int n = 0;
+                for (int u0 = 0; u0 < nrow; u0 += 64) {
+                    const int u = u0 + lane;
+                    double z = 0.0;
+                    int j = 0;
+                    if (u < nrow) {
+                        if (nu >= 0) { z = g.zd[twx_zd_index(tm, ci) + twx_zd_row(u)]; j = g.urow[tm * TWX_UROWS + u]; }
+                        else { const int r = g.perm[lc * w.ksel + u]; z = r < ka ? g.z[(lc * 12 + m0) * TWX_KZ + r] : 0.0; j = w.near_idx[lc * w.ksel + r]; }
+                    }
+                    const bool f = z != 0.0;
+                    const unsigned long long b = __ballot(f);
+                    if (f) { const int p = n + __popcll(b & ((1ull << lane) - 1ull)); s_zl[wvi][p] = z; s_jl[wvi][p] = j; }
+                    n += __popcll(b);
+                }
+                if (lane == 0) s_nl[wvi] = n;
+            }
+            __syncthreads();
+            const int nn = s_nl[0], nx = s_nl[1];
+            const double zcn = gn.zc[lc * 12 + m0], zcx = gx.zc[lc * 12 + m0];
+            for (int dm = da.moff[m0] + threadIdx.x; dm < da.moff[m0 + 1]; dm += blockDim.x) {
+                double an = 0.0, ax = 0.0;
+#pragma unroll 4
+                for (int i = 0; i < nn; ++i) an = fma(s_zl[0][i], (double)stn.obs[(size_t)s_jl[0][i] * da.ndays + dm], an);
+#pragma unroll 4
+                for (int i = 0; i < nx; ++i) ax = fma(s_zl[1][i], (double)stx.obs[(size_t)s_jl[1][i] * da.ndays + dm], ax);
+                const int d = da.mm2chron[dm];
+                tmin[d] = an + zcn;
+                tmax[d] = ax + zcx;
+            }
+            __syncthreads();
         }
         __syncthreads();
         fix_series_block(tmin, tmax, list, da, &s_n, &s_err, s_norm);

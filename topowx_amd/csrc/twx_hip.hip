@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, hminp, noff, near_pos, urow,
-        nurow, zd;
+        nurow, zd, perm, kp, uslot;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
@@ -59,7 +59,7 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &hminp, &noff,
-                          &near_pos, &urow, &nurow, &zd})
+                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot})
             b->release();
     }
 };
@@ -189,12 +189,15 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
         HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
+        HIPCHK(w.perm.ensure((size_t)ncell * ksel * 4));     // ranks in ascending station-index order (k_perm)
+        HIPCHK(w.kp.ensure((size_t)ncell * 4));
     }
-    if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_union)
-    if (tile_tab) {      // grid mode with daily output: k_tile_union / k_daily_tile
+    if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_uidx, k_gwr_z_cell)
+    if (tile_tab) {      // grid mode with daily output: k_tile_uidx / k_gwr_z_cell / k_daily_tile
         HIPCHK(w.zd.ensure((size_t)ntile * 12 * 64 * TWX_UROWS * 8));   // per tile: 64 cell slots x 224 rows, wave layout
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
+        HIPCHK(w.uslot.ensure((size_t)ntile * 12 * w.cmax * 2));
     }
     if (fit_vario) {
         HIPCHK(w.uk_beta.ensure((size_t)ncell * 12 * 5 * 8));
@@ -220,6 +223,9 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
+    w.gw.perm = w.perm.as<int32_t>(); w.gw.kp = w.kp.as<int32_t>();
+    w.gw.uslot = tile_tab ? w.uslot.as<uint16_t>() : nullptr;
+    w.gw.nurow2 = nullptr; w.gw.use_table = 0;                           // (twx_interp_grid_dev switches it on: both variables, 8x8 tiles, no gather flag)
     s.near_pos = grid ? w.near_pos.as<uint16_t>() : nullptr;
     w.gw.zd = tile_tab ? w.zd.as<double>() : nullptr;
     w.gw.urow = tile_tab ? w.urow.as<int32_t>() : nullptr;
@@ -385,10 +391,23 @@ int pick_ksel(const twx_ctx *ctx, int v, int kextra)
     return std::min(k, TWX_KSEL_MAX);
 }
 
-int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, hipStream_t stream)
+// before the hat rows: the one order of every daily sum (k_perm) and, in table mode, which rows the tables of the
+// (tile, month)s hold (k_tile_uidx) -- the hat rows are then delivered in that order
+int run_gwr_prep(twx_ctx *ctx, int v, const CellSrc &src, hipStream_t stream)
+{
+    Work &w = ctx->work[v];
+    EvScope ev(ctx, stream, EV_GWR);
+    hipLaunchKernelGGL(k_perm, dim3((unsigned)((w.ws.ncell + 3) / 4)), dim3(256), 0, stream, w.ws, w.gw);
+    if (w.gw.use_table)
+        hipLaunchKernelGGL(k_tile_uidx, dim3((unsigned)(w.ws.ntile * 12)), dim3(256), 0, stream, src, w.ws, w.gw);
+    return 0;
+}
+
+int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, hipStream_t stream, bool prep = true)
 {
     Work &w = ctx->work[v];
     HIPCHK(hipMemsetAsync(w.gstat.p, 0, (size_t)w.ws.ncell * 4, stream));
+    if (prep && run_gwr_prep(ctx, v, src, stream)) return -1;
     EvScope ev(ctx, stream, EV_GWR);
     int64_t items = w.ws.ncell * 12;
     if (src.mode == 0 && !pt_norm_dev)       // grid: one work-group per cell, the month-independent columns staged once
@@ -1124,6 +1143,9 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
     const int Y = g->Y, X = g->X;
     const int ntx = (X + ts - 1) / ts;
     int64_t batch = ctx->p.batch_cells > 0 ? ctx->p.batch_cells : (daily ? TWX_DAILY_BATCH : 131072);
+    // both variables on 8x8 tiles: the daily sums walk per-(tile, month) tables of observation rows staged in LDS
+    // (k_daily_tile), and the hat rows are produced in table-row order; the gather flags switch the tables off
+    const bool use_table = daily && has_n && has_x && ts * ts <= 64 && !(ctx->p.flags & (TWX_FLAG_OBS_ADDR64 | TWX_FLAG_DAILY_GATHER));
     int band = (int)std::max<int64_t>(ts, batch / X / ts * ts);
     ctx->ev_used = 0; ctx->t_cells = 0;
     // outputs start at the netCDF fill values the reference's worker pre-fills with (step25:68-88): failed and
@@ -1156,7 +1178,18 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             s.lst = v == 0 ? g->lst_night : g->lst_day;
             s.do_krig = 1; s.do_anom = daily ? 1 : 0; s.do_vario = 1;
             if (run_select_uk(ctx, v, s, cell0, ncell, tile0, ntile, pick_ksel(ctx, v, 0), daily, stream)) return -1;
-            if (daily && run_gwr(ctx, v, s, nullptr, stream)) return -1;
+            ctx->work[v].gw.use_table = use_table ? 1 : 0;
+        }
+        if (daily) {
+            // both variables' tables are numbered before any hat row is computed: a (tile, month) goes through the
+            // tables only when BOTH unions fit (k_daily_tile takes both variables of a block or neither)
+            for (int v = 0; v < 2; ++v)
+                if ((v == 0 ? has_n : has_x) && run_gwr_prep(ctx, v, src[v], stream)) return -1;
+            for (int v = 0; v < 2; ++v) {
+                if (!(v == 0 ? has_n : has_x)) continue;
+                ctx->work[v].gw.nurow2 = use_table ? ctx->work[1 - v].gw.nurow : nullptr;
+                if (run_gwr(ctx, v, src[v], nullptr, stream, false)) return -1;
+            }
         }
         const CellSrc &s0 = has_n ? src[0] : src[1];
         hipLaunchKernelGGL(k_finalize_grid, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, s0,
@@ -1184,9 +1217,6 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 const int addr64 = (ctx->p.flags & TWX_FLAG_OBS_ADDR64) ? 1 : 0;
                 if (has_n && has_x && ts * ts <= 64) {
                     // both variables: the tile kernel (observation rows of a tile-month staged in LDS)
-                    for (int v = 0; v < 2; ++v)
-                        hipLaunchKernelGGL(k_tile_union, dim3((unsigned)(ntile * 12)), dim3(256), 0, stream, s0, ctx->work[v].ws,
-                                           ctx->work[v].gw);
                     int32_t *d_okc = ctx->flag_list.as<int32_t>();      // free until k_compact_flags (which runs after)
                     hipLaunchKernelGGL(k_daily_ok, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, ctx->work[0].ws,
                                        ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, d_okc);
