@@ -85,12 +85,11 @@ typedef struct {
 #define TWX_FLAG_NO_HOST_SYNC 2
 /* daily values: gather every (cell, neighbour) observation row from global memory instead of staging the rows of a
  * tile-month in LDS (the path a tile-month with more than 224 distinct rows takes -- a test / diagnostic switch;
- * TWX_FLAG_OBS_ADDR64 implies it).  The two gather forms (32- / 64-bit addressing) and the fixer's recompute add a
- * cell-day's terms in neighbour-rank order and agree bit for bit; the default LDS-table path adds the same terms in
- * table (station-index) order, so its fp64 sums differ from theirs in the last bits: packed int16 values are identical
- * up to isolated +-1 LSB (a value within rounding distance of a 0.005 degC boundary), and a day with tmin within an
- * ulp of tmax can be flagged for the fixer by one path and not the other.  Which path a tile-month takes depends on
- * its station union (<= 224 rows: table), i.e. on tiling and station density.
+ * TWX_FLAG_OBS_ADDR64 implies it).  Every daily sum -- LDS-table walk, 32- / 64-bit gathers, single-variable requests,
+ * the fixer's recompute, the point entries -- adds a cell-day's terms in ONE order, ascending station index (the
+ * reference's neighbour order, station_select.py:179-182; a table row the cell does not use carries weight 0 and adds
+ * exactly nothing): all paths give the same bits, so which path a tile-month takes (its station union <= 224 rows, i.e.
+ * tiling and station density) does not show in any output (tests/test_gpu_configs.py).
  * Precondition of every daily path: observations are finite (the reference's database is serially complete,
  * station_data.py:547-616); twx_set_stations rejects a table whose obs hold NaN / Inf, because the table walk
  * multiplies every row of a tile-month by every cell's weight (0 for rows a cell does not use: 0 * NaN = NaN would

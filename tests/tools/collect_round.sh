@@ -7,5 +7,11 @@ bash tests/tools/collect_profiles.sh > gpurun_out/collect_profiles.log 2>&1
 python3 bench.py --steps 6 --warmup 2 --daily-years 69 --stream-tiles 4 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/prof_round/c4_stream_daily.json
 bash tests/tools/collect_sq.sh sq_krig > /dev/null 2>&1
 TWX_SQ_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-configs --stream-tiles 0" bash tests/tools/collect_sq.sh sq_daily > /dev/null 2>&1
-python3 -m topowx_amd.xval --nstns 10000 --years 3 > gpurun_out/prof_round/xval_10k.json 2> gpurun_out/xval.err
+python3 -m topowx_amd.xval --db c5 --nstns 12000 --years 3 > gpurun_out/prof_round/xval_c5.json 2> gpurun_out/xval.err
 ls gpurun_out/prof_round gpurun_out/sq_krig gpurun_out/sq_daily
+# round 4: ill-conditioned kriging systems -- error of the routed and of the fast-only build per (nugget, psill, range), and the
+# cost of the fp64 covariance build when EVERY system of the C2 tile takes it
+python3 tests/tools/gpu_closepair_scan.py > gpurun_out/prof_round/closepair_scan.log 2>&1
+python3 tests/tools/gpu_closepair_scan.py --fast-only > gpurun_out/prof_round/closepair_scan_fast.log 2>&1
+python3 tests/tools/gpu_f64_cost.py > gpurun_out/prof_round/f64_cost.log 2>&1
+cp gpurun_out/closepair_scan.json gpurun_out/closepair_scan_fast.json gpurun_out/f64_cost.json gpurun_out/prof_round/

@@ -15,6 +15,10 @@ cp $P/pmc_daily_FETCH_SIZE.csv profiles/${R}_daily_pmc_FETCH_SIZE.csv
 cp $P/pmc_daily_WRITE_SIZE.csv profiles/${R}_daily_pmc_WRITE_SIZE.csv
 cp $P/hbm_traffic.json profiles/${R}_bench_hbm_traffic.json
 cp $P/c4_stream_daily.json profiles/${R}_c4_stream_daily.json
-cp $P/xval_10k.json profiles/${R}_xval_10k.json
+cp $P/xval_c5.json profiles/${R}_xval_c5.json
 cp gpurun_out/sq_krig/sq_table.txt profiles/${R}_sq_counters_kriging.txt
 cp gpurun_out/sq_daily/sq_table.txt profiles/${R}_sq_counters_daily.txt
+cp $P/closepair_scan.json profiles/${R}_closepair_scan.json
+cp $P/closepair_scan_fast.json profiles/${R}_closepair_scan_fast_only.json
+cp $P/f64_cost.json profiles/${R}_f64_build_cost.json
+cp topowx_amd/libtwxhip.resources.txt profiles/${R}_isa_resources.txt
