@@ -148,6 +148,20 @@ __device__ __attribute__((noinline)) double ellip_far_f64(double Sd, double cc, 
     return 2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2);
 }
 
+// The same formula for S = sin^2(w) < 4e-3 (pairs closer than ~800 km: every neighbourhood of the path) without atan and
+// with one square root less: w = asin(sqrt S) = sqrt(S) P(S), P = the series of asin(x) / x in x^2 (terms through S^7:
+// truncation < 2e-19 relative), R = sqrt(S C) / w = sqrt(C) / P.  ~70 instructions instead of ~250.
+__device__ __forceinline__ double ellip_near_f64(double Sd, double cc, double sG2)
+{
+    const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
+    double P = 0.01396484375;
+    P = fma(P, Sd, 0.017352764423076924); P = fma(P, Sd, 0.022372159090909092); P = fma(P, Sd, 0.030381944444444444);
+    P = fma(P, Sd, 0.044642857142857144); P = fma(P, Sd, 0.075); P = fma(P, Sd, 0.16666666666666666); P = fma(P, Sd, 1.0);
+    const double R = sqrt(Cd) / P;
+    const double H1 = (3 * R - 1) / (2 * Cd), H2 = (3 * R + 1) / (2 * Sd);
+    return (2 * TWX_WGS84_A) * (sqrt(Sd) * P) * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2);
+}
+
 // a, b: {sin, cos of the half latitude, sin, cos of the half longitude, cos(latitude)}
 __device__ __forceinline__ double ellip_pair_f64(const double *a, const double *b)
 {
@@ -158,14 +172,31 @@ __device__ __forceinline__ double ellip_pair_f64(const double *a, const double *
     const double sG2 = sG * sG, sL2 = sL * sL;
     const double Sd = fma(cc, sL2, sG2);
     if (!(Sd > 0.0)) return 0.0;
+    if (Sd < 4e-3) return ellip_near_f64(Sd, cc, sG2);
     return ellip_far_f64(Sd, cc, sG2);
+}
+
+// exp(x) for x <= 0 in fp64 (relative error ~2e-16): x = n ln 2 + r, |r| <= ln 2 / 2, degree-12 Taylor polynomial, ldexp
+// (the library exp is a call of ~60 instructions; the fp64 build evaluates one per matrix element)
+__device__ __forceinline__ double exp_neg_f64(double x)
+{
+    if (!(x > -700.0)) return 0.0;
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;                   // 1 / 12!
+    p = fma(p, r, 2.50521083854417187751e-08); p = fma(p, r, 2.75573192239858906526e-07); p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05); p = fma(p, r, 1.98412698412698412698e-04); p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03); p = fma(p, r, 4.16666666666666666667e-02); p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
 }
 
 // psill exp(-h / range) with ninv = -1 / range (0 with psill = 0 for a pure nugget); coincident points give psill,
 // as the fast build does (their systems are singular and flagged through SelWs.cdup)
 __device__ __attribute__((noinline)) double cov_pair_f64(const double *a, const double *b, double ninv, double psill)
 {
-    return psill * exp(ellip_pair_f64(a, b) * ninv);
+    return psill * exp_neg_f64(ellip_pair_f64(a, b) * ninv);
 }
 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
