@@ -5,6 +5,6 @@ set -u
 for v in old new old new; do
   cp ab/libtwxhip_$v.so topowx_amd/libtwxhip.so
   echo "== $v"
-  bash tests/tools/quick_stats.sh ab_$v "$@" | grep "k_uk\|k_gwr\|k_select<4>\|kriging\|bench"
+  bash tests/tools/quick_stats.sh ab_$v "$@" | grep "k_uk\|k_gwr\|k_select<\|k_tile_dist\|kriging\|bench"
 done
 cp ab/libtwxhip_new.so topowx_amd/libtwxhip.so

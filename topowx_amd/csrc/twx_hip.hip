@@ -321,10 +321,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     }
     {
         EvScope ev(ctx, stream, EV_SELECT);
-        hipLaunchKernelGGL((k_select<4>), dim3((unsigned)(((ncell + 3) / 4 + 7) / 8 * 8)), dim3(256), (size_t)4 * TWX_CAND_SMALL * (sizeof(double) + 2),
+        hipLaunchKernelGGL((k_select<4, 0>), dim3((unsigned)(((ncell + 3) / 4 + 7) / 8 * 8)), dim3(256), (size_t)4 * TWX_CAND_SMALL * (sizeof(double) + 2),
                            stream, st, src, w.ws, 0, TWX_CAND_SMALL);
-        if (w.cmax > TWX_CAND_SMALL)      // cells of tiles with long candidate lists (dense station clusters)
-            hipLaunchKernelGGL((k_select<1>), dim3((unsigned)((ncell + 7) / 8 * 8)), dim3(64), (size_t)w.cmax * (sizeof(double) + 2), stream, st, src,
+        if (w.cmax > TWX_CAND_SMALL)      // cells of tiles with long candidate lists (dense station clusters): one work-group per TILE
+            hipLaunchKernelGGL((k_select<1, 1>), dim3((unsigned)ntile), dim3(64), (size_t)w.cmax * (sizeof(double) + 2), stream, st, src,
                                w.ws, TWX_CAND_SMALL, w.cmax);
     }
     if (!src.do_krig) return 0;
@@ -334,9 +334,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems -- and the smallest
         // pair distance by rank, which k_bucket_items needs to route ill-conditioned systems to the fp64 build
         EvScope ev(ctx, stream, EV_UK);
-        if (w.ws.near_pos)       // grid mode: per tile, from a table of the tile's station pairs
-            hipLaunchKernelGGL(k_tile_dist, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
-        else
+        if (w.ws.near_pos) {     // grid mode: per tile, from a table of the tile's station pairs; hminp in a launch of its own
+            hipLaunchKernelGGL(k_tile_dist<0>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
+            hipLaunchKernelGGL(k_tile_dist<1>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
+        } else
             hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
     }
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
 #define TWX_SEL_GA 4
 #define TWX_SEL_GB 1
 #endif
+#ifndef TWX_CAND_MAX
 #define TWX_CAND_MAX 4096    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS; round 3: 2 048)
+#endif
 struct SmoothOut { int status; int k; };
 
 // v with lane L (wave-uniform index) replaced by the wave-uniform value x; lane L of v as a uniform value.  An fp64
@@ -269,17 +271,14 @@ __device__ __forceinline__ int smooth3(const double *snd, const int *sidx, int n
 }
 
 template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, SelWs ws, int clo, int chi)
+__device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src, const SelWs &ws, int clo, int chi, int64_t lc)
 {
     extern __shared__ double s_dyn[];
     __shared__ double s_nd[WPB][TWX_KSEL_MAX];
     __shared__ int s_ni[WPB][TWX_KSEL_MAX];
     __shared__ int s_np[WPB][TWX_KSEL_MAX];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wgi = xcd_contig(blockIdx.x, (int)((ws.ncell + WPB - 1) / WPB));   // row-major cells: a tile's rows meet in one L2
-    if (wgi < 0) return;
-    const int64_t lc = (int64_t)wgi * WPB + wv;             // local cell
-    bool in_range = lc < ws.ncell;
+    bool in_range = lc >= 0 && lc < ws.ncell;
     const int64_t c = ws.cell0 + (in_range ? lc : 0);       // global cell id
     bool valid = in_range && cell_valid(src, c);
     double *sd = s_dyn + (size_t)wv * chi;
@@ -600,6 +599,33 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
     }
 }
 
+// Launch forms: BY_TILE = 0: work-group g takes the cells g WPB .. g WPB + WPB - 1 (one wave each; the launch of ordinary
+// tiles).  BY_TILE = 1 (WPB = 1): work-group g takes the g-th tile of the batch and, when its candidate list is a long
+// one (clo < ncand <= chi), walks its cells -- a handful of work-groups do real work and the launch costs nothing otherwise
+// (one work-group per CELL with 40 KB of dynamic LDS each took 0.16 ms per C2 step just to find that out).
+template <int WPB, int BY_TILE>
+__global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, SelWs ws, int clo, int chi)
+{
+    if constexpr (BY_TILE) {
+        const int64_t tl = blockIdx.x;
+        if (tl >= ws.ntile) return;
+        const int nc = ws.ncand[tl];
+        if (!(nc > clo && nc <= chi)) return;               // (an overflowing tile's cells are failed by the first launch)
+        const int64_t tile = ws.tile0 + tl;
+        const int r0 = (int)(tile / src.ntx) * src.ts, q0 = (int)(tile % src.ntx) * src.ts;
+        for (int ci = 0; ci < src.ts * src.ts; ++ci) {
+            const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
+            if (rr >= src.Y || qq >= src.X) continue;
+            select_cell<WPB>(st, src, ws, clo, chi, (int64_t)rr * src.X + qq - ws.cell0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        const int wgi = xcd_contig(blockIdx.x, (int)((ws.ncell + WPB - 1) / WPB));   // row-major cells: a tile's rows meet in one L2
+        if (wgi < 0) return;
+        select_cell<WPB>(st, src, ws, clo, chi, (int64_t)wgi * WPB + (threadIdx.x >> 6));
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // k_bucket_items: counting sort of the (cell, month) kriging items by matrix size, in steps of 8 neighbours.
 // With m = ceil(k / 16) block rows of 16:
@@ -632,11 +658,24 @@ __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 #ifndef TWX_F64_AMP
 #define TWX_F64_AMP 8.0
 #endif
+// necessary condition (1 - exp(.) >= 0): the nugget alone must be below psill / 16.  The distance kernels record hminp
+// only for cells with such a month, and k_bucket_items reads it only then (the synthetic benchmark never does).
+__device__ __forceinline__ bool uk_may_need_f64(double nug, double psill, double rng)
+{
+    return rng > 0.0 && psill > 0.0 && (2.0 * TWX_F64_AMP) * nug < psill;
+}
 __device__ __forceinline__ bool uk_needs_f64(double nug, double psill, double rng, float hmin)
 {
-    if (!(rng > 0.0) || !(psill > 0.0)) return false;
     const double t = -expm1(-(double)hmin / rng);            // hmin = +inf (a single neighbour): t = 1
     return (2.0 * TWX_F64_AMP) * (nug + psill * t) < psill;
+}
+// does any month of the cell meet the necessary condition?  Lanes 0..11 of the calling wave take a month each (one
+// 24-byte load per lane, one ballot: wave-uniform result); vario = ws.vario + lc * 36
+__device__ __forceinline__ bool cell_may_need_f64(const double *vario, int lane)
+{
+    bool mine = false;
+    if (lane < 12) mine = uk_may_need_f64(vario[lane * 3], vario[lane * 3 + 1], vario[lane * 3 + 2]);
+    return __ballot(mine) != 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
@@ -652,8 +691,9 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
         if (k > 0) {
             id = twx_krig_bucket(k);
-            if (!ws.fast_only && uk_needs_f64(ws.vario[item * 3], ws.vario[item * 3 + 1], ws.vario[item * 3 + 2],
-                                              ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))
+            const double nug = ws.vario[item * 3], psill = ws.vario[item * 3 + 1], rng = ws.vario[item * 3 + 2];
+            if (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
+                uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))
                 id = TWX_BUCKET_F64 + (k > 104 ? 1 : 0);
             rank = atomicAdd(&s_cnt[id], 1);
         }

@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
     }
     __syncthreads();
     if (t == 0) ws.cdup[lc] = s_dup;
-    // smallest pair distance among the neighbours of ranks <= r (uk_needs_f64 reads entry k - 1 of a system of k)
-    if (t < 64) {
+    // smallest pair distance among the neighbours of ranks <= r (uk_needs_f64 reads entry k - 1 of a system of k);
+    // only for a cell with a month whose nugget is small enough for the fp64 build to be possible at all
+    if (t < 64 && cell_may_need_f64(ws.vario + lc * 36, t)) {
         float run = __builtin_inff();
         for (int r0 = 0; r0 < kmax; r0 += 64) {
             const int r = r0 + t;
@@ -291,6 +292,13 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 #ifndef TWX_TD_PARTS
 #define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
 #endif
+// HM = 0: the cache (dist, h0, cdup).  HM = 1: only hminp -- the smallest pair distance among a cell's neighbours by rank,
+// which routes a system to the fp64 covariance build (uk_needs_f64) -- and only for cells with a month whose nugget
+// makes that possible (uk_may_need_f64): a second, separate launch whose work-groups leave at once when no cell of
+// their tile part qualifies (the synthetic benchmark: all of them).  Kept out of the cache kernel on purpose: with the
+// row minima in its block loop -- even behind a per-cell branch, even as a second instance of the loop -- the cache
+// kernel ran 616 -> 668...695 us per C2 step.
+template <int HM>
 __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, CellSrc src, SelWs ws)
 {
     constexpr int NTH = 64 * TWX_TD_WAVES;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
     __shared__ uint16_t s_slot[TWX_CAND_MAX];                // candidate position -> 1 + number in the union (0: not used)
     __shared__ double s_trig[TWX_TD_U * 5];                  // sin / cos of half latitude and longitude, cos(latitude)
     __shared__ uint16_t s_ur[TWX_TD_WAVES][TWX_KSEL_MAX];    // per wave: union number by rank, of the wave's current cell
-    __shared__ int s_cnt[TWX_TD_WAVES], s_base, s_dup[TWX_TD_WAVES];
+    __shared__ int s_cnt[TWX_TD_WAVES], s_base, s_dup[TWX_TD_WAVES], s_any;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t tl = blockIdx.x / TWX_TD_PARTS;            // local tile; this work-group takes one part of its cells
@@ -309,20 +317,32 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
     const int ncl = src.ts * src.ts;                         // cells per tile (<= 64)
     const int ci0 = ncl * part / TWX_TD_PARTS, ci1 = ncl * (part + 1) / TWX_TD_PARTS;
     const int ncand = min(ws.ncand[tl], ws.cmax);
-    for (int p = t; p < ncand; p += NTH) s_slot[p] = 0;
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    // local cell of the tile's ci-th cell and its largest monthly neighbourhood (wave-uniform; -1 / 0: nothing to do)
+    // local cell of the tile's ci-th cell and its largest monthly neighbourhood (wave-uniform; -1 / 0: nothing to do);
+    // HM: only the cells that can need the fp64 build
     auto cell_of = [&](int ci, int &kmax) __attribute__((always_inline)) -> int64_t {
         kmax = 0;
         const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
         if (rr >= src.Y || qq >= src.X) return -1;
         const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
         if (lc < 0 || lc >= ws.ncell || ws.cstat[lc] != 0) return -1;
+        if (HM && !cell_may_need_f64(ws.vario + lc * 36, lane)) return -1;
 #pragma unroll
         for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
         return lc;
     };
+    if constexpr (HM) {                                      // does any cell of this part qualify?
+        if (t == 0) s_any = 0;
+        __syncthreads();
+        for (int ci = ci0 + wv; ci < ci1; ci += TWX_TD_WAVES) {
+            int kmax;
+            if (cell_of(ci, kmax) >= 0 && kmax > 0 && lane == 0) s_any = 1;
+        }
+        __syncthreads();
+        if (!s_any) return;
+    }
+    for (int p = t; p < ncand; p += NTH) s_slot[p] = 0;
+    if (t == 0) s_base = 0;
+    __syncthreads();
     // (1) mark the candidates any cell of the tile kriges with
     for (int ci = ci0 + wv; ci < ci1; ci += TWX_TD_WAVES) {
         int kmax;
@@ -377,26 +397,28 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
         const int64_t lc = cell_of(ci, kmax);
         if (kmax <= 0) continue;
         uint16_t *ur = s_ur[wv];
-        if (lane == 0) s_dup[wv] = 0x7fffffff;
+        if (!HM && lane == 0) s_dup[wv] = 0x7fffffff;
         const double *ct = ws.ctrig + lc * 4;
         const double ccph = fma(ct[1], ct[1], -(ct[0] * ct[0]));
         for (int r = lane; r < kmax; r += 64) {
             const int u = (int)s_slot[ws.near_pos[lc * ws.ksel + r]] - 1;
             ur[r] = (uint16_t)u;
-            const double *bq = &trig[u * 5];
-            ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
+            if constexpr (!HM) {
+                const double *bq = &trig[u * 5];
+                ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const int nbk = (kmax + 15) >> 4;
         float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
         const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
-        float run = __builtin_inff();                        // smallest pair distance among the rows above this block row
+        float run = __builtin_inff();                        // (HM) smallest pair distance among the rows above this block row
         for (int a = 0; a < nbk; ++a) {
             const int i = 16 * a + tr;
             const bool iv = i < kmax;
             const int ui = iv ? ur[i] : 0, ti = ui * (ui + 1) / 2;
             const double *pa = &trig[ui * 5];
-            float rm = __builtin_inff();                     // min over j < i of h(i, j) (this lane's columns)
+            float rm = __builtin_inff();                     // (HM) min over j < i of h(i, j) (this lane's columns)
             for (int b = 0; b <= a; ++b) {
                 float *ob = out + (a * (a + 1) / 2 + b) * 256 + lane;
 #pragma unroll
@@ -410,22 +432,23 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
                             const double *pb = &trig[uj * 5];
                             h = ellip_pair_fast(pa[0], pa[1], pa[2], pa[3], pa[4], pb[0], pb[1], pb[2], pb[3], pb[4]);
                         }
-                        if (j < i) rm = fminf(rm, h);
+                        if (HM && j < i) rm = fminf(rm, h);
                         // coincident neighbours: see k_cell_dist
-                        if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
+                        if (!HM && h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
-                    __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
+                    if constexpr (!HM) __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
                 }
             }
-            // hminp (see k_cell_dist): row minimum over the four lane columns, running minimum down the rows
-            rm = fminf(rm, __shfl_xor(rm, 16, 64));
-            rm = fminf(rm, __shfl_xor(rm, 32, 64));
-            rm = fminf(row_scan_min(rm), run);
-            if (lane < 16 && iv) ws.hminp[lc * ws.ksel + i] = rm;
-            run = __shfl(rm, 15, 64);
+            if constexpr (HM) {                              // row minimum over the four lane columns, running minimum down the rows
+                rm = fminf(rm, __shfl_xor(rm, 16, 64));
+                rm = fminf(rm, __shfl_xor(rm, 32, 64));
+                rm = fminf(row_scan_min(rm), run);
+                if (lane < 16 && iv) ws.hminp[lc * ws.ksel + i] = rm;
+                run = __shfl(rm, 15, 64);
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) ws.cdup[lc] = s_dup[wv];
+        if (!HM && lane == 0) ws.cdup[lc] = s_dup[wv];
     }
 }
 
