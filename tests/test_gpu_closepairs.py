@@ -173,3 +173,26 @@ def test_close_pairs_grid_vs_oracle(env, orc):
     for k in ("norm_tmin", "se_tmin"):
         err = np.abs(got[k].astype(np.float64) - want[k])[:, ok].max()
         assert err < TOL + 4e-6, (k, err)
+
+
+def test_close_pairs_leave_one_out(env, orc):
+    """The cross-validation form (step21 / step24: the point is a station, its own id excluded, zero-distance stations
+    removed) on the close-pair table: the station's 50-300 m partner stays in the neighbourhood, the system is routed to
+    the fp64 build like any other."""
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    c = env["odb"].cols
+    # the ten partner stations around the first test cell and ten ordinary ones
+    idx, _, _, _ = ctx.knn(lib.TMIN, grid["lon"][env["cells"][:1, 1]], grid["lat"][env["cells"][:1, 0]], 20)
+    js = np.concatenate([idx[0], np.arange(200, 210)]).astype(np.int32)
+    pts = ctx.make_pts(c["lon"][js], c["lat"][js], c["elev"][js], c["tdi"][js], c["lst"][:, js].T)
+    worst = 0.0
+    for vario in ((0.0, 2.0, 900.0), (1e-3, 0.2, 40.0), (0.3, 1.0, 40.0)):
+        for k in (40, 112):
+            mean, var, used, st, _ = ctx.krig_points(lib.TMIN, pts, 5, nnghs=k, vario=[vario] * js.size, excl=js, rm_zero_dist=True)
+            for i, j in enumerate(js):
+                pt = orc.make_pt(c["lon"][j], c["lat"][j], c["elev"][j], c["tdi"][j], c["lst"][:, j])
+                rc, m, v, u, _ = orc.krig(env["odb"], env["prm"], pt, 5, nnghs=k, vario=vario, excl=int(j), rm_zero_dist=True)
+                assert (rc != 0) == (st[i] != 0), (vario, k, int(j), rc, int(st[i]))
+                if rc == 0:
+                    worst = max(worst, abs(mean[i] - m), abs(var[i] - v))
+    assert worst < TOL, worst
