@@ -743,6 +743,14 @@ def main():
             cfg["c4_tile"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(1948, 1, 1), dt.date(2016, 12, 31),
                                           "c4_tile (BASELINE.json configs[3], one tile)", 3, 1, 0, 2)
             cfg["c4_tile"]["record_wall_s"] = time.perf_counter() - t1
+            # measured HBM bytes of the daily launches on THIS tile (tests/tools/collect_c4_traffic.sh): the hat rows are per
+            # (cell, month), so their share shrinks with the day axis -- quoted from the newest committed PMC reduction
+            c4p = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_daily_traffic.json")))
+            if c4p and args.size == 250 and args.nstns == 10000:
+                tj = json.load(open(c4p[-1]))
+                cfg["c4_tile"]["traffic"] = {"bytes_per_step": tj["fetched_bytes_per_step"] + tj["written_bytes_per_step"],
+                                             "algorithmic_bytes_per_step": tj["algorithmic_bytes_per_step"], "ratio": tj["ratio"],
+                                             "measured_in_this_run": False, "source": "profiles/" + os.path.basename(c4p[-1])}
         ctx.close()
         ctx = None
         del d_in, d_norm, d_se
