@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, hminp, noff, near_pos, urow,
-        nurow, zd, perm, kp, uslot;
+        nurow, zd, perm, kp, uslot, cellf64, dist64, h064;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
@@ -59,7 +59,7 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &hminp, &noff,
-                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot})
+                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot, &cellf64, &dist64, &h064})
             b->release();
     }
 };
@@ -184,6 +184,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.dist.ensure((size_t)ncell * TWX_DIST_BLOCKS * 256 * 4));   // pair distances shared by a cell's 12 systems
     HIPCHK(w.h0.ensure((size_t)ncell * ksel * 4));
     HIPCHK(w.hminp.ensure((size_t)ncell * ksel * 4));
+    HIPCHK(w.cellf64.ensure((size_t)ncell * 4));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
@@ -221,6 +222,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>(); s.hminp = w.hminp.as<float>();
     s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
+    s.cellf64 = w.cellf64.as<int32_t>(); s.dist64 = nullptr; s.h064 = nullptr;
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
     w.gw.perm = w.perm.as<int32_t>(); w.gw.kp = w.kp.as<int32_t>();
@@ -340,6 +342,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         } else
             hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
     }
+    HIPCHK(hipMemsetAsync(w.cellf64.p, 0, (size_t)ncell * 4, stream));
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     HIPCHK(ctx->stats.ensure(64));
     hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
@@ -349,6 +352,15 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         HIPCHK(hipMemcpyAsync(cnt_host, w.ws.bucket_cnt, sizeof cnt_host, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         cnt = cnt_host;
+    }
+    if (cnt && cnt[TWX_BUCKET_F64] + cnt[TWX_BUCKET_F64 + 1] > 0) {
+        // this batch has systems on the fp64 covariance build: the fp64 pair distances of their cells, once per cell
+        // (110 KB of address space per cell: allocated on first need)
+        HIPCHK(w.dist64.ensure((size_t)ncell * TWX_DIST_BLOCKS * 256 * 8));
+        HIPCHK(w.h064.ensure((size_t)ncell * ksel * 8));
+        w.ws.dist64 = w.dist64.as<double>(); w.ws.h064 = w.h064.as<double>();
+        EvScope ev(ctx, stream, EV_UK);
+        hipLaunchKernelGGL(k_cell_dist64, dim3((unsigned)ncell), dim3(256), 0, stream, st, w.ws);
     }
     {
         EvScope ev(ctx, stream, EV_UK);
@@ -375,8 +387,13 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         launch_uk<8>(cnt, st, src, w.ws, 9, mi, stream);        // 104 < k <= 120
         launch_uk<9>(cnt, st, src, w.ws, 10, mi, stream);       // 120 < k <= 136
         launch_uk<10>(cnt, st, src, w.ws, 11, mi, stream);      // 136 < k <= 152
-        launch_uk<7, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);        // ill-conditioned systems (uk_needs_f64): fp64
-        launch_uk<10, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);   // covariance build, k <= 104 / k <= 152
+        if (w.ws.dist64) {       // ill-conditioned systems (uk_needs_f64): fp64 covariance build, k <= 104 / k <= 152
+            launch_uk<7, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);        // distances from the cells' fp64 slabs
+            launch_uk<10, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);
+        } else {                 // (no host decision possible: per-element distances)
+            launch_uk<7, 2>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);
+            launch_uk<10, 2>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);
+        }
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit

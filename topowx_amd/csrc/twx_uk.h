@@ -278,6 +278,45 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
 }
 
 // ---------------------------------------------------------------------------------
+// k_cell_dist64: the fp64 pair distances of the cells that have a month on the fp64 covariance build (SelWs.cellf64), in
+// the block layout of the fp32 cache, and their cell -> neighbour distances.  One work-group per cell (the others leave at
+// once); launched only when a batch has routed systems.  Evaluated once per cell instead of once per routed month and
+// element (every-system-flagged C2 step: 54 -> see profiles/README.md).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_dist64(StnDev st, SelWs ws)
+{
+    __shared__ double s_tg[TWX_KSEL_MAX * 5];
+    const int64_t lc = blockIdx.x;
+    if (lc >= ws.ncell || ws.cstat[lc] != 0 || !ws.cellf64[lc]) return;
+    const int t = threadIdx.x, tr = t & 15, tc = t >> 4;
+    int kmax = 0;
+#pragma unroll
+    for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
+    if (kmax <= 0) return;
+    if (t < kmax) {
+        const int j = ws.near_idx[lc * ws.ksel + t];
+        const double sp = st.sph[j], cp = st.cph[j];
+        double *q = &s_tg[t * 5];
+        q[0] = sp; q[1] = cp; q[2] = st.slh[j]; q[3] = st.clh[j]; q[4] = fma(cp, cp, -(sp * sp));
+        const double *ct = ws.ctrig + lc * 4;
+        const double ctr[5] = {ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0]))};
+        ws.h064[lc * ws.ksel + t] = ellip_pair_f64(ctr, q);
+    }
+    __syncthreads();
+    const int nbk = (kmax + 15) >> 4;
+    double *out = ws.dist64 + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
+    for (int a = 0; a < nbk; ++a) {
+        const int i = 16 * a + tr;
+        for (int b = 0; b <= a; ++b) {
+            const int j = 16 * b + tc;
+            double h = 0.0;
+            if (i < kmax && j < i) h = ellip_pair_f64(&s_tg[i * 5], &s_tg[j * 5]);
+            out[(a * (a + 1) / 2 + b) * 256 + t] = h;            // t = tc * 16 + tr
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // k_tile_dist (grid mode): the same cache as k_cell_dist, one work-group per 8x8-cell tile.  The kriging
 // neighbourhoods of a tile's cells draw on the same ~200 stations, so the pair distances of that UNION are evaluated
 // once per tile into an LDS table (lower triangle, fp32, <= TWX_TD_U stations: 129 KB of gfx950's 160 KB) and every
@@ -499,12 +538,14 @@ __host__ __device__ constexpr int twx_uk_waves(int nb)
 template <int NW> __device__ __forceinline__ constexpr int uk_nbc(int a) { return 16 * (a + 1) / (4 * NW); }
 template <int NW> __device__ __forceinline__ constexpr int uk_eidx(int a, int b) { return (4 / NW) * (a * (a + 1) / 2) + b; }
 
-// PREC = 1: the fp64 covariance build (ill-conditioned systems, uk_needs_f64): pair and cell -> station distances from
-// the neighbours' half-angle trigonometry staged in LDS, fp64 exp, nothing read from the fp32 distance cache.  Same
-// elimination.  Instantiated for NB = 7 (k <= 104) and NB = 10; not tuned: few systems take it.
+// PREC > 0: the fp64 covariance build (ill-conditioned systems, uk_needs_f64): fp64 distances, fp64 exp, nothing read from
+// the fp32 distance cache.  PREC = 1: distances from the cell's fp64 slab (k_cell_dist64: evaluated once per cell, one
+// coalesced load per element here); PREC = 2: no slab (TWX_FLAG_NO_HOST_SYNC: the host does not know that a batch has
+// routed systems) -- every element's distance from the neighbours' half-angle trigonometry staged in LDS, per system.
+// Same elimination.  Instantiated for NB = 7 (k <= 104) and NB = 10; not tuned: few systems take it.
 template <int NB, int NW, int PREC = 0>
 __global__ __launch_bounds__(64 * NW)
-__attribute__((amdgpu_waves_per_eu(PREC ? 1 : twx_uk_waves(NB), twx_uk_waves(NB))))
+__attribute__((amdgpu_waves_per_eu(PREC == 2 ? 1 : twx_uk_waves(NB), twx_uk_waves(NB))))
 void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
 {
     constexpr int NP = NB * 16, CB = 4 * NW, NBC = NP / CB, NT = uk_eidx<NW>(NB, 0), NTH = 64 * NW;
@@ -515,7 +556,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
                                                                               // the next panel is factorised while this one is still being applied
     __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
-    __shared__ double s_trig[PREC ? NP * 5 : 1];             // PREC: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by rank
+    __shared__ double s_trig[PREC == 2 ? NP * 5 : 1];        // PREC = 2: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by rank
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
@@ -598,12 +639,15 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             if constexpr (PREC) {
-                const double sp = st.sph[j], cp = st.cph[j];
-                double *tq = &s_trig[q * 5];
-                tq[0] = sp; tq[1] = cp; tq[2] = st.slh[j]; tq[3] = st.clh[j]; tq[4] = fma(cp, cp, -(sp * sp));
-                const double *ct = ws.ctrig + lc * 4;
-                const double ctr[5] = {ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0]))};
-                c0v = same ? c00 : cov_pair_f64(ctr, tq, ninv, psill_e);
+                if constexpr (PREC == 1) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[lc * ws.ksel + q] * ninv);
+                else {
+                    const double sp = st.sph[j], cp = st.cph[j];
+                    double *tq = &s_trig[q * 5];
+                    tq[0] = sp; tq[1] = cp; tq[2] = st.slh[j]; tq[3] = st.clh[j]; tq[4] = fma(cp, cp, -(sp * sp));
+                    const double *ct = ws.ctrig + lc * 4;
+                    const double ctr[5] = {ct[0], ct[1], ct[2], ct[3], fma(ct[1], ct[1], -(ct[0] * ct[0]))};
+                    c0v = same ? c00 : cov_pair_f64(ctr, tq, ninv, psill_e);
+                }
             } else
                 c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
@@ -635,8 +679,13 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
             double v;
-            if constexpr (PREC) v = (i < k && j < i) ? cov_pair_f64(&s_trig[i * 5], &s_trig[j * 5], ninv, psill_e) : 0.0;
-            else v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
+            if constexpr (PREC) {
+                constexpr int j0 = CB * b;
+                if constexpr (PREC == 1)   // the cell's fp64 pair distances (k_cell_dist64): one coalesced load + the exponential
+                    v = (i < k && j < i) ? psill_e * exp_neg_f64(ws.dist64[lc * (int64_t)(TWX_DIST_BLOCKS * 256) + tri(a, j0 / 16) * 256 +
+                                                                          ((j0 % 16) + (tc % 16)) * 16 + tr] * ninv) : 0.0;
+                else v = (i < k && j < i) ? cov_pair_f64(&s_trig[i * 5], &s_trig[j * 5], ninv, psill_e) : 0.0;
+            } else v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0: eliminating them changes nothing), so the panel step has no special cases
             if (CB * b / 16 == a && i == j) v = i < k ? c00 : ((a == NB - 1 && tr >= 9) ? 0.0 : 1.0);
