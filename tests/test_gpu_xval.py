@@ -125,3 +125,31 @@ def test_step22_farm(golden_case, orc):
                 assert not ok[q]
                 continue
             np.testing.assert_allclose([nug[m - 1, q], psill[m - 1, q], rng[m - 1, q]], v, rtol=1e-6, atol=1e-9)
+
+
+def test_pipeline_step21_22_then_grid_with_fitted_variograms(golden_case, orc):
+    """The reference's own order of use: step21 optimises the bandwidths, step22 fits every station's variogram
+    (nugget = min gamma: small nuggets occur), and step25 then interpolates the grid with the neighbour-weighted means of
+    THOSE parameters.  Grid normals / SE on such a table against the oracle -- whatever share of the systems the small
+    fitted nuggets route to the fp64 covariance build."""
+    from topowx_amd import _lib, stationdb as sdb, xval
+    grid, tmin, _ = golden_case
+    stn = sdb.StationDataWrkChk(tmin.stns.copy(), "tmin", tmin.days, None)
+    ids, mae = xval.optim_nstns_norms(stn, "tmin", batch=64)
+    xval.set_optim_nstns_tair_norm(stn, ids, mae)
+    _, nug, psill, rng = xval.set_stn_variograms(stn, "tmin", batch=100)
+    ok = np.isfinite(nug)
+    small = ok & (rng > 0) & (psill > 0) & (16 * nug < psill)
+    assert ok.mean() > 0.95 and small.sum() > 0                  # fitted tables do hold nuggets below psill / 16
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, stn, with_obs=False)
+    rs, cs = slice(24, 56), slice(30, 70)
+    got = ctx.interp_grid(grid, variables=("tmin",), daily=False, rows=rs, cols=cs)
+    t = ctx.timing()
+    ctx.close()
+    want = orc.interp_grid(orc.Db(stn), None, orc.params(), grid, daily=False, nthreads=8, rows=rs, cols=cs)
+    assert np.array_equal(got["status"], want["status"]) and (want["status"] == 0).mean() > 0.9
+    okc = want["status"] == 0
+    for k in ("norm_tmin", "se_tmin"):
+        assert np.abs(got[k].astype(np.float64) - want[k])[:, okc].max() < TOL, k
+    assert t["uk_solves"] == int(okc.sum()) * 12 and 0 <= t["uk_f64_solves"] <= t["uk_solves"]
