@@ -25,7 +25,7 @@ EXPECT = {
     "k_tile_dist<0>": (4, 0), "k_tile_dist<1>": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4, 0>": (4, 0), "k_select<1, 1>": (2, 0), "k_tile_cand": (4, 0),
     "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
-    "k_daily_grid": (4, 0), "k_fix_cells": (4, 0),
+    "k_daily_grid": (4, 0), "k_fix_cells": (4, 0), "k_fix_sparse": (2, 0),
 }
 LDS_PER_CU = 160 * 1024
 

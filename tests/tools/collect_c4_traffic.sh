@@ -16,7 +16,7 @@ f, w = t["FETCH_SIZE"]["daily_path_per_step_bytes"], t["WRITE_SIZE"]["daily_path
 alg = 2.03 * 62500 * 25203 * 2
 out = {"workload": "configs[3] tile: 250x250 cells, 25 203 days, Tmin + Tmax", "fetched_bytes_per_step": f, "written_bytes_per_step": w,
        "algorithmic_bytes_per_step": alg, "ratio": (f + w) / alg, "per_kernel": {k: {"fetch": t["FETCH_SIZE"][k]["per_launch_bytes"], "write": t["WRITE_SIZE"][k]["per_launch_bytes"], "launches_per_step": t["FETCH_SIZE"][k]["launches"]}
-       for k in ("k_daily_tile", "k_gwr_z_cell", "k_tile_uidx", "k_perm", "k_fix_cells")}, "kernel_sources_sha16": t["kernel_sources_sha16"]}
+       for k in ("k_daily_tile", "k_gwr_z_cell", "k_tile_uidx", "k_perm", "k_fix_cells", "k_fix_sparse")}, "kernel_sources_sha16": t["kernel_sources_sha16"]}
 json.dump(out, open("gpurun_out/prof_c4/c4_daily_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY

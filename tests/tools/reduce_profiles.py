@@ -11,7 +11,7 @@ import sys
 out = sys.argv[1]
 KRIG = ("k_uk<", "k_ukw<", "k_ukwz<", "k_ukw2<", "k_cell_dist", "k_tile_dist")   # (prefix: k_tile_dist<0>, <1>)   # the kernels behind bench.py's uk_ms
 DAILY = ("k_daily_tile", "k_tile_union", "k_tile_uidx", "k_perm", "k_row_offsets", "k_daily_ok", "k_daily_grid")   # ... daily_ms
-DAILY_ONLY = DAILY + ("k_gwr_z", "k_gwr_z_cell", "k_fix_cells", "k_compact_flags")
+DAILY_ONLY = DAILY + ("k_gwr_z", "k_gwr_z_cell", "k_fix_cells", "k_fix_sparse", "k_compact_flags")
 
 
 def short(name):
@@ -56,7 +56,7 @@ for key, sub, dsub, pre in (("FETCH_SIZE", "fetch", "dfetch", "f"), ("WRITE_SIZE
             for k, (n, v) in sorted(dper.items(), key=lambda kv: -kv[1][1]):
                 if k.startswith(DAILY_ONLY):
                     fh.write('"%s",%d,%.1f\n' % (k, n, v))
-        for o in ("k_daily_tile", "k_daily_tile_gather", "k_tile_uidx", "k_perm", "k_gwr_z", "k_gwr_z_cell", "k_fix_cells"):
+        for o in ("k_daily_tile", "k_daily_tile_gather", "k_tile_uidx", "k_perm", "k_gwr_z", "k_gwr_z_cell", "k_fix_cells", "k_fix_sparse"):
             n, kb = group(dper, (o,), exact=True)
             res[key][o] = {"launches": n, "per_launch_bytes": kb * 1024.0 / max(n, 1)}
         # the launches behind bench.py's daily.timing_ms.daily_ms + gwr_ms, per daily step (Tmin + Tmax): the record's

@@ -14,6 +14,7 @@ struct DayAxis {
     const int32_t *day_year;  // [ndays]
     int tail;
     int norm_ny;              // years of the normals period present in the day axis (0 = none)
+    int norm_y0;              // first of them
     const int32_t *ym_start;  // [norm_ny * 12] first chronological day of (year, month)
     const int32_t *ym_cnt;    // [norm_ny * 12] days of (year, month)
 };
@@ -666,6 +667,17 @@ __global__ __launch_bounds__(256) void k_tile_uidx(CellSrc src, SelWs ws, GwrWs 
 // TWX_DT_WAVES = 8 waves per work-group (2 work-groups fit a CU: LDS).  The kernel is VALU bound: 8 cells per wave share each
 // row's LDS read + convert (C4 tile: 16 waves x 4 cells 35.2 ms, 8 x 8 27.5 ms, 4 x 16 34.5 ms)
 
+// Days with tmin >= tmax are recorded per cell as they are found (chronological day index, unordered; the count keeps
+// running past the capacity): a cell with at most TWX_INV_CAP of them is fixed from those days' windows alone
+// (k_fix_sparse), any other by recomputing its whole series (k_fix_cells).
+#define TWX_INV_CAP 256
+__device__ __forceinline__ void note_invalid_day(int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, int64_t lc, int d)
+{
+    flag[lc] = 1;
+    const int slot = atomicAdd(&inv_cnt[lc], 1);
+    if (slot < TWX_INV_CAP) inv_day[lc * TWX_INV_CAP + slot] = d;
+}
+
 // lean argument block of k_daily_tile (the full workspaces would not fit the scalar registers: 97 spilled SGPRs)
 struct DtVar {
     const float *obs;         // [n][ndays] month-major
@@ -681,6 +693,7 @@ struct DtArgs {
     const int32_t *mm2chron;
     int16_t *out_n, *out_x;   // [ndays][Y][X]
     int32_t *flag;
+    int32_t *inv_cnt, *inv_day;   // per cell: number of days with tmin >= tmax, and the first TWX_INV_CAP of them (k_fix_sparse)
     int64_t cell0, ncell, tile0, ntile;
     int Y, X, ts, ntx, ndays, nblk_max, gather;
     int moff[13];
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
         const int cl = wv * TWX_DT_CPW + i;
         const int64_t lc = lcs[i];
         const double vx = vxs[i];
-        if (lc >= 0 && day_ok && vn[i] >= vx) a.flag[lc] = 1;
+        if (lc >= 0 && day_ok && vn[i] >= vx) note_invalid_day(a.flag, a.inv_cnt, a.inv_day, lc, a.mm2chron[dm]);
         const bool okd = lc >= 0 && day_ok;
         s_v[0][lane][cl] = okd ? pack_i16(vn[i]) : TWX_FILL_I2;
         s_v[1][lane][cl] = okd ? pack_i16(vx) : TWX_FILL_I2;
@@ -865,8 +878,8 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
 // rows, or all of them with TWX_FLAG_DAILY_GATHER / TWX_FLAG_OBS_ADDR64
 __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                            GwrWs gn, GwrWs gx, DayAxis da, twx_grid_out out,
-                                                           int32_t *flag, const int32_t *okc, int nblk_max, int addr64,
-                                                           int gather)
+                                                           int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, const int32_t *okc,
+                                                           int nblk_max, int addr64, int gather)
 {
     __shared__ int16_t s_v[2][64][66];
     const int lane = threadIdx.x & 63;
@@ -899,7 +912,7 @@ __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev st
         if (lc >= 0 && day_ok) {
             if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
             else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
-            if (va >= vb) flag[lc] = 1;
+            if (va >= vb) note_invalid_day(flag, inv_cnt, inv_day, lc, da.mm2chron[dm]);
         }
         const bool okd = lc >= 0 && day_ok;
         s_v[0][lane][cl] = okd ? pack_i16(va) : TWX_FILL_I2;
@@ -926,7 +939,8 @@ __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev st
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                     GwrWs gn, GwrWs gx, int has_n, int has_x, DayAxis da,
-                                                    twx_grid_out out, int32_t *flag, int nblk_max, int addr64)
+                                                    twx_grid_out out, int32_t *flag, int32_t *inv_cnt, int32_t *inv_day,
+                                                    int nblk_max, int addr64)
 {
     __shared__ int16_t s_v[2][64][66];
     const int lane = threadIdx.x & 63;
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
             if (has_n && has_x) {
                 if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
                 else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
-                if (vn >= vx) flag[lc] = 1;
+                if (vn >= vx) note_invalid_day(flag, inv_cnt, inv_day, lc, da.mm2chron[dm]);
             } else if (has_n) vn = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
             else vx = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
         }
@@ -993,6 +1007,8 @@ struct FixArgs {
     const int32_t *cells;   // flagged local cells (grid mode) or null
     int ncells;             // twx_fix_pair: number of series
     const int32_t *ncells_dev; // grid mode: number of flagged cells (k_compact_flags), read on the device
+    const int32_t *inv_cnt;  // grid mode: [ncell] days with tmin >= tmax found by the daily kernels
+    const int32_t *inv_day;  // grid mode: [ncell][TWX_INV_CAP] the first of them (chronological day index, unordered)
     double *scratch;        // [gridDim][2][ndays]
     int32_t *lists;         // [gridDim][ndays]
     double *series_min;     // twx_fix_pair: [nseries][ndays] in/out (chronological), else null
@@ -1064,6 +1080,42 @@ __device__ void fix_series_block(double *tmin, double *tmax, int32_t *list, cons
     __syncthreads();
 }
 
+// lane `l` (wave-uniform) of a double
+__device__ __forceinline__ double readlane_dv(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// One variable's (weight, station) list of a (cell, month) in ascending station-index order -- from the tile-month's table
+// (GwrWs.zd: the rows with a non-zero weight; a zero weight adds exactly nothing) or from the rank-ordered hat row through
+// perm -- built by ONE wave (ordered compaction by ballot): what the fixers sum a day's value with, bit for bit the value
+// k_daily_tile / the gather kernels produced.
+__device__ __forceinline__ void fix_month_list(const SelWs &w, const GwrWs &g, int64_t lc, int64_t tl, int ci, int m0, int lane,
+                                               double *zl, int *jl, int *nl)
+{
+    const int ka = w.ka[lc * 12 + m0];
+    const int64_t tm = tl * 12 + m0;
+    const int nu = (g.use_table && g.nurow2[tm] >= 0) ? g.nurow[tm] : -1;
+    const int nrow = nu >= 0 ? nu : g.kp[lc];
+    int n = 0;
+    for (int u0 = 0; u0 < nrow; u0 += 64) {
+        const int u = u0 + lane;
+        double z = 0.0;
+        int j = 0;
+        if (u < nrow) {
+            if (nu >= 0) { z = g.zd[twx_zd_index(tm, ci) + twx_zd_row(u)]; j = g.urow[tm * TWX_UROWS + u]; }
+            else { const int r = g.perm[lc * w.ksel + u]; z = r < ka ? g.z[(lc * 12 + m0) * TWX_KZ + r] : 0.0; j = w.near_idx[lc * w.ksel + r]; }
+        }
+        const bool f = z != 0.0;
+        const unsigned long long b = __ballot(f);
+        if (f) { const int p = n + __popcll(b & ((1ull << lane) - 1ull)); zl[p] = z; jl[p] = j; }
+        n += __popcll(b);
+    }
+    if (lane == 0) *nl = n;
+}
+
 // 8 waves per flagged cell (TWX_FIX_THREADS): the recompute is a chain of gathers per day (memory latency), and a tile has
 // fewer flagged cells than the GPU has CUs (C4 tile: 229): 4 waves per cell 2.36 ms, 8 waves 1.54, 16 waves 1.64
 __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
@@ -1082,38 +1134,16 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
     const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
+        if (fa.inv_cnt[lc] <= TWX_INV_CAP && stn.ymsum && da.norm_ny > 0) continue;   // fixed from its windows by k_fix_sparse
         const int64_t c = wn.cell0 + lc;
         const int rr = (int)(c / src.X), qq = (int)(c % src.X);
         const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
         const int ci = (rr % src.ts) * src.ts + (qq % src.ts);
         // Recompute both series with the bits k_daily_tile / the gather kernels produced: per month the cell's
-        // (weight, station) list in ascending station-index order -- from the tile-month's table (GwrWs.zd: the rows
-        // with a non-zero weight; a zero weight adds exactly nothing) or from the rank-ordered hat row through perm --
-        // then one fma chain per day.  Waves 0 / 1 build the Tmin / Tmax list, every thread takes days.
+        // (weight, station) lists (fix_month_list), then one fma chain per day.  Waves 0 / 1 build the Tmin / Tmax list,
+        // every thread takes days.
         for (int m0 = 0; m0 < 12; ++m0) {
-            if (wvi < 2) {
-                const SelWs &w = wvi ? wx : wn;
-                const GwrWs &g = wvi ? gx : gn;
-                const int ka = w.ka[lc * 12 + m0];
-                const int64_t tm = tl * 12 + m0;
-                const int nu = (g.use_table && g.nurow2[tm] >= 0) ? g.nurow[tm] : -1;
-                const int nrow = nu >= 0 ? nu : g.kp[lc];
-                int n = 0;
-                for (int u0 = 0; u0 < nrow; u0 += 64) {
-                    const int u = u0 + lane;
-                    double z = 0.0;
-                    int j = 0;
-                    if (u < nrow) {
-                        if (nu >= 0) { z = g.zd[twx_zd_index(tm, ci) + twx_zd_row(u)]; j = g.urow[tm * TWX_UROWS + u]; }
-                        else { const int r = g.perm[lc * w.ksel + u]; z = r < ka ? g.z[(lc * 12 + m0) * TWX_KZ + r] : 0.0; j = w.near_idx[lc * w.ksel + r]; }
-                    }
-                    const bool f = z != 0.0;
-                    const unsigned long long b = __ballot(f);
-                    if (f) { const int p = n + __popcll(b & ((1ull << lane) - 1ull)); s_zl[wvi][p] = z; s_jl[wvi][p] = j; }
-                    n += __popcll(b);
-                }
-                if (lane == 0) s_nl[wvi] = n;
-            }
+            if (wvi < 2) fix_month_list(wvi ? wx : wn, wvi ? gx : gn, lc, tl, ci, m0, lane, s_zl[wvi], s_jl[wvi], &s_nl[wvi]);
             __syncthreads();
             const int nn = s_nl[0], nx = s_nl[1];
             const double zcn = gn.zc[lc * 12 + m0], zcx = gx.zc[lc * 12 + m0];
@@ -1160,6 +1190,165 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
                     if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(tmin[d]);
                     if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = pack_i16(tmax[d]);
                 }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_fix_sparse: the same fixer for a cell with at most TWX_INV_CAP invalid days, from those days alone.
+//
+// k_fix_cells recomputes a flagged cell's WHOLE series -- 25 203 days x ~150 terms -- although the fixer only touches the
+// invalid days and reads the +-tail days around each (interp_tair.py:173-195), and the normals recompute (:583-590)
+// only needs per-(year, month) sums.  A tile whose cells are mostly flagged (one day in 69 years is enough) would spend
+// several times its whole interpolation in that recompute.  Here:
+//   * the invalid days come from the daily kernels themselves (note_invalid_day: the exact fp64 test vn >= vx at the
+//     moment the value is packed), sorted ascending;
+//   * only the days of their windows are recomputed (same lists, same fma chain, same bits as the daily kernels);
+//   * the sequential fix runs on those (earlier fixes feed later windows: one thread, day order);
+//   * the normals are the linear form  sum_{d in (y,m)} daily[d] = sum_j z_j S_j[y][m] + n zc  with the per-station
+//     sums S of observations over every (year, month) of the normals period precomputed at twx_set_stations
+//     (StnDev.ymsum), plus the changes of the fixed days.  The f8 normals differ from a day-by-day sum in the last
+//     bits (f4 outputs: the same value unless it sits on a rounding boundary).
+// One work-group of 256 threads per flagged cell (grid-stride), scratch [gridDim][2][ndays] as k_fix_cells.
+// ---------------------------------------------------------------------------------
+#define TWX_NORM_NY_MAX 40
+#define TWX_FIX_LCAP (TWX_MAX_NNGHS + 8)                     // entries of a month's (weight, station) list
+__global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx, GwrWs gn, GwrWs gx,
+                                                    DayAxis da, twx_grid_out out, FixArgs fa)
+{
+    __shared__ int s_inv[TWX_INV_CAP], s_sorted[TWX_INV_CAP];
+    __shared__ double s_fmin[TWX_INV_CAP], s_fmax[TWX_INV_CAP];  // the fixed values of the invalid days, by position in s_sorted
+    __shared__ double s_zl[12][2][TWX_FIX_LCAP];              // all twelve months' lists of both variables
+    __shared__ int s_jl[12][2][TWX_FIX_LCAP];
+    __shared__ int s_nl[12][2], s_err;
+    __shared__ double s_ym[2][12][TWX_NORM_NY_MAX];          // per variable: sum of the (fixed) daily values of (month, year)
+    if (!stn.ymsum || da.norm_ny <= 0 || da.norm_ny > TWX_NORM_NY_MAX || 2 * da.tail + 1 > 64) return;   // (k_fix_cells takes every cell then)
+    double *tmin = fa.scratch + (size_t)blockIdx.x * 2 * da.ndays;
+    double *tmax = tmin + da.ndays;
+    const int64_t yx = (int64_t)src.Y * src.X;
+    const int ncells = *fa.ncells_dev;
+    const int t = threadIdx.x, lane = t & 63, wvi = t >> 6;
+    const int ny = da.norm_ny, W = 2 * da.tail + 1;
+    for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
+        const int64_t lc = fa.cells[it];
+        const int ninv = fa.inv_cnt[lc];
+        if (ninv > TWX_INV_CAP || ninv <= 0) continue;       // (uniform) the full recompute takes this cell
+        const int64_t c = wn.cell0 + lc;
+        const int rr = (int)(c / src.X), qq = (int)(c % src.X);
+        const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
+        const int ci = (rr % src.ts) * src.ts + (qq % src.ts);
+        // the invalid days in ascending order (rank by counting: they are distinct)
+        if (t < ninv) s_inv[t] = fa.inv_day[lc * TWX_INV_CAP + t];
+        // the (weight, station) lists of the twelve months, both variables: 24 lists, one wave each
+        for (int q = wvi; q < 24; q += 4) {
+            const int m0 = q >> 1, v = q & 1;
+            fix_month_list(v ? wx : wn, v ? gx : gn, lc, tl, ci, m0, lane, s_zl[m0][v], s_jl[m0][v], &s_nl[m0][v]);
+        }
+        __syncthreads();
+        if (t < ninv) {
+            const int mine = s_inv[t];
+            int pos = 0;
+            for (int q = 0; q < ninv; ++q) pos += s_inv[q] < mine ? 1 : 0;
+            s_sorted[pos] = mine;
+        }
+        __syncthreads();
+        // the days of the invalid days' windows (overlapping windows write the same bits twice)
+        for (int p = t; p < ninv * W; p += 256) {
+            const int d = s_sorted[p / W] - da.tail + p % W;
+            if (d < 0 || d >= da.ndays) continue;
+            const int m0 = da.day_month[d] - 1, dm = da.chron2mm[d];
+            const int nn = s_nl[m0][0], nx = s_nl[m0][1];
+            const double *zn = s_zl[m0][0], *zx = s_zl[m0][1];
+            const int *jn = s_jl[m0][0], *jx = s_jl[m0][1];
+            double an = 0.0, ax = 0.0;
+#pragma unroll 4
+            for (int i = 0; i < nn; ++i) an = fma(zn[i], (double)stn.obs[(size_t)jn[i] * da.ndays + dm], an);
+#pragma unroll 4
+            for (int i = 0; i < nx; ++i) ax = fma(zx[i], (double)stx.obs[(size_t)jx[i] * da.ndays + dm], ax);
+            tmin[d] = an + gn.zc[lc * 12 + m0];
+            tmax[d] = ax + gx.zc[lc * 12 + m0];
+        }
+        // sum of every month's daily values per year of the normals period, from the stations' (month, year) sums
+        for (int q = t; q < 24 * ny; q += 256) {
+            const int y = q % ny, mv = q / ny, m0 = mv >> 1, v = mv & 1;
+            const double *S = (v ? stx.ymsum : stn.ymsum) + (size_t)m0 * ny + y;
+            const int n = s_nl[m0][v];
+            const double *zl = s_zl[m0][v];
+            const int *jl = s_jl[m0][v];
+            double acc = 0.0;
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) acc = fma(zl[i], S[(size_t)jl[i] * 12 * ny], acc);
+            s_ym[v][m0][y] = acc + (double)da.ym_cnt[y * 12 + m0] * (v ? gx.zc[lc * 12 + m0] : gn.zc[lc * 12 + m0]);
+        }
+        if (t == 0) s_err = 0;
+        __syncthreads();
+        // the fix itself: day order, earlier fixes feed later windows (interp_tair.py:177-195).  One wave: lane = day of
+        // the window (raw values from the scratch, which is not written here; the days fixed so far -- found by bisection
+        // in the sorted list -- from LDS), wave sums instead of a 31-step serial scan
+        if (wvi == 0) {
+            for (int q = 0; q < ninv; ++q) {
+                const int x = s_sorted[q];
+                int s0 = x - da.tail, e = x + da.tail + 1;
+                if (s0 < 0) s0 = 0;
+                if (e > da.ndays) e = da.ndays;
+                const int d = s0 + lane;
+                double a = 0.0, b = 0.0;
+                bool in = d < e;
+                if (in) {
+                    a = tmin[d]; b = tmax[d];
+                    int lo = 0, hi = q;                       // is d one of the days already fixed (s_sorted[0 .. q))?
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_sorted[mid] < d) lo = mid + 1; else hi = mid; }
+                    if (lo < q && s_sorted[lo] == d) { a = s_fmin[lo]; b = s_fmax[lo]; }
+                }
+                const bool ok = in && a < b;
+                const int cnt = __popcll(__ballot(ok));
+                const double sum = wave_sum(ok ? b - a : 0.0);
+                if (cnt == 0) { if (lane == 0) s_err = 1; break; }
+                // this day's own (raw) values sit in lane x - s0
+                const double xa = readlane_dv(a, x - s0), xb = readlane_dv(b, x - s0);
+                const double tavg = (xa + xb) / 2.0, half = (sum / (double)cnt) / 2.0;
+                if (lane == 0) {
+                    const double nmin = tavg - half, nmax = tavg + half;
+                    const int y = da.day_year[x] - da.norm_y0, m = da.day_month[x] - 1;
+                    if (y >= 0 && y < ny) { s_ym[0][m][y] += nmin - xa; s_ym[1][m][y] += nmax - xb; }
+                    s_fmin[q] = nmin; s_fmax[q] = nmax;
+                }
+                __builtin_amdgcn_wave_barrier();             // (LDS operations of one wave execute in order)
+            }
+        }
+        __syncthreads();
+        if (s_err) {
+            // the reference raises (interp_tair.py:192) -> the worker leaves fill values
+            if (t == 0) {
+                if (out.status) out.status[c] = TWX_CELL_FIXER;
+                if (out.ninvalid) out.ninvalid[c] = TWX_FILL_I4;
+            }
+            for (int m = t; m < 12; m += 256) {
+                if (out.norm_tmin) out.norm_tmin[m * yx + c] = TWX_FILL_F4;
+                if (out.se_tmin) out.se_tmin[m * yx + c] = TWX_FILL_F4;
+                if (out.norm_tmax) out.norm_tmax[m * yx + c] = TWX_FILL_F4;
+                if (out.se_tmax) out.se_tmax[m * yx + c] = TWX_FILL_F4;
+            }
+            for (int d = t; d < da.ndays; d += 256) {
+                if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = TWX_FILL_I2;
+                if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = TWX_FILL_I2;
+            }
+        } else {
+            if (t == 0 && out.ninvalid) out.ninvalid[c] = ninv;
+            if (t < 24) {       // normals: mean over the years of the (year, month) means (interp_tair.py:583-590)
+                const int v = t / 12, m = t - v * 12;
+                double acc = 0.0;
+                for (int y = 0; y < ny; ++y) acc += s_ym[v][m][y] / (double)da.ym_cnt[y * 12 + m];
+                const double nrm = acc / (double)ny;
+                float *dst = v ? out.norm_tmax : out.norm_tmin;
+                if (dst) dst[m * yx + c] = (float)nrm;
+            }
+            for (int q = t; q < ninv; q += 256) {
+                const int d = s_sorted[q];
+                if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(s_fmin[q]);
+                if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = pack_i16(s_fmax[q]);
             }
         }
         __syncthreads();

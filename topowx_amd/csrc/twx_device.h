@@ -28,6 +28,8 @@ struct StnDev {
     const double2 *mon_s;                                       // [n][12] (lst, norm)
     const double *coslat;                                       // cos(lat * TWX_DEG2RAD) [n] (k_stn_coslat; k_tile_cand's fp32 bound)
     const float *obs;                                           // [n][ndays_mm] month-major days, or null
+    const double *ymsum;                                        // [n][12][norm_ny] sum of a station's observations over every (month, year) of
+                                                                // the normals period (k_fix_sparse), or null
 };
 
 // ---- where the cells of a launch come from -------------------------------------

@@ -44,7 +44,7 @@ struct DevBuf {
 struct VarData {
     int n = 0, kmax = 0;
     bool has_obs = false;
-    DevBuf cols, obs;
+    DevBuf cols, obs, ymsum;
     StnDev dev{};
 };
 
@@ -90,6 +90,8 @@ struct twx_ctx {
     // day axis
     int64_t ndays = 0;
     std::vector<int32_t> day_month, day_year, mm2chron, chron2mm;
+    std::vector<int32_t> ym_start, ym_cnt;   // host copies of DayAxis.ym_start / ym_cnt ((year, month) runs of the normals period)
+    int norm_y0 = 0, norm_ny = 0;
     DevBuf day_dev;
     DayAxis da{};
     // (year, month) groups of the aggregation entry (tiling.py:1085-1118)
@@ -97,12 +99,12 @@ struct twx_ctx {
     AggAxis agg{};
     hipEvent_t ev_agg_a = nullptr, ev_agg_b = nullptr;
     // scratch for the point entries / fixer
-    DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list;
+    DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list, inv_cnt, inv_day;
     DevBuf grid_in, grid_out;     // persistent device images of the host-buffer grid entry
     // every context-level device buffer (the per-variable ones live in var[] / work[]): twx_destroy releases these
     std::vector<DevBuf *> all_bufs()
     {
-        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list, &stats,
+        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list, &inv_cnt, &inv_day, &stats,
                 &grid_in, &grid_out};
     }
     std::string err;
@@ -487,7 +489,7 @@ void twx_destroy(twx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     while (!ctx->streams.empty()) twx_stream_destroy(ctx->streams.back());   // (removes itself from the list)
-    for (int v = 0; v < 2; ++v) { ctx->var[v].cols.release(); ctx->var[v].obs.release(); ctx->work[v].release(); }
+    for (int v = 0; v < 2; ++v) { ctx->var[v].cols.release(); ctx->var[v].obs.release(); ctx->var[v].ymsum.release(); ctx->work[v].release(); }
     for (DevBuf *b : ctx->all_bufs()) b->release();
     for (auto &e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->ev_total_a) (void)hipEventDestroy(ctx->ev_total_a);
@@ -546,7 +548,8 @@ int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const in
         HIPCHK(hipMemcpy(d_yc, yc.data(), yc.size() * 4, hipMemcpyHostToDevice));
     }
     da.ndays = (int)ndays; da.mm2chron = d_mm2c; da.chron2mm = d_c2mm; da.day_month = d_dm; da.day_year = d_dy;
-    da.tail = ctx->p.fixer_tail; da.norm_ny = ny; da.ym_start = d_ys; da.ym_cnt = d_yc;
+    da.tail = ctx->p.fixer_tail; da.norm_ny = ny; da.norm_y0 = ny ? y0 : 0; da.ym_start = d_ys; da.ym_cnt = d_yc;
+    ctx->ym_start = ys; ctx->ym_cnt = yc; ctx->norm_y0 = ny ? y0 : 0; ctx->norm_ny = ny;
 
     // _TairAggregate.__init__: groups = unique years x unique months, year-major; days ascending
     {
@@ -642,7 +645,7 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     // twx_interp_grid_dev) can read cos(lat) -- k_tile_cand's conservative radius -- before it is written, and so
     // that an asynchronous fault of this kernel is reported by this call
     HIPCHK(hipStreamSynchronize(nullptr));
-    s.obs = nullptr;
+    s.obs = nullptr; s.ymsum = nullptr;
     vd.n = (int)n; vd.kmax = s.kmax; vd.has_obs = false;
     if (t->obs) {
         if (ctx->ndays <= 0) return fail(ctx, "twx_set_stations: call twx_set_days before passing observations");
@@ -670,6 +673,26 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
         HIPCHK(hipMemcpy(vd.obs.p, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
         s.obs = vd.obs.as<float>();
         vd.has_obs = true;
+        // per station: the sum of its observations over every (month, year) of the normals period -- what the sparse fixer
+        // forms a cell's recomputed normals from (k_fix_sparse) instead of re-evaluating ~11 000 daily values per cell
+        s.ymsum = nullptr;
+        const int ny = ctx->norm_ny;
+        bool full_years = ny > 0;
+        for (int q = 0; q < ny * 12; ++q) full_years = full_years && ctx->ym_cnt[q] > 0;
+        if (full_years) {
+            std::vector<double> ym(n * 12 * (size_t)ny, 0.0);
+            for (int y = 0; y < ny; ++y)
+                for (int m = 0; m < 12; ++m) {
+                    const int d0 = ctx->ym_start[y * 12 + m], cntd = ctx->ym_cnt[y * 12 + m];
+                    for (int d = d0; d < d0 + cntd; ++d) {
+                        const float *row = t->obs + (size_t)d * n;
+                        for (size_t j = 0; j < n; ++j) ym[(j * 12 + m) * ny + y] += (double)row[j];
+                    }
+                }
+            HIPCHK(vd.ymsum.ensure(ym.size() * 8));
+            HIPCHK(hipMemcpy(vd.ymsum.p, ym.data(), ym.size() * 8, hipMemcpyHostToDevice));
+            s.ymsum = vd.ymsum.as<double>();
+        }
     }
     return 0;
 }
@@ -1222,6 +1245,10 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             HIPCHK(ctx->flags.ensure((size_t)ncell * 4 + 256));
             HIPCHK(ctx->flag_list.ensure((size_t)ncell * 4 + 256));
             HIPCHK(hipMemsetAsync(ctx->flags.p, 0, (size_t)ncell * 4 + 256, stream));
+            HIPCHK(ctx->inv_cnt.ensure((size_t)ncell * 4));
+            HIPCHK(ctx->inv_day.ensure((size_t)ncell * TWX_INV_CAP * 4));
+            HIPCHK(hipMemsetAsync(ctx->inv_cnt.p, 0, (size_t)ncell * 4, stream));
+            int32_t *d_icnt = ctx->inv_cnt.as<int32_t>(), *d_iday = ctx->inv_day.as<int32_t>();
             int32_t *d_flag = ctx->flags.as<int32_t>();
             int32_t *d_count = d_flag + ncell;
             {
@@ -1247,7 +1274,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                         dv.urow = wk.gw.urow; dv.nurow = wk.gw.nurow;
                     }
                     da.okc = d_okc; da.mm2chron = ctx->da.mm2chron; da.out_n = o->daily_tmin; da.out_x = o->daily_tmax;
-                    da.flag = d_flag; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0; da.ntile = ntile;
+                    da.flag = d_flag; da.inv_cnt = d_icnt; da.inv_day = d_iday; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0; da.ntile = ntile;
                     da.Y = Y; da.X = X; da.ts = ts; da.ntx = ntx; da.ndays = (int)ctx->ndays; da.nblk_max = nblk; da.gather = gather;
                     for (int m = 0; m < 13; ++m) da.moff[m] = ctx->da.moff[m];
                     if (!gather)
@@ -1255,11 +1282,11 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                         hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)((((ntile + 7) / 8) * 12 + 7) / 8 * 8 * 8 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
                     hipLaunchKernelGGL(k_daily_tile_gather, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(256), 0, stream,
                                        ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw,
-                                       ctx->work[1].gw, ctx->da, *o, d_flag, d_okc, nblk, addr64, gather);
+                                       ctx->work[1].gw, ctx->da, *o, d_flag, d_icnt, d_iday, d_okc, nblk, addr64, gather);
                 } else {
                     hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
                                        stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
-                                       ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, nblk, addr64);
+                                       ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, d_icnt, d_iday, nblk, addr64);
                 }
             }
             if (has_n && has_x) {
@@ -1270,9 +1297,12 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 HIPCHK(ctx->fix_scratch.ensure((size_t)nb * 2 * ctx->ndays * 8));
                 HIPCHK(ctx->fix_lists.ensure((size_t)nb * ctx->ndays * 4));
                 FixArgs fa{};
-                fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count;
+                fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count; fa.inv_cnt = d_icnt; fa.inv_day = d_iday;
                 fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
                 EvScope ev(ctx, stream, EV_FIX);
+                // cells with at most TWX_INV_CAP invalid days: fixed from those days' windows; the others: whole series
+                hipLaunchKernelGGL(k_fix_sparse, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws,
+                                   ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
                 hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(TWX_FIX_THREADS), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
                                    ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
             }
