@@ -49,10 +49,13 @@ extern "C" {
 #define TWX_CELL_RANGE 6        /* bandwidth above TWX_MAX_NNGHS */
 #define TWX_CELL_CAND_OVERFLOW 7 /* library limit, no reference counterpart: the candidate list of the cell's 8x8-cell tile
                                   * (stations that can be among the nearest TWX_MAX_NNGHS + 1 of any of its cells) holds
-                                  * more than 4 096 stations (512 per point in the point entries): the cell is failed
-                                  * rather than ranked from a truncated list.  Only reached by station clusters far
-                                  * denser than the grid (> 4 096 stations within ~10 km: a third of all CONUS stations
-                                  * in reach of one 8 km tile). */
+                                  * more stations than the selection kernel can rank: 15 872 per tile in the grid entries
+                                  * (a batch with a list longer than 4 096 is run a second time with longer lists and
+                                  * without the per-tile LDS tables: slower, same results), 4 096 under
+                                  * TWX_FLAG_NO_HOST_SYNC (nothing is read back, so nothing can be re-run), 512 per point
+                                  * in the point entries.  The cell is failed rather than ranked from a truncated list.
+                                  * A station table of fewer than 15 872 stations can never reach it in the grid
+                                  * entries (the reference's CONUS tables hold 11-12 000). */
 #define TWX_CELL_MASKED (-1)    /* cell outside the interpolation mask: nothing computed */
 
 /* netCDF4 default fill values the reference worker pre-fills with (step25:73-88) */

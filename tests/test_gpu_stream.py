@@ -40,25 +40,32 @@ def test_tile_stream_equals_synchronous_entry(golden_case):
     assert np.all(got[3]["status"] == -1) and np.all(got[3]["daily_tmin"] == _lib.FILL_I2)      # the fully masked tile
 
 
-@pytest.mark.parametrize("nclust,expect_range", [(1500, False), (6000, False), (14000, True)])
-def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
+def _cluster_db(base, nclust, var, with_obs):
+    """``base`` plus ``nclust`` stations inside a 0.3-degree box of the golden grid (ids sort after the base's)."""
+    from topowx_amd import stationdb as sdb, synth
+    extra = synth.make_stations((45.55, 45.85, -110.7, -110.4), nclust, 77, var, base.days, with_obs=with_obs, expand_deg=0.0)
+    extra.stns[sdb.STN_ID] = ["T%07d" % i for i in range(extra.stns.size)]           # sorts after the 'S...' ids
+    stns = np.concatenate([base.stns, extra.stns])
+    obs = np.concatenate([base.var, extra.var], axis=1) if with_obs else None
+    return sdb.StationDataWrkChk(stns, var, base.days, obs)
+
+
+@pytest.mark.parametrize("nclust,flags,overflow", [(1500, 0, False), (6000, 0, False), (14000, 0, False), (14000, "nosync", True)])
+def test_dense_station_cluster(golden_case, orc, nclust, flags, overflow):
     """A cluster of stations far denser than the tile size: the candidate lists of its tiles outgrow the 512-slot LDS
-    path.  Up to 4 096 candidates the full-list kernel ranks them (results = oracle, which searches all stations);
-    beyond that the cells fail with TWX_CELL_CAND_OVERFLOW instead of using a truncated list."""
-    from topowx_amd import _lib, stationdb as sdb, synth
+    path.  Up to 4 096 candidates the full-list kernel ranks them directly; a batch with a longer list is run again with
+    lists as long as needed (up to 15 872: the readback that sizes the kriging launches carries the longest list) --
+    results = oracle, which searches all stations.  Only where the host may not look (TWX_FLAG_NO_HOST_SYNC) the cells
+    of such a tile still fail with TWX_CELL_CAND_OVERFLOW instead of using a truncated list."""
+    from topowx_amd import _lib
     grid, tmin, _ = golden_case
-    rng = np.random.default_rng(9)
-    base = tmin.stns
-    extra = synth.make_stations((45.55, 45.85, -110.7, -110.4), nclust, 77, "tmin", expand_deg=0.0).stns
-    extra[sdb.STN_ID] = ["T%07d" % i for i in range(extra.size)]                    # sorts after the 'S...' ids
-    stns = np.concatenate([base, extra])
-    db = sdb.StationDataWrkChk(stns, "tmin", tmin.days, None)
-    ctx = _lib.Context()
+    db = _cluster_db(tmin, nclust, "tmin", False)
+    ctx = _lib.Context(flags=_lib.FLAG_NO_HOST_SYNC if flags == "nosync" else 0)
     ctx.set_stations(_lib.TMIN, db, with_obs=False)
     rs, cs = slice(30, 46), slice(44, 60)                                             # inside the cluster's box
     got = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
     ctx.close()
-    if expect_range:
+    if overflow:
         assert np.all(got["status"] == 7) and np.all(got["norm_tmin"] == _lib.FILL_F4)
         return
     assert np.all(got["status"] == 0)
@@ -66,6 +73,30 @@ def test_dense_station_cluster(golden_case, orc, nclust, expect_range):
     assert np.array_equal(want["status"], got["status"])
     assert np.abs(got["norm_tmin"].astype(np.float64) - want["norm_tmin"]).max() < 1e-4
     assert np.abs(got["se_tmin"].astype(np.float64) - want["se_tmin"]).max() < 1e-4
+
+
+def test_dense_cluster_daily_through_long_lists(golden_case, orc):
+    """Daily output of a batch that was re-run with long candidate lists (no per-tile LDS tables: per-cell pair distances,
+    gather sums, fixer lists from the rank-order hat rows): same values as the oracle."""
+    import make_golden
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    dbn = _cluster_db(tmin, 14000, "tmin", True)
+    dbx = make_golden.lowered_tmax(_cluster_db(tmax, 14000, "tmax", True))          # (a few tmin >= tmax days: the fixer)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, dbn)
+    ctx.set_stations(_lib.TMAX, dbx)
+    rs, cs = slice(32, 40), slice(44, 60)
+    got = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    ctx.close()
+    want = orc.interp_grid(orc.Db(dbn), orc.Db(dbx), orc.params(), grid, daily=True, nthreads=8, rows=rs, cols=cs)
+    assert np.array_equal(got["status"], want["status"]) and np.all(got["status"] == 0)
+    assert np.array_equal(got["ninvalid"], want["ninvalid"]) and want["ninvalid"].max() > 0
+    for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+        assert np.abs(got[k].astype(np.float64) - want[k]).max() < 1e-4, k
+    for k in ("daily_tmin", "daily_tmax"):
+        dd = np.abs(got[k].astype(int) - want[k].astype(int))
+        assert dd.max() <= 1 and (dd == 0).mean() > 0.9999
 
 
 def test_step25_resume_and_tile_log(golden_case, tmp_path):

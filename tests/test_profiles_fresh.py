@@ -25,3 +25,16 @@ def test_committed_hbm_traffic_belongs_to_the_kernels_in_the_tree():
     import bench
     traffic, daily, src = bench.latest_traffic()
     assert traffic > 0 and daily > 0 and "STALE" not in src
+
+
+def test_committed_bench_lines_quote_counters_of_their_own_kernels():
+    """The newest committed bench lines were produced after the counter passes of the same collection
+    (tests/tools/collect_profiles.sh runs the PMC passes first): none of them carries the STALE marker, and the C4 tile's
+    traffic record belongs to the kernels in the tree as well."""
+    import kernel_hash
+    for pat in ("r*_bench.json", "r*_bench_profiled.json", "r*_bench_daily_profiled.json", "r*_c4_stream_daily.json"):
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        assert paths, pat
+        assert "STALE" not in open(paths[-1]).read(), "%s quotes counters of other kernel sources" % os.path.basename(paths[-1])
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_daily_traffic.json")))
+    assert paths and json.load(open(paths[-1])).get("kernel_sources_sha16") == kernel_hash.kernel_sources_sha16()

@@ -3,6 +3,11 @@
 # the C4 daily / streamed record, the SQ counter tables and the config-5 cross-validation timings.
 # gpurun -- bash tests/tools/collect_round.sh
 set -u
+mkdir -p gpurun_out
+# the C4 tile's counter passes first (bench.py's configs.c4_tile.traffic quotes the newest profiles/r*_c4_daily_traffic.json)
+bash tests/tools/collect_c4_traffic.sh > gpurun_out/collect_c4.log 2>&1
+NEWEST=$(ls profiles/r*_c4_daily_traffic.json 2>/dev/null | sort | tail -1)
+[ -n "$NEWEST" ] && cp gpurun_out/prof_c4/c4_daily_traffic.json $NEWEST
 bash tests/tools/collect_profiles.sh > gpurun_out/collect_profiles.log 2>&1
 python3 bench.py --steps 6 --warmup 2 --daily-years 69 --stream-tiles 4 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/prof_round/c4_stream_daily.json
 bash tests/tools/collect_sq.sh sq_krig > /dev/null 2>&1

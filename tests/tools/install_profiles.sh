@@ -22,3 +22,6 @@ cp $P/closepair_scan.json profiles/${R}_closepair_scan.json
 cp $P/closepair_scan_fast.json profiles/${R}_closepair_scan_fast_only.json
 cp $P/f64_cost.json profiles/${R}_f64_build_cost.json
 cp topowx_amd/libtwxhip.resources.txt profiles/${R}_isa_resources.txt
+cp gpurun_out/prof_c4/c4_daily_traffic.json profiles/${R}_c4_daily_traffic.json
+cp gpurun_out/prof_c4/pmc_daily_FETCH_SIZE.csv profiles/${R}_c4_daily_pmc_FETCH_SIZE.csv
+cp gpurun_out/prof_c4/pmc_daily_WRITE_SIZE.csv profiles/${R}_c4_daily_pmc_WRITE_SIZE.csv

@@ -84,6 +84,7 @@ struct EvPair { hipEvent_t a, b; int kind; };
 
 struct twx_ctx {
     int device = 0;
+    bool select_lds_set = false;   // k_select<1,1> may use TWX_CAND_LDS_MAX candidates' worth of dynamic LDS (set on first need)
     twx_params p{};
     VarData var[2];
     Work work[2];
@@ -306,15 +307,27 @@ void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const 
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
 int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_t ncell, int64_t tile0,
-                  int64_t ntile, int ksel, bool need_gwr, hipStream_t stream, bool fit_vario = false)
+                  int64_t ntile, int ksel, bool need_gwr, hipStream_t stream, bool fit_vario = false, int cmax_retry = 0)
 {
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
     const int nblk = (int)std::min<int64_t>(ntile, 2048);
-    // Candidate lists have a fixed stride (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW): the host
-    // never looks at them.  The bucket counts are read back once (exact kriging grids) unless TWX_FLAG_NO_HOST_SYNC.
-    w.cmax = src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX;
-    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0, src.mode == 0)) return -1;
+    // Candidate lists have a fixed stride, chosen before anything is known about the batch.  The longest list of the batch
+    // comes back with the bucket counts (one readback per (batch, variable), unless TWX_FLAG_NO_HOST_SYNC): a grid batch
+    // with a tile that holds more than TWX_CAND_MAX candidates (thousands of stations inside one tile's search radius) is
+    // run again with the stride that fits, up to TWX_CAND_LDS_MAX (what k_select<1,1> can rank in LDS) -- cmax_retry.  Only
+    // past that -- or without the readback -- do a tile's cells fail with TWX_CELL_CAND_OVERFLOW.
+    w.cmax = cmax_retry ? cmax_retry : (src.mode == 1 ? TWX_CAND_SMALL : TWX_CAND_MAX);
+    const bool long_lists = w.cmax > TWX_CAND_MAX;           // (retry batch: no per-tile LDS tables, k_cell_dist / gather paths)
+    if (long_lists) {
+        bool &lds_set = ctx->select_lds_set;                 // > 64 KB of dynamic LDS has to be asked for, once
+        if (!lds_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       TWX_CAND_LDS_MAX * (int)(sizeof(double) + 2)));
+            lds_set = true;
+        }
+    }
+    if (prepare_work(ctx, v, cell0, ncell, tile0, ntile, ksel, nblk, need_gwr, fit_vario, need_gwr && src.mode == 0 && !long_lists, src.mode == 0)) return -1;
     HIPCHK(hipMemsetAsync(w.small.p, 0, 256, stream));
     {
         EvScope ev(ctx, stream, EV_TILE);
@@ -338,7 +351,7 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems -- and the smallest
         // pair distance by rank, which k_bucket_items needs to route ill-conditioned systems to the fp64 build
         EvScope ev(ctx, stream, EV_UK);
-        if (w.ws.near_pos) {     // grid mode: per tile, from a table of the tile's station pairs; hminp in a launch of its own
+        if (w.ws.near_pos && !long_lists) {     // grid mode: per tile, from a table of the tile's station pairs; hminp in a launch of its own
             hipLaunchKernelGGL(k_tile_dist<0>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
             hipLaunchKernelGGL(k_tile_dist<1>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
         } else
@@ -348,12 +361,15 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     HIPCHK(ctx->stats.ensure(64));
     hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
-    int32_t cnt_host[16];
+    int32_t small_host[32];                                  // [0] longest candidate list, [16..31] bucket counts
     const int32_t *cnt = nullptr;
     if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
-        HIPCHK(hipMemcpyAsync(cnt_host, w.ws.bucket_cnt, sizeof cnt_host, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(small_host, w.small.p, sizeof small_host, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        cnt = cnt_host;
+        cnt = small_host + 16;
+        if (src.mode == 0 && !cmax_retry && small_host[0] > w.cmax && w.cmax < TWX_CAND_LDS_MAX)
+            return run_select_uk(ctx, v, src, cell0, ncell, tile0, ntile, ksel, need_gwr, stream, fit_vario,
+                                 std::min((small_host[0] + 255) / 256 * 256, TWX_CAND_LDS_MAX));
     }
     if (cnt && cnt[TWX_BUCKET_F64] + cnt[TWX_BUCKET_F64 + 1] > 0) {
         // this batch has systems on the fp64 covariance build: the fp64 pair distances of their cells, once per cell
@@ -1219,8 +1235,11 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             s.lst = v == 0 ? g->lst_night : g->lst_day;
             s.do_krig = 1; s.do_anom = daily ? 1 : 0; s.do_vario = 1;
             if (run_select_uk(ctx, v, s, cell0, ncell, tile0, ntile, pick_ksel(ctx, v, 0), daily, stream)) return -1;
-            ctx->work[v].gw.use_table = use_table ? 1 : 0;
         }
+        // (a batch that had to be re-run with longer candidate lists than the per-tile LDS tables index takes the gather paths)
+        const bool long_lists = (has_n && ctx->work[0].cmax > TWX_CAND_MAX) || (has_x && ctx->work[1].cmax > TWX_CAND_MAX);
+        const bool use_table_b = use_table && !long_lists;
+        for (int v = 0; v < 2; ++v) ctx->work[v].gw.use_table = use_table_b ? 1 : 0;
         if (daily) {
             // both variables' tables are numbered before any hat row is computed: a (tile, month) goes through the
             // tables only when BOTH unions fit (k_daily_tile takes both variables of a block or neither)
@@ -1228,7 +1247,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 if ((v == 0 ? has_n : has_x) && run_gwr_prep(ctx, v, src[v], stream)) return -1;
             for (int v = 0; v < 2; ++v) {
                 if (!(v == 0 ? has_n : has_x)) continue;
-                ctx->work[v].gw.nurow2 = use_table ? ctx->work[1 - v].gw.nurow : nullptr;
+                ctx->work[v].gw.nurow2 = use_table_b ? ctx->work[1 - v].gw.nurow : nullptr;
                 if (run_gwr(ctx, v, src[v], nullptr, stream, false)) return -1;
             }
         }
@@ -1265,7 +1284,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                     int32_t *d_okc = ctx->flag_list.as<int32_t>();      // free until k_compact_flags (which runs after)
                     hipLaunchKernelGGL(k_daily_ok, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, ctx->work[0].ws,
                                        ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, d_okc);
-                    const int gather = (addr64 || (ctx->p.flags & TWX_FLAG_DAILY_GATHER)) ? 1 : 0;
+                    const int gather = (addr64 || (ctx->p.flags & TWX_FLAG_DAILY_GATHER) || long_lists) ? 1 : 0;
                     DtArgs da{};
                     for (int v = 0; v < 2; ++v) {
                         DtVar &dv = v == 0 ? da.n : da.x;

@@ -19,7 +19,8 @@
 
 struct SelWs {
     int ksel;            // nearest-list length kept per cell (<= TWX_KSEL_MAX)
-    int cmax;            // candidate slots per tile (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW)
+    int cmax;            // candidate slots per tile of this batch (a tile with more candidates fails its cells with TWX_CELL_CAND_OVERFLOW;
+                         // run_select_uk re-runs a grid batch with longer lists before it lets that happen)
     int init_nnghs;
     int reserved0;
     int64_t cell0;       // first global cell id of the batch
@@ -216,6 +217,9 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
 #ifndef TWX_CAND_MAX
 #define TWX_CAND_MAX 4096    // candidate slots per tile in grid mode (k_select<1> ranks up to this many in LDS; round 3: 2 048)
 #endif
+// a grid batch whose longest list does not fit is run again with up to this many slots (run_select_uk): what k_select<1,1>
+// can hold in a work-group's 160 KB of LDS at 10 bytes per candidate, beside its 3 KB of static arrays
+#define TWX_CAND_LDS_MAX 15872
 struct SmoothOut { int status; int k; };
 
 // v with lane L (wave-uniform index) replaced by the wave-uniform value x; lane L of v as a uniform value.  An fp64
