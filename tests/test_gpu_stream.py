@@ -40,10 +40,10 @@ def test_tile_stream_equals_synchronous_entry(golden_case):
     assert np.all(got[3]["status"] == -1) and np.all(got[3]["daily_tmin"] == _lib.FILL_I2)      # the fully masked tile
 
 
-def _cluster_db(base, nclust, var, with_obs):
+def _cluster_db(base, nclust, var, with_obs, box=(45.55, 45.85, -110.7, -110.4)):
     """``base`` plus ``nclust`` stations inside a 0.3-degree box of the golden grid (ids sort after the base's)."""
     from topowx_amd import stationdb as sdb, synth
-    extra = synth.make_stations((45.55, 45.85, -110.7, -110.4), nclust, 77, var, base.days, with_obs=with_obs, expand_deg=0.0)
+    extra = synth.make_stations(box, nclust, 77, var, base.days, with_obs=with_obs, expand_deg=0.0)
     extra.stns[sdb.STN_ID] = ["T%07d" % i for i in range(extra.stns.size)]           # sorts after the 'S...' ids
     stns = np.concatenate([base.stns, extra.stns])
     obs = np.concatenate([base.var, extra.var], axis=1) if with_obs else None
@@ -73,6 +73,28 @@ def test_dense_station_cluster(golden_case, orc, nclust, flags, overflow):
     assert np.array_equal(want["status"], got["status"])
     assert np.abs(got["norm_tmin"].astype(np.float64) - want["norm_tmin"]).max() < 1e-4
     assert np.abs(got["se_tmin"].astype(np.float64) - want["se_tmin"]).max() < 1e-4
+
+
+def test_cluster_beyond_the_longest_list_still_fails_cleanly(golden_case, orc):
+    """17 000 stations inside a 0.1-degree box: the tiles at its centre have more candidates than the re-run can rank
+    (15 872).  Their cells fail with TWX_CELL_CAND_OVERFLOW; the other cells of the same batch are computed (== oracle)."""
+    from topowx_amd import _lib
+    grid, tmin, _ = golden_case
+    db = _cluster_db(tmin, 17000, "tmin", False, box=(45.65, 45.75, -110.6, -110.5))
+    r = int(np.abs(grid["lat"] - 45.7).argmin()) // 8 * 8
+    c = int(np.abs(grid["lon"] + 110.55).argmin()) // 8 * 8
+    rs, cs = slice(r - 24, r + 32), slice(c - 24, c + 32)                             # 7 x 7 tiles around the centre
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, db, with_obs=False)
+    got = ctx.interp_grid(grid, variables=("tmin",), rows=rs, cols=cs)
+    ctx.close()
+    st = got["status"]
+    assert set(np.unique(st)) == {0, 7} and st[24:32, 24:32].min() == 7               # the central tile, at least
+    assert np.all(got["norm_tmin"][:, st == 7] == _lib.FILL_F4)
+    want = orc.interp_grid(orc.Db(db), None, orc.params(), grid, nthreads=8, rows=rs, cols=cs)
+    assert np.all(want["status"] == 0)                                                 # (the reference has no such limit)
+    ok = st == 0
+    assert np.abs(got["norm_tmin"].astype(np.float64) - want["norm_tmin"])[:, ok].max() < 1e-4
 
 
 def test_dense_cluster_daily_through_long_lists(golden_case, orc):
