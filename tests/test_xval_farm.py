@@ -239,3 +239,54 @@ def test_two_rank_xval_farm_equals_single_process(tmp_path):
         np.testing.assert_array_equal(got["optim"], want_optim)
         np.testing.assert_array_equal(got["vario"], want_vario)          # step22: every rank ends with the same table
     assert len(chosen) >= 1 and all(set(v) <= {35, 57} for v in chosen.values())
+
+
+def _set_optim_nstns_masked_loop(stns, stn_ids, mae, ladder, namer):
+    """optimize.py:268-374 statement by statement (division loop, masked mean, first minimum) -- the checker of the
+    batched ``xval.set_optim_nstns``."""
+    from topowx_amd import stationdb as sdb
+    ladder, ids = np.asarray(ladder), np.asarray(stn_ids)
+    pos = {s: i for i, s in enumerate(stns[sdb.STN_ID])}
+    div_of_xval = stns[sdb.CLIMDIV][[pos[s] for s in ids]]
+    climdiv_stns = stns[sdb.CLIMDIV]
+    chosen = {}
+    for clim_div in np.unique(climdiv_stns[np.isfinite(climdiv_stns)]):
+        cols = np.nonzero(div_of_xval == clim_div)[0]
+        if cols.size == 0:
+            continue
+        climdiv_mask = np.nonzero(climdiv_stns == clim_div)[0]
+        pick = np.zeros(12, ladder.dtype)
+        for mth in range(1, 13):
+            mmae = np.ma.mean(np.ma.masked_invalid(mae[mth - 1][:, cols]), axis=1)
+            min_idx = int(np.argmin(mmae))
+            stns[namer(mth)][climdiv_mask] = ladder[min_idx]
+            pick[mth - 1] = ladder[min_idx]
+        chosen[float(clim_div)] = pick
+    return stns, chosen
+
+
+@pytest.mark.parametrize("case", ["plain", "nan_entries", "failed_stations", "ties", "dead_bandwidth"])
+def test_set_optim_nstns_equals_masked_division_loop(case):
+    """The batched reduction picks the same bandwidth as the reference's loop of masked means for every (division,
+    month) -- also when means tie exactly, when stations failed (NaN columns) and when a bandwidth has no finite
+    error in a division."""
+    from topowx_amd import stationdb as sdb, synth, xval
+    stn = synth.make_stations((30.0, 38.0, -100.0, -90.0), 3000, 5, "tmin")
+    ids = xval.xval_station_ids(stn)
+    rng = np.random.default_rng(3)
+    mae = rng.random((12, 16, len(ids)))
+    if case != "plain":
+        mae[rng.random(mae.shape) < 0.05] = np.nan
+    if case == "failed_stations":
+        mae[:, :, rng.random(len(ids)) < 0.3] = np.nan
+    if case == "ties":
+        mae = np.round(mae, 1)
+    if case == "dead_bandwidth":
+        mae[:, 3, :] = np.nan
+        mae[:, 0, : len(ids) // 2] = np.nan
+    a, ca = _set_optim_nstns_masked_loop(stn.stns.copy(), ids, mae, xval.DFLT_LADDER, sdb.get_optim_varname)
+    b, cb = xval.set_optim_nstns(stn.stns.copy(), ids, mae, xval.DFLT_LADDER, sdb.get_optim_varname)
+    assert len(ca) > 50 and set(ca) == set(cb)
+    assert all(np.array_equal(ca[k], cb[k]) for k in ca)
+    for m in range(1, 13):
+        assert np.array_equal(a[sdb.get_optim_varname(m)], b[sdb.get_optim_varname(m)], equal_nan=True)

@@ -39,7 +39,7 @@ __device__ __forceinline__ double block_max(double v, double *s_tmp)
 template <int PASS>
 __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
 {
-    __shared__ double s_lon[TWX_KSEL_MAX], s_lat[TWX_KSEL_MAX], s_e[TWX_KSEL_MAX];
+    __shared__ double s_trig[TWX_KSEL_MAX * 5], s_e[TWX_KSEL_MAX];   // per neighbour: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)}
     __shared__ double s_sh[TWX_VBINS], s_sg[TWX_VBINS], s_sn[TWX_VBINS];
     __shared__ double s_red[4], s_beta[5], s_nrm[20];
     __shared__ int s_bad;
@@ -61,7 +61,12 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     if (t < k) {
         const int j = ws.near_idx[lc * ws.ksel + t];
         const double lo = st.lon[j], la = st.lat[j];
-        s_lon[t] = lo; s_lat[t] = la;
+        {   // the pair distances below come from the stations' half-angle trigonometry (k_stn_coslat), as in the kriging kernels'
+            // fp64 build: no trigonometric call per pair (the six of ellip_km per pair were 60 % of config 5's kernel time)
+            const double sp = st.sph[j], cp = st.cph[j];
+            s_trig[t * 5 + 0] = sp; s_trig[t * 5 + 1] = cp; s_trig[t * 5 + 2] = st.slh[j]; s_trig[t * 5 + 3] = st.clh[j];
+            s_trig[t * 5 + 4] = fma(cp, cp, -(sp * sp));
+        }
         x[0] = 1.0; x[1] = lo - cv.lon; x[2] = la - cv.lat; x[3] = st.elev[j] - cv.elev; x[4] = st.lst[m0 * n + j] - plst;
         y = st.norm[m0 * n + j];
         dh = ws.near_dist[lc * ws.ksel + t];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
         while (i * (i - 1) / 2 > p) --i;
         while ((i + 1) * i / 2 <= p) ++i;
         const int j = p - i * (i - 1) / 2;
-        const double h = ellip_km(s_lon[i], s_lat[i], s_lon[j], s_lat[j]);
+        const double h = ellip_pair_f64(&s_trig[i * 5], &s_trig[j * 5]);
         if (h <= cutoff) {
             int b = (int)floor(h / width);
             if (b > 0 && h == b * width) --b;

@@ -201,21 +201,37 @@ def set_optim_nstns(stns, stn_ids, mae, ladder, namer):
     pos = {s: i for i, s in enumerate(stns[STN_ID])}
     div_of_xval = stns[CLIMDIV][[pos[s] for s in ids]]
     climdiv_stns = stns[CLIMDIV]
-    divs = np.unique(climdiv_stns[np.isfinite(climdiv_stns)])                    # :300
+    # The reference loops over ~340 division files; the synthetic CONUS table has ~2 000 divisions, and 24 masked-array
+    # reductions per division took longer than the GPU farm that produced the errors.  Here: the cross-validated stations
+    # are ordered by division once, and a division's twelve months are reduced together on plain arrays -- the same row
+    # sums (numpy's pairwise summation along the contiguous station axis), counts and first-minimum choice as the
+    # masked mean of :312-313, so also the same choice when two bandwidths tie.
+    order = np.argsort(div_of_xval, kind="stable")
+    order = order[np.isfinite(div_of_xval[order])]
+    xdivs, start = np.unique(div_of_xval[order], return_index=True)              # divisions with an MAE "file" (step21:96-104)
+    stop = np.append(start[1:], order.size)
     chosen = {}
-    for clim_div in divs:
-        cols = np.nonzero(div_of_xval == clim_div)[0]                            # the division's MAE file (step21:96-104)
-        if cols.size == 0:
-            continue            # the reference would fail opening a file that was never written; nothing to set
-        climdiv_mask = np.nonzero(climdiv_stns == clim_div)[0]                   # :308
-        pick = np.zeros(12, ladder.dtype)
+    if xdivs.size:
+        m = np.asarray(mae, np.float64)[:, :, order]                             # [12, nb, xval stations by division]
+        fin = np.isfinite(m)
+        m0 = np.where(fin, m, 0.0)
+        picks = np.empty((12, xdivs.size), ladder.dtype)
+        for q in range(xdivs.size):
+            seg = slice(start[q], stop[q])
+            cnt = fin[:, :, seg].sum(axis=2)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                mmae = m0[:, :, seg].sum(axis=2) * 1. / cnt                      # :312 (no finite error: masked there)
+            mmae[cnt == 0] = np.inf                                              # (a masked mean never wins the argmin)
+            picks[:, q] = ladder[np.argmin(mmae, axis=1)]                        # :313 (first minimum)
+        # :308/:314 every station of the division, cross-validated or not
+        fin_all = np.nonzero(np.isfinite(climdiv_stns))[0]
+        slot = np.minimum(np.searchsorted(xdivs, climdiv_stns[fin_all]), xdivs.size - 1)
+        hit = xdivs[slot] == climdiv_stns[fin_all]
+        rows, slot = fin_all[hit], slot[hit]
         for mth in range(1, 13):
-            m = np.ma.masked_invalid(mae[mth - 1][:, cols])
-            mmae = np.ma.mean(m, axis=1)                                         # :312
-            min_idx = int(np.argmin(mmae))                                       # :313 (first minimum)
-            stns[namer(mth)][climdiv_mask] = ladder[min_idx]                     # :314
-            pick[mth - 1] = ladder[min_idx]
-        chosen[float(clim_div)] = pick
+            stns[namer(mth)][rows] = picks[mth - 1][slot]
+        for q, clim_div in enumerate(xdivs):
+            chosen[float(clim_div)] = picks[:, q].copy()
     return stns, chosen
 
 
@@ -325,14 +341,18 @@ def run_config5(nstns=2000, years=3, var="tmin", max_stations=0, rank=0, world=1
     _, mae_n = optim_nstns_norms(stn, var, **kw)
     res["step21_s"] = time.perf_counter() - t0
     stn_before = stn.stns.copy()                     # the table step21 cross-validated against (for spot checks)
+    t0 = time.perf_counter()
     set_optim_nstns_tair_norm(stn, ids, mae_n)
+    res["set_optim_s"] = time.perf_counter() - t0    # (host: the reductions between the farms, norm + anom)
     t0 = time.perf_counter()
     _, nug, psill, rng = set_stn_variograms(stn, var, **kw)
     res["step22_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     _, mae_a, _, _ = optim_nstns_anoms(stn, var, **kw)
     res["step23_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     set_optim_nstns_tair_anom(stn, ids, mae_a)
+    res["set_optim_s"] += time.perf_counter() - t0
     t0 = time.perf_counter()
     _, norms, _, _, st = xval_interp(stn, var, daily=True, **kw)
     res["step24_s"] = time.perf_counter() - t0
