@@ -1,7 +1,7 @@
 """Soak: seeded random small cases through the whole grid path (normals + daily + fixer), GPU against the CPU oracle.
 Every case draws its own grid extent and shape (not multiples of the 8-cell tiles), mask, station count, nugget scale
 (down to values that route systems to the fp64 covariance build), close station pairs, Tmax offset (days with
-tmin >= tmax for the fixer), batch size and flags.  Not part of the test suite (minutes of oracle time): run on the GPU
+tmin >= tmax for the fixer), batch size and flags; some cases have too few stations or NaN predictors (failure statuses).  Not part of the test suite (minutes of oracle time): run on the GPU
 box after kernel changes.   python3 tests/tools/gpu_soak.py [n_cases] [first_seed]  ->  gpurun_out/soak.json"""
 import datetime as dt
 import json
@@ -36,6 +36,18 @@ for seed in range(seed0, seed0 + ncase):
     years = int(rng.integers(1, 3))
     days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1980 + years, 12, 31))
     n = int(rng.integers(220, 700))
+    if rng.random() < 0.12:                                              # too few stations for some / all bandwidths: failure statuses
+        n = int(rng.integers(12, 160))
+    if rng.random() < 0.15:                                              # NaN predictors in patches of the grid
+        for name in ("elev", "tdi"):
+            if rng.random() < 0.5:
+                r, c = int(rng.integers(0, Y)), int(rng.integers(0, X))
+                grid[name] = grid[name].copy()
+                grid[name][r:r + int(rng.integers(1, 6)), c:c + int(rng.integers(1, 6))] = np.nan
+        if rng.random() < 0.5:
+            r, c = int(rng.integers(0, Y)), int(rng.integers(0, X))
+            grid["lst_day"] = grid["lst_day"].copy()
+            grid["lst_day"][int(rng.integers(0, 12)), r:r + 3, c:c + 3] = np.nan
     tmin = synth.make_stations(grid["bbox"], n, 300 + seed, "tmin", days, with_obs=True, expand_deg=float(rng.uniform(0.3, 1.5)))
     tmax = synth.make_stations(grid["bbox"], n, 300 + seed, "tmax", days, with_obs=True, expand_deg=float(rng.uniform(0.3, 1.5)))
     knobs = {"seed": seed, "Y": Y, "X": X, "stations": n, "years": years}
