@@ -18,6 +18,47 @@
 
 #define TWX_VBINS 512        // 5 km bins: cutoff up to 2 555 km
 
+// ---- the semivariogram's pair distance.  ellip_pair_f64 (twx_uk.h) spends most of its ~120 instructions in two IEEE
+// divisions and two IEEE square roots; here the same formula with the hardware reciprocal / reciprocal square root and
+// Newton steps: the main term sqrt(S) to an ulp or two, the terms of the flattening correction (weight f = 1/298) to
+// ~1e-14 -- the distance differs from ellip_pair_f64's by a few ulp, which moves a pair across a 5 km bin boundary
+// with probability ~1e-15 and the bin's mean distance by less.  (Three quarters of k_vario's time was this loop.)
+__device__ __forceinline__ double rcp_nr1(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    return fma(y, fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ double sqrt_nr(double x)          // x > 0, normal
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    const double sq = x * y;
+    return fma(fma(-sq, sq, x), 0.5 * y, sq);
+}
+// a, b: {sin, cos of the half latitude, sin, cos of the half longitude, cos(latitude)} of the two stations
+__device__ __forceinline__ double ellip_pair_vario(const double (&a)[5], const double (&b)[5])
+{
+    if (a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3]) return 0.0;   // same location
+    const double sG = fma(a[0], b[1], -(a[1] * b[0]));
+    const double sL = fma(a[2], b[3], -(a[3] * b[2]));
+    const double cc = a[4] * b[4];
+    const double sG2 = sG * sG, sL2 = sL * sL;
+    const double Sd = fma(cc, sL2, sG2);
+    if (!(Sd > 0.0)) return 0.0;
+    if (!(Sd < 4e-3)) return ellip_far_f64(Sd, cc, sG2);                           // > ~800 km: never in a neighbourhood
+    const double cF2 = cc + sG2, sF2 = 1.0 - cF2, cG2 = 1.0 - sG2, Cd = 1.0 - Sd;
+    double P = 0.01396484375;                                                       // asin(x) / x in x^2 = S (ellip_near_f64)
+    P = fma(P, Sd, 0.017352764423076924); P = fma(P, Sd, 0.022372159090909092); P = fma(P, Sd, 0.030381944444444444);
+    P = fma(P, Sd, 0.044642857142857144); P = fma(P, Sd, 0.075); P = fma(P, Sd, 0.16666666666666666); P = fma(P, Sd, 1.0);
+    double yc = __builtin_amdgcn_rsq(Cd);                                           // sqrt(C), C ~ 1: one Newton step (2^-46)
+    yc = yc * fma(-0.5 * Cd * yc, yc, 1.5);
+    const double R3 = 3.0 * (Cd * yc) * rcp_nr1(P);
+    const double H1 = (R3 - 1.0) * rcp_nr1(2.0 * Cd), H2 = (R3 + 1.0) * rcp_nr1(2.0 * Sd);
+    return (2 * TWX_WGS84_A) * (sqrt_nr(Sd) * P) * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2);
+}
+
 __device__ __forceinline__ double block_sum(double v, double *s_tmp /*[4]*/)
 {
     v = wave_sum(v);
@@ -39,7 +80,8 @@ __device__ __forceinline__ double block_max(double v, double *s_tmp)
 template <int PASS>
 __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
 {
-    __shared__ double s_trig[TWX_KSEL_MAX * 5], s_e[TWX_KSEL_MAX];   // per neighbour: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)}
+    __shared__ double s_trig[5][TWX_KSEL_MAX], s_e[TWX_KSEL_MAX];   // {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by neighbour: the
+                                                                    // pair loop's lanes read consecutive neighbours (no bank conflicts)
     __shared__ double s_sh[TWX_VBINS], s_sg[TWX_VBINS], s_sn[TWX_VBINS];
     __shared__ double s_red[4], s_beta[5], s_nrm[20];
     __shared__ int s_bad;
@@ -64,8 +106,8 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
         {   // the pair distances below come from the stations' half-angle trigonometry (k_stn_coslat), as in the kriging kernels'
             // fp64 build: no trigonometric call per pair (the six of ellip_km per pair were 60 % of config 5's kernel time)
             const double sp = st.sph[j], cp = st.cph[j];
-            s_trig[t * 5 + 0] = sp; s_trig[t * 5 + 1] = cp; s_trig[t * 5 + 2] = st.slh[j]; s_trig[t * 5 + 3] = st.clh[j];
-            s_trig[t * 5 + 4] = fma(cp, cp, -(sp * sp));
+            s_trig[0][t] = sp; s_trig[1][t] = cp; s_trig[2][t] = st.slh[j]; s_trig[3][t] = st.clh[j];
+            s_trig[4][t] = fma(cp, cp, -(sp * sp));
         }
         x[0] = 1.0; x[1] = lo - cv.lon; x[2] = la - cv.lat; x[3] = st.elev[j] - cv.elev; x[4] = st.lst[m0 * n + j] - plst;
         y = st.norm[m0 * n + j];
@@ -137,12 +179,16 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     for (int b = t; b < TWX_VBINS; b += 256) { s_sh[b] = 0.0; s_sg[b] = 0.0; s_sn[b] = 0.0; }
     __syncthreads();
     const int npair = k * (k - 1) / 2;
-    for (int p = t; p < npair; p += 256) {
-        int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
-        while (i * (i - 1) / 2 > p) --i;
-        while ((i + 1) * i / 2 <= p) ++i;
-        const int j = p - i * (i - 1) / 2;
-        const double h = ellip_pair_f64(&s_trig[i * 5], &s_trig[j * 5]);
+    // pair p = i (i - 1) / 2 + j, j < i: decoded once, then stepped (256 pairs ahead is at most a few rows down: k <= 152)
+    int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+    while (i * (i - 1) / 2 > t) --i;
+    while ((i + 1) * i / 2 <= t) ++i;
+    int j = t - i * (i - 1) / 2;
+    for (int p = t; p < npair; p += 256, j += 256) {
+        while (j >= i) { j -= i; ++i; }
+        const double ta[5] = {s_trig[0][i], s_trig[1][i], s_trig[2][i], s_trig[3][i], s_trig[4][i]};
+        const double tb[5] = {s_trig[0][j], s_trig[1][j], s_trig[2][j], s_trig[3][j], s_trig[4][j]};
+        const double h = ellip_pair_vario(ta, tb);
         if (h <= cutoff) {
             int b = (int)floor(h / width);
             if (b > 0 && h == b * width) --b;
