@@ -87,11 +87,11 @@ typedef struct {
  * waits for the selection kernels; everything after them -- kriging, GWR, daily values, fixer -- is asynchronous. */
 #define TWX_FLAG_NO_HOST_SYNC 2
 /* daily values: gather every (cell, neighbour) observation row from global memory instead of staging the rows of a
- * tile-month in LDS (the path a tile-month with more than 224 distinct rows takes -- a test / diagnostic switch;
+ * tile-month in LDS (the path a tile-month with more than 208 distinct rows takes -- a test / diagnostic switch;
  * TWX_FLAG_OBS_ADDR64 implies it).  Every daily sum -- LDS-table walk, 32- / 64-bit gathers, single-variable requests,
  * the fixer's recompute, the point entries -- adds a cell-day's terms in ONE order, ascending station index (the
  * reference's neighbour order, station_select.py:179-182; a table row the cell does not use carries weight 0 and adds
- * exactly nothing): all paths give the same bits, so which path a tile-month takes (its station union <= 224 rows, i.e.
+ * exactly nothing): all paths give the same bits, so which path a tile-month takes (its station union <= 208 rows, i.e.
  * tiling and station density) does not show in any output (tests/test_gpu_configs.py).
  * Precondition of every daily path: observations are finite (the reference's database is serially complete,
  * station_data.py:547-616); twx_set_stations rejects a table whose obs hold NaN / Inf, because the table walk

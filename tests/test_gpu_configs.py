@@ -103,7 +103,7 @@ def test_daily_64bit_obs_addressing_equals_32bit(golden_case, orc):
     rows of the tile-month staged in LDS (default: hat rows delivered in table order by k_gwr_z_cell),
     gathered from global memory with 32-bit offsets (a tile-month with too many distinct rows; TWX_FLAG_DAILY_GATHER)
     and with 64-bit offsets (stations x days >= 2^30; TWX_FLAG_OBS_ADDR64); the fixer recomputes with the same lists.
-    Which path a tile-month takes (<= 224 union rows, i.e. tiling and station density) does not show in any output."""
+    Which path a tile-month takes (<= 208 union rows, i.e. tiling and station density) does not show in any output."""
     from topowx_amd import _lib
     import make_golden
     grid, tmin, tmax = golden_case

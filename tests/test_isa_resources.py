@@ -24,7 +24,7 @@ EXPECT = {
     "k_uk<7, 2, 1>": (3, 0), "k_uk<10, 2, 1>": (2, 160), "k_uk<7, 2, 2>": (1, 64), "k_uk<10, 2, 2>": (1, 64),
     "k_tile_dist<0>": (4, 0), "k_tile_dist<1>": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4, 0>": (4, 0), "k_select<1, 1>": (2, 0), "k_tile_cand": (4, 0),
-    "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (4, 0), "k_daily_tile_gather": (4, 0),
+    "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (6, 0), "k_daily_tile_gather": (4, 0),
     "k_daily_grid": (4, 0), "k_fix_cells": (4, 0), "k_fix_sparse": (2, 0),
 }
 LDS_PER_CU = 160 * 1024
@@ -63,9 +63,10 @@ def test_register_and_scratch_budget(table, kernel):
     assert r["occupancy"] >= waves, "%s: occupancy %d < %d waves per SIMD" % (kernel, r["occupancy"], waves)
 
 
-def test_daily_tile_keeps_two_workgroups_per_cu(table):
-    # k_daily_tile stages a tile-month's rows in LDS; its tuning (8 waves x 2 work-groups per CU) needs <= 80 KB each
-    assert table["k_daily_tile"]["lds"] <= LDS_PER_CU // 2
+def test_daily_tile_keeps_three_workgroups_per_cu(table):
+    # k_daily_tile stages a tile-month's rows in LDS; its tuning (8 waves x 3 work-groups per CU: six waves per SIMD, 80 VGPRs)
+    # needs <= 53.3 KB each
+    assert table["k_daily_tile"]["lds"] <= LDS_PER_CU // 3
     # the pair table of k_tile_dist takes nearly all of a CU's LDS by design (one work-group per CU)
     assert table["k_tile_dist<0>"]["lds"] <= LDS_PER_CU
 

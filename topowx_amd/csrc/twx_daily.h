@@ -19,7 +19,7 @@ struct DayAxis {
     const int32_t *ym_cnt;    // [norm_ny * 12] days of (year, month)
 };
 
-#define TWX_UROWS 224 // observation rows of a (tile, month) staged in LDS by k_daily_tile (x 64 days x 4 B = 56 KB)
+#define TWX_UROWS 208 // observation rows of a (tile, month) staged in LDS by k_daily_tile (x 64 days x 4 B = 52 KB: three work-groups per CU)
 #ifndef TWX_DT_WAVES
 #define TWX_DT_WAVES 8                           // waves per work-group of k_daily_tile (see there)
 #endif
@@ -664,7 +664,9 @@ __global__ __launch_bounds__(256) void k_tile_uidx(CellSrc src, SelWs ws, GwrWs 
 // of a tile row) of the [ndays][Y][X] int16 output.
 // A tile-month whose union exceeds TWX_UROWS rows gathers from global memory (daily_value2: rank-order sums).
 // ---------------------------------------------------------------------------------
-// TWX_DT_WAVES = 8 waves per work-group (2 work-groups fit a CU: LDS).  The kernel is VALU bound: 8 cells per wave share each
+// TWX_DT_WAVES = 8 waves per work-group, THREE work-groups per CU (52 KB of LDS -- the output's transposition buffer shares the
+// table's space --, 76 VGPRs: the Tmax rows are fetched after the Tmin sums, not beside them; round 4: 21.2 -> 19.9 ms per C4
+// tile against two work-groups with a 224-row table).  8 cells per wave share each
 // row's LDS read + convert (C4 tile: 16 waves x 4 cells 35.2 ms, 8 x 8 27.5 ms, 4 x 16 34.5 ms)
 
 // Days with tmin >= tmax are recorded per cell as they are found (chronological day index, unordered; the count keeps
@@ -784,10 +786,11 @@ __device__ __forceinline__ void dt_value4(const DtVar &v, const int64_t (&lc)[TW
 
 #define TWX_DT_RPW ((TWX_UROWS + TWX_DT_WAVES - 1) / TWX_DT_WAVES)   // table rows staged per wave
 
-__global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
+__global__ __launch_bounds__(64 * TWX_DT_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_daily_tile(DtArgs a)
 {
     __shared__ float s_tab[TWX_UROWS * 64];
-    __shared__ int16_t s_v[2][64][66];
+    static_assert(sizeof(int16_t) * 2 * 64 * 66 <= sizeof(float) * TWX_UROWS * 64, "the transposition buffer shares the table's space");
+    int16_t (*s_v)[64][66] = reinterpret_cast<int16_t (*)[64][66]>(s_tab);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Work-groups are dealt round-robin to the 8 XCDs (one L2 each).  A unit = 8 consecutive tiles (neighbours in x) x
@@ -842,14 +845,14 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) lcs[i] = dt_cell(a, r0, q0, wv * TWX_DT_CPW + i);
     double vn[TWX_DT_CPW], vxs[TWX_DT_CPW];
-    fetch(a.x, nux);     // the Tmax rows travel while the Tmin sums run (the sums' hat-row loads are prefetched a chunk ahead,
-                         // so only their first wait sits behind these loads on the in-order counter: 42.6 -> 41.4 ms per C4 tile)
     dt_value4(a.n, lcs, m0, tab, lane4, lane, nun, a.n.zd + twx_zd_index(tl * 12 + m0, wv * TWX_DT_CPW) + (lane & 15), vn);
+    fetch(a.x, nux);     // (after the sums: the staging registers are not live beside the sums' -- 80 VGPRs, six waves per SIMD)
     __syncthreads();
     // ---- Tmax: re-stage the table, walk the cells, flag, pack
     store(nux);
     __syncthreads();
     dt_value4(a.x, lcs, m0, tab, lane4, lane, nux, a.x.zd + twx_zd_index(tl * 12 + m0, wv * TWX_DT_CPW) + (lane & 15), vxs);
+    __syncthreads();     // (s_v shares the table's space: every wave is done with the table)
 #pragma unroll
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         const int cl = wv * TWX_DT_CPW + i;
@@ -861,10 +864,25 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) void k_daily_tile(DtArgs a)
         s_v[1][lane][cl] = okd ? pack_i16(vx) : TWX_FILL_I2;
     }
     __syncthreads();
-    // write: each wave takes 64 / TWX_DT_WAVES days; lane = cell of the tile
+    // write: each wave takes 64 / TWX_DT_WAVES days
+    const int64_t yx = (int64_t)a.Y * a.X;
+    if (a.ts == 8 && TWX_DT_CPW == 8 && q0 + 8 <= a.X && r0 + 8 <= a.Y && (a.X & 1) == 0) {
+        // a tile wholly inside the grid: lane = (tile row, day of the wave's eight), one 16-byte store per variable -- the
+        // run of a tile row's 8 cells (the cells that failed or are masked hold the fill value the output was
+        // initialised with: writing it again changes nothing).  Element offsets are even (X even): 4-byte aligned.
+        struct __attribute__((packed, aligned(4))) Run { int32_t w[4]; };
+        const int rw = lane >> 3, dl = wv * TWX_DT_CPW + (lane & 7);
+        if (dm0 + dl < dm1) {
+            const int64_t e = (int64_t)a.mm2chron[dm0 + dl] * yx + (int64_t)(r0 + rw) * a.X + q0;
+            *reinterpret_cast<Run *>(a.out_n + e) = *reinterpret_cast<const Run *>(&s_v[0][dl][rw * 8]);
+            *reinterpret_cast<Run *>(a.out_x + e) = *reinterpret_cast<const Run *>(&s_v[1][dl][rw * 8]);
+        }
+        return;
+    }
+    // edge tiles: lane = cell of the tile, 2-byte stores
     const int64_t lcw = dt_cell(a, r0, q0, lane);
     if (lcw < 0) return;
-    const int64_t c = a.cell0 + lcw, yx = (int64_t)a.Y * a.X;
+    const int64_t c = a.cell0 + lcw;
     for (int i = 0; i < TWX_DT_CPW; ++i) {
         const int dl = wv * TWX_DT_CPW + i;
         if (dm0 + dl >= dm1) break;

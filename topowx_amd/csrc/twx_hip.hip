@@ -198,7 +198,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     }
     if (grid) HIPCHK(w.near_pos.ensure((size_t)ncell * ksel * 2));   // position in the tile's candidate list (k_tile_dist, k_tile_uidx, k_gwr_z_cell)
     if (tile_tab) {      // grid mode with daily output: k_tile_uidx / k_gwr_z_cell / k_daily_tile
-        HIPCHK(w.zd.ensure((size_t)ntile * 12 * 64 * TWX_UROWS * 8));   // per tile: 64 cell slots x 224 rows, wave layout
+        HIPCHK(w.zd.ensure((size_t)ntile * 12 * 64 * TWX_UROWS * 8));   // per tile: 64 cell slots x TWX_UROWS rows, wave layout
         HIPCHK(w.urow.ensure((size_t)ntile * 12 * TWX_UROWS * 4));
         HIPCHK(w.nurow.ensure((size_t)ntile * 12 * 4));
         HIPCHK(w.uslot.ensure((size_t)ntile * 12 * w.cmax * 2));
