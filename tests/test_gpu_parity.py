@@ -284,6 +284,34 @@ def test_all_masked_and_nan_predictors(env):
     assert np.all(np.isfinite(got["norm_tmin"][:, ~bad])) and np.all(got["ninvalid"][bad] == lib.FILL_I4)
 
 
+def test_failures_of_two_kinds_keep_the_reference_order(env, orc, golden_case):
+    """A cell with a NaN predictor in a database too small for some months' bandwidths fails twice: its kriging with a
+    floating-point error in month 1, its station selection in a later month.  The reference walks the months in order
+    (interp_tair.py:429-437), so the FIRST failure is the one it reports -- the kriging's (found by tests/tools/gpu_soak.py,
+    seed 5043: the selection kernel, which runs first on the GPU, used to report its own)."""
+    from topowx_amd import stationdb as sdb
+    lib = env["lib"]
+    grid = dict(env["grid"])
+    for name in ("elev", "tdi", "lst_night", "lst_day"):
+        grid[name] = grid[name].copy()
+    grid["elev"][2:4, 5:7] = np.nan
+    grid["tdi"][8, 1] = np.nan
+    grid["lst_night"][7, 10, 3] = np.nan                                 # August only
+    rs, cs = slice(0, 12), slice(0, 12)
+    for nkeep in (104, 125, 150):                                        # too few stations for all / some / the largest bandwidths
+        dbn = sdb.StationDataWrkChk(golden_case[1].stns[:nkeep].copy(), "tmin", golden_case[1].days, golden_case[1].var[:, :nkeep].copy())
+        dbx = sdb.StationDataWrkChk(golden_case[2].stns[:nkeep].copy(), "tmax", golden_case[2].days, golden_case[2].var[:, :nkeep].copy())
+        ctx = lib.Context()
+        ctx.set_stations(lib.TMIN, dbn)
+        ctx.set_stations(lib.TMAX, dbx)
+        for daily in (False, True):
+            got = ctx.interp_grid(grid, daily=daily, rows=rs, cols=cs)
+            want = orc.interp_grid(orc.Db(dbn), orc.Db(dbx), env["prm"], grid, daily=daily, nthreads=8, rows=rs, cols=cs)
+            assert np.array_equal(got["status"], want["status"]), (nkeep, daily, got["status"], want["status"])
+        ctx.close()
+        assert len(np.unique(want["status"])) >= 2                       # (more than one kind of outcome in the window)
+
+
 def test_api_misuse_is_reported_not_crashed(env):
     lib = env["lib"]
     ctx = lib.Context()

@@ -91,6 +91,12 @@ for seed in range(seed0, seed0 + ncase):
     rec = dict(knobs, gpu_s=round(t1 - t0, 2), oracle_s=round(t2 - t1, 2))
     ok = got["status"] == 0
     rec["status_equal"] = bool(np.array_equal(got["status"], want["status"]))
+    if not rec["status_equal"]:                                           # which codes disagree, where
+        neq = got["status"] != want["status"]
+        pairs, cnt = np.unique(np.stack([got["status"][neq], want["status"][neq]]), axis=1, return_counts=True)
+        rec["status_mismatch_gpu_vs_oracle"] = [[int(a), int(b), int(c)] for (a, b), c in zip(pairs.T, cnt)]
+        rr, cc = np.nonzero(neq)
+        rec["status_mismatch_first_cell"] = [int(rr[0]), int(cc[0])]
     rec["cells_ok"] = int(ok.sum())
     rec["failed_cells"] = int((got["status"] > 0).sum())
     rec["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"], want["ninvalid"]))

@@ -311,6 +311,12 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
         cv = cell_load(src, c);
         if (src.mode == 1 && src.excl) excl = src.excl[c];
     }
+    // non-finite predictors of the point, as scalar bits (wave-uniform): 0 elev, 1 tdi, 2 + m lst of month m
+    unsigned nan_pred = 0;
+    if (valid) {
+        const unsigned nl = (unsigned)__ballot(lane < 12 && !finite_d(cell_lst(src, c, lane < 12 ? lane : 0)));
+        nan_pred = (unsigned)__builtin_amdgcn_readfirstlane((int)((nl << 2) | (finite_d(cv.elev) ? 0u : 1u) | (finite_d(cv.tdi) ? 0u : 2u)));
+    }
     // which of the two launches owns this cell (wave-uniform)
     const int nc_tile = valid ? (too_many ? 0 : ncand) : 0;
     if (!(nc_tile > clo && nc_tile <= chi) && !(clo == 0 && nc_tile == 0)) in_range = false;
@@ -534,11 +540,18 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
             }
             if (src.do_vario && lane < 36) ws.vario[lc * 36 + lane] = vnum / vden;
         }
-        // resolve month by month: the first failure sticks (the reference abandons the point)
+        // resolve month by month: the first failure sticks (the reference abandons the point).  A non-finite predictor of
+        // the point fails a month's kriging (lon, lat, elev, lst) / GWR (+ tdi) with a floating-point error AFTER that month's
+        // selection steps and BEFORE the next month's: it is entered here, in its place in the sequence (the kriging
+        // kernels would find it too -- NaN results -- but only for cells that no LATER month's selection had failed)
+        const unsigned nan_lst = nan_pred >> 2;
+        const bool nan_k = nan_pred & 1u, nan_a = nan_pred & 3u;
 #pragma unroll
         for (int m0 = 0; m0 < 12; ++m0) {
             if (status == TWX_CELL_OK && src.do_krig) status = rq[m0] ? rq[m0] : rvq[m0];
+            if (status == TWX_CELL_OK && src.do_krig && (nan_k || ((nan_lst >> m0) & 1u))) status = TWX_CELL_NUMERIC;
             if (status == TWX_CELL_OK && src.do_anom) status = raq[m0];
+            if (status == TWX_CELL_OK && src.do_anom && (nan_a || ((nan_lst >> m0) & 1u))) status = TWX_CELL_NUMERIC;
             if (lane == 0) {
                 ws.kk[lc * 12 + m0] = status ? 0 : kq[m0];
                 ws.ka[lc * 12 + m0] = status ? 0 : kaq[m0];
@@ -575,6 +588,8 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
                     }
                 }
             }
+            // (a non-finite predictor of the point: the month's kriging fails here, see the all-months form above)
+            if (!status && src.do_krig && ((nan_pred & 1u) || ((nan_pred >> (2 + m0)) & 1u))) status = TWX_CELL_NUMERIC;
             // GwrTairAnom.__get_nnghs (interp_tair.py:245-259)
             if (!status && src.do_anom) {
                 if (k_in > 0) kan = k_in;
@@ -586,6 +601,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
                 if (!status && (kan < 1 || kan > TWX_MAX_NNGHS)) status = TWX_CELL_RANGE;
                 if (!status && kan >= nnear) status = TWX_CELL_FEW_STATIONS;
                 if (!status && !(snd[kan] > 0.0)) status = TWX_CELL_NUMERIC;
+                if (!status && ((nan_pred & 3u) || ((nan_pred >> (2 + m0)) & 1u))) status = TWX_CELL_NUMERIC;
             }
         }
         if (status) { k = 0; kan = 0; }
