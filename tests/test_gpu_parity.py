@@ -312,6 +312,26 @@ def test_failures_of_two_kinds_keep_the_reference_order(env, orc, golden_case):
         assert len(np.unique(want["status"])) >= 2                       # (more than one kind of outcome in the window)
 
 
+def test_krig_tiny_neighbourhoods_in_a_fresh_context(env, orc):
+    """Explicit bandwidths of 6 ... 16 stations (below anything the reference's ladder holds; the point entries accept them):
+    the pair-distance slab of such a neighbourhood has one block row, the smallest kriging kernel reads three and masks
+    only the last itself -- the middle one used to be whatever the allocation held (zeros in a fresh context: 0 x -inf = NaN,
+    TWX_CELL_NUMERIC; found by tests/tools/gpu_soak_points.py)."""
+    lib, grid = env["lib"], env["grid"]
+    cells = np.array([[10, 12], [40, 41], [77, 3], [55, 90]])
+    for k in (6, 8, 12, 16, 17, 31):
+        ctx = lib.Context()                                              # fresh allocations every time
+        ctx.set_stations(lib.TMIN, env["tmin"], with_obs=False)
+        pts = _pts(ctx, grid, cells, "tmin")
+        mean, var, used, st, _ = ctx.krig_points(lib.TMIN, pts, [1, 4, 8, 12], nnghs=k)
+        ctx.close()
+        for i in range(4):
+            rc, m, v, ku, _ = orc.krig(env["dbn"], env["prm"], orc.make_pt(pts["lon"][i], pts["lat"][i], pts["elev"][i], pts["tdi"][i],
+                                                                           pts["lst"][i]), [1, 4, 8, 12][i], k)
+            assert st[i] == rc == 0 and used[i] == ku == k
+            assert abs(mean[i] - m) < TOL and abs(var[i] - v) < TOL, (k, i, mean[i], m, var[i], v)
+
+
 def test_api_misuse_is_reported_not_crashed(env):
     lib = env["lib"]
     ctx = lib.Context()

@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
                                                   sp, cp, sl, cl, cph);
     }
     __syncthreads();
-    const int nbk = (kmax + 15) >> 4;   // (the kriging kernels may read one block row more: they mask it themselves)
+    // (the kriging kernels read every block row of their matrix size: the LAST one they mask themselves; the smallest kernel
+    // holds three, so two are always written -- a neighbourhood of <= 16 stations (explicit bandwidths of the point entries
+    // only) left the middle block row to whatever the slab held: 0 x -inf = NaN in a fresh allocation, found by
+    // tests/tools/gpu_soak_points.py)
+    const int nbk = max((kmax + 15) >> 4, 2);
     float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
     for (int a = 0; a < nbk; ++a) {
         const int i = 16 * a + tr;
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int nbk = (kmax + 15) >> 4;
+        const int nbk = max((kmax + 15) >> 4, 2);            // (two block rows at least: see k_cell_dist)
         float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
         const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
         float run = __builtin_inff();                        // (HM) smallest pair distance among the rows above this block row
