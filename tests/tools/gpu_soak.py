@@ -75,18 +75,21 @@ for seed in range(seed0, seed0 + ncase):
             obs = obs - np.float32(shift)
             knobs["tmax_shift"] = shift
         dbs.append(sdb.StationDataWrkChk(stns, var, days, obs))
-    flags = int(rng.choice([0, 0, _lib.FLAG_NO_HOST_SYNC, _lib.FLAG_DAILY_GATHER]))
+    flags = int(rng.choice([0, 0, _lib.FLAG_NO_HOST_SYNC, _lib.FLAG_DAILY_GATHER, _lib.FLAG_OBS_ADDR64]))
     batch = int(rng.choice([0, 0, 512, 2048]))
-    knobs.update(flags=flags, batch_cells=batch)
+    tile_cells = int(rng.choice([0, 0, 0, 4, 16]))                       # 8 (tile tables), 4 (small tables), 16 (no tables: strips)
+    which = [("tmin", "tmax"), ("tmin", "tmax"), ("tmin", "tmax"), ("tmin",), ("tmax",)][int(rng.integers(0, 5))]
+    knobs.update(flags=flags, batch_cells=batch, tile_cells=tile_cells, variables="+".join(which))
     t0 = time.perf_counter()
-    ctx = _lib.Context(flags=flags, batch_cells=batch)
+    ctx = _lib.Context(flags=flags, batch_cells=batch, tile_cells=tile_cells)
     ctx.set_stations(_lib.TMIN, dbs[0])
     ctx.set_stations(_lib.TMAX, dbs[1])
-    got = ctx.interp_grid(grid, daily=True)
+    got = ctx.interp_grid(grid, variables=which, daily=True)
     tim = ctx.timing()
     ctx.close()
     t1 = time.perf_counter()
-    want = orc.interp_grid(orc.Db(dbs[0]), orc.Db(dbs[1]), orc.params(), grid, daily=True, nthreads=nthr)
+    want = orc.interp_grid(orc.Db(dbs[0]) if "tmin" in which else None, orc.Db(dbs[1]) if "tmax" in which else None, orc.params(),
+                           grid, daily=True, nthreads=nthr)
     t2 = time.perf_counter()
     rec = dict(knobs, gpu_s=round(t1 - t0, 2), oracle_s=round(t2 - t1, 2))
     ok = got["status"] == 0
@@ -103,10 +106,10 @@ for seed in range(seed0, seed0 + ncase):
     rec["ninvalid_max"] = int(want["ninvalid"][want["status"] == 0].max()) if (want["status"] == 0).any() else 0
     rec["f64_solves"] = int(tim.get("uk_f64_solves", -1)) if isinstance(tim, dict) else int(getattr(tim, "uk_f64_solves", -1))
     for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
-        d = np.abs(got[k].astype(np.float64) - want[k])[:, ok]
+        d = np.abs(got[k].astype(np.float64) - want[k])[:, ok] if k in got else np.zeros(0)
         rec[k] = float(d.max()) if d.size else 0.0
     for k in ("daily_tmin", "daily_tmax"):
-        d = np.abs(got[k].astype(np.int64) - want[k].astype(np.int64))[:, ok]
+        d = np.abs(got[k].astype(np.int64) - want[k].astype(np.int64))[:, ok] if k in got else np.zeros(0)
         rec[k + "_maxdiff"] = int(d.max()) if d.size else 0
         rec[k + "_flip"] = float((d != 0).mean()) if d.size else 0.0
     good = (rec["status_equal"] and rec["ninvalid_equal"] and max(rec["norm_tmin"], rec["norm_tmax"], rec["se_tmin"], rec["se_tmax"]) < 1e-4
