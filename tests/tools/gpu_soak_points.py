@@ -145,13 +145,31 @@ for seed in range(seed0, seed0 + ncase):
     rec["vario_above_1e-6"] = bool(w > 1e-6)
     rec["worst"]["vario_rel"] = w
     tot["vario"] += 12
+    # ---- step21 shape: leave-one-out, explicit bandwidth, fit then krige all twelve months (KrigTairAll.krigall)
+    w = 0.0
+    for sj1 in rng.integers(0, ns, 5):
+        k = int(rng.choice([35, 42, 57, 76, 101, 147]))
+        p12 = ctx.make_pts(np.repeat(c["lon"][sj1], 12), np.repeat(c["lat"][sj1], 12), np.repeat(c["elev"][sj1], 12),
+                           np.repeat(c["tdi"][sj1], 12), np.tile(c["lst"][:, sj1], (12, 1)))
+        m12 = np.arange(1, 13, dtype=np.int32)
+        vf, _, st1 = ctx.fit_vario_points(_lib.TMIN, p12, m12, nnghs=k, excl=int(sj1), rm_zero_dist=True)
+        mean, _, _, st2, _ = ctx.krig_points(_lib.TMIN, p12, m12, nnghs=k, vario=np.nan_to_num(vf), excl=int(sj1), rm_zero_dist=True)
+        rc, norms_o, _ = orc.krigall(odb, prm, orc.make_pt(c["lon"][sj1], c["lat"][sj1], c["elev"][sj1], c["tdi"][sj1], c["lst"][:, sj1]),
+                                     k, excl=int(sj1), rm_zero_dist=True)
+        gpu_ok = bool(np.all(st1 == 0) and np.all(st2 == 0))
+        note("krigall_status", gpu_ok == (rc == 0), [int(sj1), k, st1.tolist(), st2.tolist(), int(rc)])
+        if gpu_ok and rc == 0:
+            w = max(w, float(np.abs(mean - norms_o).max()))
+    note("krigall_value", w < TOL, w)
+    rec["worst"]["krigall"] = w
+    tot["krigall"] = tot.get("krigall", 0) + 5
     ctx.close()
     rec["pass"] = ok_case
     bad += not ok_case
     report.append(rec)
     print(json.dumps(rec), flush=True)
 out = {"cases": len(report), "failed": bad, "points": tot,
-       "worst": {k: max(r["worst"][k] for r in report) for k in ("krig", "gwr", "interp", "vario_rel")}, "records": report}
+       "worst": {k: max(r["worst"][k] for r in report) for k in ("krig", "gwr", "interp", "vario_rel", "krigall")}, "records": report}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "soak_points.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "records"}))
