@@ -196,3 +196,26 @@ def test_close_pairs_leave_one_out(env, orc):
                 if rc == 0:
                     worst = max(worst, abs(mean[i] - m), abs(var[i] - v))
     assert worst < TOL, worst
+
+
+def test_every_system_on_the_fp64_build_matches_the_oracle_to_the_last_f4_bit(golden_case, orc):
+    """TWX_FLAG_UK_F64_ALL: with fp64 pair distances and exponentials for EVERY system the normals agree with the oracle to
+    ~1e-11 degC, i.e. the f4 outputs are the same bits (the default build is one f4 ulp off in about half of them), and the
+    packed int16 daily values that flip by one count in the default build (2e-5 of them: a normal 1e-6 degC off moves a
+    value across a rounding boundary) no longer do."""
+    from topowx_amd import _lib
+    grid, tmin, tmax = golden_case
+    rs, cs = slice(40, 64), slice(30, 54)
+    want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, daily=True, nthreads=8, rows=rs, cols=cs)
+    ctx = _lib.Context(flags=_lib.FLAG_UK_F64_ALL)
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    got = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+    t = ctx.timing()
+    ctx.close()
+    assert t["uk_f64_solves"] == t["uk_solves"] > 0
+    assert np.array_equal(got["status"], want["status"]) and np.all(got["status"] == 0)
+    for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+        assert np.array_equal(got[k], want[k].astype(np.float32)), k                 # the same f4 bits
+    for k in ("daily_tmin", "daily_tmax"):
+        assert (got[k] != want[k]).mean() < 2e-6, k

@@ -1,7 +1,7 @@
 """Every cell of the C2 tile (BASELINE.json configs[1]: 250 x 250 cells, 10 000 stations per variable), normals + SE of
 both variables, GPU against the CPU oracle -- the full-size check the suite samples (the oracle needs ~1 minute on the GPU
 box's host cores).  With --daily: three years of daily values of both variables with a lowered Tmax (fixer), every cell.
-python3 tests/tools/gpu_full_tile_parity.py [--daily]  ->  gpurun_out/full_tile_parity[_daily].json"""
+python3 tests/tools/gpu_full_tile_parity.py [--daily] [--f64]  ->  gpurun_out/full_tile_parity[_daily].json"""
 import json
 import os
 import sys
@@ -28,7 +28,8 @@ if daily:
     tmax = sdb.StationDataWrkChk(stns, "tmax", days, tmax.var - np.float32(7.5))
 else:
     grid, tmin, tmax = synth.make_case("C2")
-ctx = _lib.Context()
+f64 = "--f64" in sys.argv                                     # TWX_FLAG_UK_F64_ALL: every kriging system on the fp64 build
+ctx = _lib.Context(flags=_lib.FLAG_UK_F64_ALL if f64 else 0)
 ctx.set_stations(_lib.TMIN, tmin, with_obs=daily)
 ctx.set_stations(_lib.TMAX, tmax, with_obs=daily)
 t0 = time.perf_counter()
@@ -38,7 +39,7 @@ ctx.close()
 want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, daily=daily, nthreads=min(256, os.cpu_count() or 8))
 t2 = time.perf_counter()
 ok = want["status"] == 0
-res = {"cells": int(grid["mask"].size), "cells_ok": int(ok.sum()), "status_equal": bool(np.array_equal(got["status"], want["status"])),
+res = {"flags": "TWX_FLAG_UK_F64_ALL" if f64 else "default", "cells": int(grid["mask"].size), "cells_ok": int(ok.sum()), "status_equal": bool(np.array_equal(got["status"], want["status"])),
        "gpu_s_incl_transfers": round(t1 - t0, 3), "oracle_s": round(t2 - t1, 1)}
 for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
     d = np.abs(got[k].astype(np.float64) - want[k])[:, ok]
@@ -52,5 +53,5 @@ if daily:
         d = np.abs(got[k].astype(np.int32) - want[k].astype(np.int32))[:, ok]
         res[k] = {"values": int(neq.size), "differ": int(neq.sum()), "flip_rate": float(neq.mean()), "max_diff_LSB": int(d.max())}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "full_tile_parity_daily.json" if daily else "full_tile_parity.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", ("full_tile_parity_daily" if daily else "full_tile_parity") + ("_f64.json" if f64 else ".json")), "w"), indent=1)
 print(json.dumps(res))

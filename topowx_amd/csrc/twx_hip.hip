@@ -225,6 +225,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.ctrig = w.ctrig.as<double>(); s.uk_S = w.uk_S.as<double>();
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>(); s.hminp = w.hminp.as<float>();
     s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
+    s.f64_all = (ctx->p.flags & TWX_FLAG_UK_F64_ALL) ? 1 : 0;
     s.cellf64 = w.cellf64.as<int32_t>(); s.dist64 = nullptr; s.h064 = nullptr;
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();

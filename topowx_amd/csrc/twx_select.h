@@ -56,6 +56,7 @@ struct SelWs {
     float *hminp;        // [ncell][ksel] smallest pair distance among the neighbours of ranks <= r (k_cell_dist / k_tile_dist;
                          // +inf at rank 0): what decides whether a system needs the fp64 covariance build (uk_needs_f64)
     int fast_only;       // TWX_FLAG_UK_FAST_ONLY: never route a system to the fp64 build (diagnostic)
+    int f64_all;         // TWX_FLAG_UK_F64_ALL: every system on the fp64 build
     int32_t *cellf64;    // [ncell] 1 = a month of the cell was routed to the fp64 build (k_bucket_items)
     // fp64 pair distances of the cells with cellf64 set, in the layout of dist (k_cell_dist64), and their cell -> neighbour
     // distances: allocated when a batch has routed systems and the host knows it (null with TWX_FLAG_NO_HOST_SYNC: the
@@ -718,8 +719,8 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
         if (k > 0) {
             id = twx_krig_bucket(k);
             const double nug = ws.vario[item * 3], psill = ws.vario[item * 3 + 1], rng = ws.vario[item * 3 + 2];
-            if (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
-                uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1])) {
+            if (ws.f64_all || (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
+                               uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))) {
                 id = TWX_BUCKET_F64 + (k > 104 ? 1 : 0);
                 ws.cellf64[lc] = 1;                          // (every routed month of the cell writes the same 1)
             }
