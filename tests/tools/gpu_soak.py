@@ -75,7 +75,8 @@ for seed in range(seed0, seed0 + ncase):
             obs = obs - np.float32(shift)
             knobs["tmax_shift"] = shift
         dbs.append(sdb.StationDataWrkChk(stns, var, days, obs))
-    flags = int(rng.choice([0, 0, _lib.FLAG_NO_HOST_SYNC, _lib.FLAG_DAILY_GATHER, _lib.FLAG_OBS_ADDR64]))
+    flags = int(rng.choice([0, 0, _lib.FLAG_NO_HOST_SYNC, _lib.FLAG_DAILY_GATHER, _lib.FLAG_OBS_ADDR64, _lib.FLAG_UK_F64_ALL,
+                            _lib.FLAG_UK_F64_ALL | _lib.FLAG_NO_HOST_SYNC]))
     batch = int(rng.choice([0, 0, 512, 2048]))
     tile_cells = int(rng.choice([0, 0, 0, 4, 16]))                       # 8 (tile tables), 4 (small tables), 16 (no tables: strips)
     which = [("tmin", "tmax"), ("tmin", "tmax"), ("tmin", "tmax"), ("tmin",), ("tmax",)][int(rng.integers(0, 5))]
@@ -114,6 +115,11 @@ for seed in range(seed0, seed0 + ncase):
         rec[k + "_flip"] = float((d != 0).mean()) if d.size else 0.0
     good = (rec["status_equal"] and rec["ninvalid_equal"] and max(rec["norm_tmin"], rec["norm_tmax"], rec["se_tmin"], rec["se_tmax"]) < 1e-4
             and max(rec["daily_tmin_maxdiff"], rec["daily_tmax_maxdiff"]) <= 1 and max(rec["daily_tmin_flip"], rec["daily_tmax_flip"]) < 1e-3)
+    if flags & _lib.FLAG_UK_F64_ALL:                                      # fp64 build everywhere: the oracle's f4 / int16 bits
+        exact = all(np.array_equal(got[k][:, ok], want[k].astype(np.float32)[:, ok]) for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax") if k in got)
+        flips = sum(int((got[k] != want[k])[:, ok].sum()) for k in ("daily_tmin", "daily_tmax") if k in got)
+        rec["f64_all_exact_f4"] = bool(exact)
+        rec["f64_all_int16_flips"] = flips
     rec["pass"] = bool(good)
     bad += not good
     worst["norm"] = max(worst["norm"], rec["norm_tmin"], rec["norm_tmax"])
