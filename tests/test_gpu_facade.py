@@ -1,4 +1,6 @@
 """GPU: the twx.interp facade classes against goldens of the reference's classes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -203,19 +205,28 @@ def test_step25_chunk_loop_equals_whole_grid(case):
             assert np.array_equal(a[k], whole[k][..., i:i + 20, j:j + 20]), (tile_id, k)
 
 
-def test_step25_to_netcdf_tiles_to_monthly(case, tmp_path):
-    """step25 -> netCDF tiles (8f-2) -> daily mosaic -> monthly product (8f-3), end to end."""
-    from topowx_amd import _lib, ncio, step25
-    from topowx_amd.interp import TairAggregate, TileMosaic, Tiler
+@pytest.mark.parametrize("out_format", ["nc4", "nc3"])
+def test_step25_to_netcdf_tiles_to_monthly(case, tmp_path, out_format):
+    """step25 -> netCDF tiles (8f-2, both containers) -> daily mosaic -> monthly product (8f-3), end to end: on arrays,
+    and through the reference's file-level calls (step26: ``TileMosaic(fpath_mask, ...).create_dly_ann_mosaics`` /
+    ``create_normals_mosaic``; step27: ``write_ds_mthly``)."""
+    from topowx_amd import _lib, h5nc, ncio, step25
+    from topowx_amd.interp import TairAggregate, TileMosaic, Tiler, write_ds_mthly
+    if out_format == "nc4" and not h5nc.available():
+        pytest.skip("libhdf5 not loadable")
+    fmt = step25.NC_FORMATS[out_format]
     grid, tmin, tmax = case
     sub = {k: (v[:20, :40] if k in ("mask", "elev", "tdi", "climdiv") else v) for k, v in grid.items()}
     sub["lat"], sub["lon"] = grid["lat"][:20], grid["lon"][:40]
     sub["lst_night"], sub["lst_day"] = grid["lst_night"][:, :20, :40], grid["lst_day"][:, :20, :40]
-    stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=str(tmp_path),
-                              out_format="nc", keep=True)
+    tdir = tmp_path / "tiles"
+    tdir.mkdir()
+    stores = step25.proc_work(sub, tmin, tmax, tile_size=20, chunk_size=10, daily=True, out_dir=str(tdir),
+                              out_format=out_format, keep=True)
     tiles = sorted(stores)
     assert tiles == ["h00v00", "h01v00"]
-    back = ncio.read_tile_stores(str(tmp_path), tiles)
+    assert ncio.file_format(str(tdir / "h00v00" / "h00v00_tmin.nc")) == fmt
+    back = ncio.read_tile_stores(str(tdir), tiles)
     for t in tiles:
         for k in ("daily_tmin", "daily_tmax", "norm_tmin", "se_tmax", "ninvalid"):
             np.testing.assert_array_equal(back[t].a[k], stores[t].a[k])
@@ -234,3 +245,40 @@ def test_step25_to_netcdf_tiles_to_monthly(case, tmp_path):
     want = np.where(np.ma.getmaskarray(tair).all(axis=0)[None], _lib.FILL_I2, want).astype(np.int16)
     np.testing.assert_array_equal(m16, want)
     agg.close()
+
+    # ---- the same through files, with the reference's call shapes --------------------------------------------------
+    fmask = str(tmp_path / "mask.nc")
+    ds = ncio.open_dataset(fmask, "w", fmt)
+    ds.createDimension("lat", 20)
+    ds.createDimension("lon", 40)
+    ds.createVariable("lat", "f8", ("lat",))[:] = sub["lat"]
+    ds.createVariable("lon", "f8", ("lon",))[:] = sub["lon"]
+    ds.createVariable("mask", "i1", ("lat", "lon"))[:] = sub["mask"].astype(np.int8)
+    ds.close()
+    fm = TileMosaic(fmask, 20, 20, 10, 10)                                     # step26:30-31
+    y0, y1 = int(yrs[0]), int(yrs[-1])
+    paths = fm.create_dly_ann_mosaics(tiles, "tmin", str(tdir), str(tmp_path / "daily"), y0, y1, "9.9.9", 50000000,
+                                      format=fmt)                             # step26:52-54
+    assert [os.path.basename(p) for p in paths] == ["tmin_%d.nc" % y for y in yrs]
+    nyr = yrs.size
+    for q, (p, y) in enumerate(zip(paths, yrs)):
+        ds_dly = ncio.open_dataset(p)
+        rows = np.nonzero(tmin.days.YEAR == y)[0]
+        np.testing.assert_array_equal(ds_dly.variables["tmin"][:], dly[rows])
+        assert ds_dly.variables["time"].units == "days since 1948-1-1 0:0:0" and "9.9.9" in ds_dly.history
+        fo = str(tmp_path / ("tmin_mthly_%d.nc" % y))
+        write_ds_mthly(ds_dly, fo, "tmin", int(y), "9.9.9", format=fmt)        # step27:33-36
+        ds_dly.close()
+        ds_m = ncio.open_dataset(fo)
+        np.testing.assert_array_equal(ds_m.variables["tmin"][:], want[12 * q:12 * q + 12])
+        assert ds_m.variables["tmin"].shape == (12, 20, 40) and ds_m.title.endswith(str(y))
+        if fmt == "NETCDF4":
+            assert ds_m.variables["tmin"].filters()["zlib"] and ds_m.variables["tmin"].chunking() == [1, 20, 40]
+        ds_m.close()
+    assert nyr >= 1
+    fn = fm.create_normals_mosaic(tiles, "tmax", str(tdir), str(tmp_path / "normals_tmax.nc"), "9.9.9", format=fmt)
+    pn, ps = mos.create_normals_mosaic(tiles, "tmax", back)
+    ds_n = ncio.open_dataset(fn)
+    np.testing.assert_array_equal(ds_n.variables["tmax_normal"][:], pn)
+    np.testing.assert_array_equal(ds_n.variables["tmax_se"][:], ps)
+    ds_n.close()

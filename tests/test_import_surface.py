@@ -1,0 +1,231 @@
+"""The reference's import surface (VERDICT r4 missing #2): a py3 translation of ``scripts/step21..27`` keeps its
+``from twx.interp import ...`` / ``from twx.db import ...`` / ``from twx.utils import ...`` lines.  The lines below are the
+scripts' own import statements, listed here as data (file:line in the comment); CPU only -- nothing is computed."""
+import datetime as dt
+import io
+import os
+
+import numpy as np
+import pytest
+
+from topowx_amd import h5nc, ncio, synth
+from topowx_amd import stationdb as sdb
+from topowx_amd.dates import get_days_metadata
+
+IMPORT_LINES = [
+    # scripts/step21_mpi_optim_nstns_norms.py:15-18
+    "from twx.db import StationSerialDataDb, STN_ID, MASK, BAD, CLIMDIV",
+    "from twx.interp import XvalTairNorm, set_optim_nstns_tair_norm, build_nstn_bandwidths, create_climdiv_optim_nstns_db",
+    "from twx.utils import StatusCheck, Unbuffered, TwxConfig",
+    # scripts/step22_mpi_set_stn_variograms.py:13-16
+    "from twx.db import StationSerialDataDb, STN_ID, MASK, BAD, get_krigparam_varname, VARIO_NUG, VARIO_PSILL, VARIO_RNG",
+    "from twx.interp import StationKrigParams",
+    # scripts/step23_mpi_optim_nstns_anoms.py:15-18
+    "from twx.db import StationSerialDataDb, STN_ID, CLIMDIV, MASK, BAD",
+    "from twx.interp import XvalTairAnom, build_nstn_bandwidths, create_climdiv_optim_nstns_db, set_optim_nstns_tair_anom",
+    # scripts/step24_mpi_xval_interp.py:11-14
+    "from twx.db import StationSerialDataDb, STN_ID, MASK, BAD, get_norm_varname, create_quick_db",
+    "from twx.interp import XvalTairOverall",
+    # scripts/step25_mpi_interp_tair.py:11-13
+    "from twx.db import LON, LAT, CLIMDIV, ELEV, TDI",
+    "from twx.interp import Tiler, TileWriter, StationDataWrkChk, PtInterpTair",
+    # scripts/step26_mosaic_tiles.py:4-5, scripts/step27_create_monthly.py:6-7
+    "from twx.interp import TileMosaic",
+    "from twx.utils import TwxConfig, mkdir_p",
+    "from twx.interp import write_ds_mthly",
+]
+
+# the four __all__ lists of the reference (interp_tair.py:22-24, station_select.py:23, optimize.py:20-23, tiling.py:23)
+REFERENCE_ALL = ["KrigTairAll", "BuildKrigParams", "GwrTairAnom", "KrigTair", "InterpTair", "StationDataWrkChk", "PtInterpTair",
+                 "StationSelect",
+                 "create_climdiv_optim_nstns_db", "XvalTairNorm", "set_optim_nstns_tair_norm", "set_optim_nstns_tair_anom",
+                 "build_nstn_bandwidths", "StationKrigParams", "XvalTairAnom", "XvalTairOverall",
+                 "Tiler", "TileWriter", "TileGridInfo", "TileMosaic", "write_ds_mthly"]
+OUT_OF_SCOPE = ["XvalOutlier"]          # optimize.py:84-234: station QA before the serially-complete database
+
+
+@pytest.mark.parametrize("line", IMPORT_LINES)
+def test_script_import_lines_execute(line):
+    ns = {}
+    exec(line, ns)
+    assert all(v is not None for k, v in ns.items() if not k.startswith("__"))
+
+
+def test_every_reference_export_resolves():
+    import twx.interp
+    import topowx_amd.interp as ti
+    for name in REFERENCE_ALL:
+        assert hasattr(twx.interp, name) and name in ti.__all__, name
+        assert getattr(twx.interp, name) is getattr(ti, name)
+    for name in OUT_OF_SCOPE:
+        assert not hasattr(twx.interp, name)
+    import twx
+    import twx.db
+    assert twx.db.STN_ID == "station_id" and twx.db.get_krigparam_varname(3, twx.db.VARIO_RNG) == "vario_rng03"
+    assert twx.db.StationSerialDataDb is sdb.StationSerialDataDb and isinstance(twx.__version__, str)
+
+
+def test_twx_utils(tmp_path):
+    from twx.utils import StatusCheck, TwxConfig, Unbuffered, mkdir_p
+    ini = tmp_path / "twx.ini"
+    ini.write_text("[TOPOWX_CONFIG]\nTWX_DATA_ROOT=%s\nINTERP_START_DATE=1948-01-01\nINTERP_END_DATE=2015-12-31\n"
+                   "TWX_DATA_VERSION=1.2.0\nSTN_BBOX=-126.0,22.0,-64.0,53.0\n" % (tmp_path / "root"))
+    cfg = TwxConfig(str(ini))
+    root = str(tmp_path / "root")
+    assert cfg.fpath_stndata_nc_serial_tmin == os.path.join(root, "station_data", "infill", "serial_tmin.nc")
+    assert cfg.path_interp_optim_anoms.endswith(os.path.join("infill", "optim_anom")) and os.path.isdir(cfg.path_interp_optim_norms)
+    assert cfg.path_predictor_rasters == os.path.join(root, "rasters", "conus_interp_grids", "ncdf")
+    assert os.path.isdir(cfg.path_tile_out) and os.path.isdir(cfg.path_mosaic_monthly) and cfg.twx_data_version == "1.2.0"
+    assert cfg.stn_bbox == (-126.0, 22.0, -64.0, 53.0) and cfg.interp_end_date.year == 2015
+    with pytest.raises(IOError):
+        TwxConfig(str(tmp_path / "missing.ini"))
+    buf = io.StringIO()
+    chk = StatusCheck(10, 4, out=buf)
+    for _ in range(9):
+        chk.increment()
+    assert buf.getvalue().count("Total items processed") == 2 and "2 items to go" in buf.getvalue()
+    u = Unbuffered(buf)
+    u.write("x")
+    assert buf.getvalue().endswith("x")
+    mkdir_p(str(tmp_path / "a" / "b"))
+    mkdir_p(str(tmp_path / "a" / "b"))
+
+
+FORMATS = [pytest.param("NETCDF4", marks=pytest.mark.skipif(not h5nc.available(), reason="libhdf5 not loadable")),
+           "NETCDF3_64BIT"]
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_tiler_on_netcdf_datasets_equals_the_grid_form(tmp_path, fmt):
+    """step25:266-289: ``Tiler(ds_mask, ds_attrs, ty, tx, cy, cx, path_out, check_done)`` on predictor rasters in netCDF
+    files yields the chunks of the in-memory form, bit for bit; tiles with a directory under ``path_out`` are skipped."""
+    from twx.interp import Tiler
+    grid = synth.make_grid("C1", nrows=16, ncols=24)
+    grid["mask"][0:8, 0:8] = 0                                     # tile h00v00 has no valid cell
+    files = {}
+
+    def raster(name, a, dtype):
+        p = str(tmp_path / (name + ".nc"))
+        ds = ncio.open_dataset(p, "w", fmt)
+        ds.createDimension("lat", 16)
+        ds.createDimension("lon", 24)
+        ds.createVariable("lat", "f8", ("lat",))[:] = grid["lat"]
+        ds.createVariable("lon", "f8", ("lon",))[:] = grid["lon"]
+        ds.createVariable(name, dtype, ("lat", "lon"))[:] = a
+        ds.close()
+        files[name] = ncio.open_dataset(p)
+        return files[name]
+    ds_mask = raster("mask", grid["mask"].astype(np.int8), "i1")
+    attrs = [("elev", raster("elev", grid["elev"], "f4")), ("tdi", raster("tdi", grid["tdi"], "f4")),
+             ("climdiv", raster("climdiv", grid["climdiv"], "i4"))]
+    attrs += [("tmin%02d" % (m + 1), raster("tmin%02d" % (m + 1), grid["lst_night"][m], "f4")) for m in range(12)]
+    attrs += [("tmax%02d" % (m + 1), raster("tmax%02d" % (m + 1), grid["lst_day"][m], "f4")) for m in range(12)]
+    out = tmp_path / "tiles"
+    out.mkdir()
+    a = Tiler(ds_mask, attrs, 8, 8, 4, 4, str(out), False)
+    b = Tiler(grid, 8, 8, 4, 4)
+    assert a.tile_ids == b.tile_ids and a.tile_rc == b.tile_rc and a.ntiles == b.ntiles == 5 and a.chk_size_i == 32
+    assert "h00v00" not in a.tile_rc and a.tile_ids[0] == "h01v00"
+    n = 0
+    for (ka, wa), (kb, wb) in zip(a, b):
+        assert ka == kb
+        np.testing.assert_array_equal(wa, wb)
+        n += 1
+    assert n == 5 * 4
+    info = a.build_tile_grid_info()
+    assert info.nchks == 20 and info.chks_per_tile == 4
+    (out / "h01v00").mkdir()                                       # done tiles are skipped (tiling.py:258-275)
+    (out / "h02v01").mkdir()
+    c = Tiler(ds_mask, attrs, 8, 8, 4, 4, str(out), True)
+    assert sorted(set(k for k, *_ in c.tile_chks)) == [1, 2, 3] and c.ntiles == 3
+    d = Tiler(ds_mask, attrs, 8, 8, 4, 4, str(out), [4])
+    assert [k for k, _ in d] == [4] * 4
+    for f in files.values():
+        f.close()
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_add_stn_variable_and_file_route_of_set_optim_nstns(tmp_path, fmt):
+    """step22:85-112 (``add_stn_variable`` + ``dsvars[...][x] = value`` + ``stn_da.ds.sync()``) and optimize.py:268-316
+    (``set_optim_nstns_tair_norm(stnda, path_xval_ds)``) on a database opened ``mode='r+'``: the file holds what the
+    table holds."""
+    from twx.db import StationSerialDataDb, get_krigparam_varname, get_optim_varname, VARIO_NUG
+    from twx.interp import create_climdiv_optim_nstns_db, set_optim_nstns_tair_norm
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 1, 10))
+    grid = synth.make_grid("C1", nrows=20, ncols=20)
+    db = synth.make_stations(grid["bbox"], 30, 4, "tmin", days, with_obs=True)
+    db.stns[sdb.CLIMDIV] = np.where(np.arange(30) < 12, 101.0, 202.0)
+    db.stns[sdb.CLIMDIV][29] = np.nan
+    keep = [f for f in db.stns.dtype.names if not f.startswith(("vario_nug", "optim_nnghs0", "optim_nnghs1"))]
+    slim = sdb.StationSerialDataDb(db.stns[keep].copy(), "tmin", days, db.var)
+    p = str(tmp_path / "serial_tmin.nc")
+    ncio.write_station_db(p, slim, format=fmt)
+    stn_da = StationSerialDataDb(p, "tmin", mode="r+")
+    assert stn_da.ds is not None and "vario_nug01" not in stn_da.stns.dtype.names
+    v = stn_da.add_stn_variable(get_krigparam_varname(1, VARIO_NUG), "vario_nug01", "C**2", "f8")
+    assert np.isnan(stn_da.stns["vario_nug01"]).all()
+    x = stn_da.stn_idxs[stn_da.stn_ids[5]]
+    v[x] = 0.25
+    v[7] = 0.5
+    stn_da.ds.sync()
+    # the bandwidth files of two divisions, then the reference's call
+    ladder = np.array([35, 50, 70], np.int32)
+    for div, ids in ((101, stn_da.stn_ids[:12]), (202, stn_da.stn_ids[12:29])):
+        ds = create_climdiv_optim_nstns_db(str(tmp_path), "tmin", ids, ladder, div, format=fmt)
+        mae = np.ones((12, 3, ids.size))
+        mae[:, 1 if div == 101 else 2, :] = 0.5
+        mae[3, :, 0] = np.nan                                       # a station whose month failed stays masked
+        ds.variables["mae"][:] = np.where(np.isnan(mae), ncio.FILL_F8, mae)
+        ds.close()
+    set_optim_nstns_tair_norm(stn_da, str(tmp_path))
+    assert (stn_da.stns[get_optim_varname(4)][:12] == 50).all() and (stn_da.stns[get_optim_varname(12)][12:29] == 70).all()
+    assert np.isnan(stn_da.stns[get_optim_varname(1)][29])          # no climate division: left at the fill value
+    stn_da.close()
+    back = StationSerialDataDb(p, "tmin")
+    want = np.full(30, np.nan)
+    want[[5, 7]] = [0.25, 0.5]
+    np.testing.assert_array_equal(back.stns["vario_nug01"], want)
+    for m in range(1, 13):
+        np.testing.assert_array_equal(back.stns[get_optim_varname(m)], stn_da.stns[get_optim_varname(m)])
+    np.testing.assert_array_equal(back.var, db.var)
+    # a missing division file fails like Dataset(fpath) (optimize.py:302-304)
+    os.remove(ncio.climdiv_optim_nstns_path(str(tmp_path), "tmin", 202))
+    with pytest.raises(IOError):
+        set_optim_nstns_tair_norm(back, str(tmp_path))
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_step24_writer_shape(tmp_path, fmt):
+    """step24:75-123: open the database read-only and close its file, ``create_quick_db`` the output, reopen it ``r+``,
+    add the twelve normals columns, assign one station's daily series and normals INTO THE FILE, sync; read back."""
+    from twx.db import StationSerialDataDb, create_quick_db, get_norm_varname
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 2, 9))
+    grid = synth.make_grid("C1", nrows=20, ncols=20)
+    db = synth.make_stations(grid["bbox"], 12, 6, "tmax", days, with_obs=True)
+    src = str(tmp_path / "serial_tmax.nc")
+    ncio.write_station_db(src, db, format=fmt)
+    stn_da = StationSerialDataDb(src, "tmax")
+    stns, ddays = stn_da.stns, stn_da.days
+    stn_da.ds.close()
+    out = str(tmp_path / "xval_interp_tmax.nc")
+    create_quick_db(out, stns, ddays, [("tmax", "f4", ncio.FILL_F4, "maximum air temperature", "C")], format=fmt)
+    stnda_out = StationSerialDataDb(out, "tmax", mode="r+")
+    assert stnda_out.var.shape == (days.size, 12) and (stnda_out.var == ncio.FILL_F4).all()
+    names = [get_norm_varname(m) for m in range(1, 13)]
+    for n in names:
+        stnda_out.add_stn_variable(n, "", units="C", dtype="f8", fill_value=ncio.FILL_F8)
+    stnda_out.ds.sync()
+    x = 4
+    series = np.linspace(-5, 5, days.size).astype(np.float32)
+    stnda_out.ds.variables["tmax"][:, x] = series
+    for i, n in enumerate(names):
+        stnda_out.ds.variables[n][x] = 10.0 + i
+    stnda_out.ds.sync()
+    stnda_out.close()
+    back = StationSerialDataDb(out, "tmax")
+    np.testing.assert_array_equal(back.var[:, x], series)
+    assert (back.var[:, :x] == ncio.FILL_F4).all()
+    assert back.stns[names[11]][x] == 21.0 and np.isnan(back.stns[names[0]][[0, 11]]).all()
+    np.testing.assert_array_equal(back.stns[sdb.LON], db.stns[sdb.LON])
+    if fmt == "NETCDF4":
+        assert back.ds.variables["tmax"].chunking() == [days.size, 1] and back.ds.variables["tmax"].filters()["zlib"]

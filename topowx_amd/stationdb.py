@@ -1,12 +1,13 @@
-"""In-memory serially-complete station database.
+"""Serially-complete station database.
 
-Mirrors the *schema* of the reference's ``StationSerialDataDb``
-(``twx/db/station_data.py:547-666``): a structured station table ``stns`` whose
-fields are the per-station netCDF variables (missing -> NaN,
-``station_data.py:159-164``), the day metadata ``days``, the month row index
-``mth_idx`` and the ``(time, station_id)`` float32 observation matrix ``var``.
-netCDF I/O is out of scope for the hot path; a database
-is built from arrays (``topowx_amd.synth``) or loaded from ``.npz``.
+Mirrors the reference's ``StationSerialDataDb`` (``twx/db/station_data.py:547-666``): a structured station
+table ``stns`` whose fields are the per-station netCDF variables (missing -> NaN, ``station_data.py:159-164``),
+the day metadata ``days``, the month row index ``mth_idx`` and the ``(time, station_id)`` float32 observation
+matrix ``var``.  A database is opened from its netCDF file -- NetCDF-4 as the reference writes it, or classic
+netCDF -- through ``topowx_amd.ncio`` (``StationSerialDataDb(nc_path, var_name, mode=)`` as in the reference), built
+from arrays (``topowx_amd.synth``) or loaded from ``.npz``.  The table and the observations live in memory (they are
+uploaded to HBM once); a database opened with ``mode='r+'`` keeps its file open as ``ds`` and
+``add_stn_variable`` writes through to it (step22:85-112, optimize.py:288-314).
 """
 import os
 
@@ -84,12 +85,16 @@ class StationSerialDataDb(object):
 
     def __init__(self, stns, var_name, days=None, obs=None, mode="r"):
         """``stns``: the structured station table -- or, as in the reference (``StationSerialDataDb(nc_path, var_name)``,
-        station_data.py:554; step25:53-54, optimize.py:229), the PATH of a station database, read through
-        ``topowx_amd.ncio`` (classic / 64-bit-offset netCDF; ``mode`` is accepted for call-site parity, the table
-        lives in memory and is written back with ``ncio.write_station_db``)."""
+        station_data.py:554; step25:53-54, optimize.py:229), the PATH of a station database (NetCDF-4 or classic
+        netCDF), read through ``topowx_amd.ncio``.  The file stays open as ``ds`` (read-only, or writable with
+        ``mode='r+'`` for ``add_stn_variable``, step22:146-166, step24:88-97); the table and the observations always
+        live in memory."""
+        self.ds = None
         if isinstance(stns, (str, os.PathLike)):
             from . import ncio
-            stns, _, days, obs = ncio.read_station_db_arrays(os.fspath(stns), var_name)
+            path = os.fspath(stns)
+            stns, _, days, obs = ncio.read_station_db_arrays(path, var_name)
+            self.ds = ncio.open_dataset(path, "r" if mode == "r" else "a")   # station_data.py:572 (callers close / sync it: step24:82)
         stns = np.asarray(stns)
         ids = stns[STN_ID]
         if ids.size > 1 and not np.all(ids[1:] > ids[:-1]):
@@ -125,6 +130,48 @@ class StationSerialDataDb(object):
             obs = obs.reshape(obs.shape[0])
         return obs
 
+    def add_stn_variable(self, varname, long_name, units, dtype, fill_value=None, reset=True):
+        """``add_stn_variable`` (station_data.py:295-341): a new (or reset) per-station variable.  Returns an object
+        with the netCDF variable's assignment syntax (``v[i] = x``, ``v[mask] = x``, ``v[:]``): values land in the
+        in-memory table ``stns[varname]`` (fill value <-> NaN, as ``_build_stn_struct`` reads them) and, when the
+        database was opened from a file with ``mode='r+'``, in the file as well (``ds.sync()`` flushes)."""
+        from . import ncio
+        dt = np.dtype(dtype)
+        key = dt.str[1:]
+        fill = ncio.DEFAULT_FILLS.get(key) if fill_value is None else fill_value
+        if varname not in self.stns.dtype.names:
+            new = np.empty(self.stns.size, dtype=self.stns.dtype.descr + [(varname, np.float64)])
+            for f in self.stns.dtype.names:
+                new[f] = self.stns[f]
+            new[varname] = np.nan
+            self.stns = new
+        elif reset:
+            self.stns[varname] = np.nan
+        fvar = None
+        if self.ds is not None and getattr(self.ds, "mode", "r") != "r":
+            if varname not in self.ds.variables:
+                fvar = self.ds.createVariable(varname, dt, (STN_ID,), fill_value=fill)
+                fvar.long_name, fvar.units = long_name, units
+                if self.ds.data_model != "NETCDF4" and self.stns.size:
+                    fvar[:] = fill
+            else:
+                fvar = self.ds.variables[varname]
+                if reset and self.stns.size:
+                    fvar[:] = fill
+            self.ds.sync()
+        return _StnVariable(self, varname, fvar, fill)
+
+    def close(self):
+        if self.ds is not None:
+            self.ds.close()
+            self.ds = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -- persistence (npz; the netCDF layout lives in topowx_amd/ncio.py) -----
     def save(self, path, compress=True):
         (np.savez_compressed if compress else np.savez)(path, stns=self.stns, var_name=self.var_name,
@@ -141,6 +188,30 @@ class StationSerialDataDb(object):
         days = get_days_metadata(_d(int(z["ymd0"])), _d(int(z["ymd1"])))
         obs = z["obs"]
         return cls(z["stns"], str(z["var_name"]), days, obs if obs.size else None)
+
+
+class _StnVariable(object):
+    """What ``add_stn_variable`` returns: assignment into the station table and (if open) the file variable."""
+
+    def __init__(self, db, name, fvar, fill):
+        self._db, self.name, self._fvar, self._fill = db, name, fvar, fill
+
+    def __setitem__(self, key, value):
+        v = np.asarray(np.ma.filled(value, np.nan) if np.ma.isMaskedArray(value) else value, np.float64)
+        col = self._db.stns[self.name]
+        col[key] = np.where(v == self._fill, np.nan, v) if self._fill is not None else v
+        if self._fvar is not None:
+            out = np.where(np.isnan(col), self._fill, col) if self._fill is not None else col
+            self._fvar[:] = out.astype(self._fvar.dtype)
+
+    def __getitem__(self, key):
+        return np.ma.masked_invalid(self._db.stns[self.name][key])
+
+    def __setattr__(self, name, value):
+        if name.startswith("_") or name == "name":
+            object.__setattr__(self, name, value)
+        elif self._fvar is not None:
+            self._fvar.setncattr(name, value)
 
 
 class StationDataWrkChk(StationSerialDataDb):

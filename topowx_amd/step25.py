@@ -66,14 +66,19 @@ def tiles_done(out_dir, tile_ids):
     return {t for t in tile_ids if t in names or (t + ".npz") in names}
 
 
+# out_format -> netCDF container: "nc" = the reference's NetCDF-4 where libhdf5 is loadable (else classic netCDF)
+NC_FORMATS = {"nc": None, "nc4": "NETCDF4", "nc3": "NETCDF3_64BIT"}
+
+
 def _write_tile(out_dir, out_format, info, tile_id, store, days):
     """Write under a temporary name, rename when complete (an interrupted tile is not mistaken for a finished one)."""
-    if out_format == "nc":                                                     # step25:181-185
+    if out_format in NC_FORMATS:                                               # step25:181-185
         from .ncio import TileWriter
         tmp = os.path.join(out_dir, tile_id + ".part")
         shutil.rmtree(tmp, ignore_errors=True)
         os.makedirs(tmp)
-        writer = TileWriter(info, tmp)      # files go to <tmp>/<tile_id>/<tile_id>_<var>.nc, the directory is moved when complete
+        # files go to <tmp>/<tile_id>/<tile_id>_<var>.nc, the directory is moved when complete
+        writer = TileWriter(info, tmp, format=NC_FORMATS[out_format])
         for v in ("tmin", "tmax"):
             writer.write_tile_chunk(tile_id, v, days, 0, 0, store.a.get("daily_" + v), store.a["norm_" + v],
                                     store.a["se_" + v], store.a["ninvalid"])

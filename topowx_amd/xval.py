@@ -21,6 +21,8 @@ Layout choice: the reference's step23 hands its writer ``
 variable shaped ``[12, n_bandwidths, nstn]``; this module always produces month-major ``[12, n_bandwidths, nstn]``,
 which is what ``set_optim_nstns_tair_*`` index (``mae_climdiv[mth - 1, :, :]``, optimize.py:311).
 """
+import os
+
 import numpy as np
 
 from .interp.optimize import XvalTairAnom, XvalTairNorm, XvalTairOverall, build_nstn_bandwidths
@@ -238,7 +240,7 @@ def set_optim_nstns(stns, stn_ids, mae, ladder, namer):
 def write_optim_nstns_files(path_out, stn_da, stn_ids, mae, ladder=DFLT_LADDER):
     """The side product of the step21 / step23 writer rank (step21:83-128, optimize.py:39-82): one
     ``optim_nstns_<var>_climdiv<id>.nc`` per climate division holding the MAE cube ``[12, n_bandwidths, stations of
-    the division]`` of the cross-validated stations (NetCDF-3 through ``topowx_amd.ncio``).  Returns the paths."""
+    the division]`` of the cross-validated stations (through ``topowx_amd.ncio``: NetCDF-4, or classic netCDF without libhdf5).  Returns the paths."""
     import os
     from . import ncio
     os.makedirs(path_out, exist_ok=True)
@@ -285,13 +287,36 @@ def set_optim_nstns_from_files(stn_da, path_xval_ds, namer, strict=True):
     return chosen
 
 
-def set_optim_nstns_tair_norm(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
-    """optimize.py:268-316 (the end of step21): writes ``optim_nnghsMM``."""
+def _set_optim_files(stn_da, path_xval_ds, namer, long_name):
+    """The reference's route (optimize.py:285-316 / :339-370): ``add_stn_variable`` for the twelve months, then the
+    per-division files; with a database opened ``mode='r+'`` the columns reach its file."""
+    cols = {}
+    if hasattr(stn_da, "add_stn_variable"):
+        for mth in range(1, 13):
+            cols[mth] = stn_da.add_stn_variable(namer(mth), long_name % mth, "", "f8")   # (reset, as :292-295)
+    chosen = set_optim_nstns_from_files(stn_da, path_xval_ds, namer)
+    for mth, v in cols.items():
+        v[:] = stn_da.stns[namer(mth)]                         # write-through of what the loop set
+    if getattr(stn_da, "ds", None) is not None:
+        stn_da.ds.sync()                                       # optimize.py:316
+    return chosen
+
+
+def set_optim_nstns_tair_norm(stn_da, stn_ids, mae=None, ladder=DFLT_LADDER):
+    """optimize.py:268-316 (the end of step21): writes ``optim_nnghsMM``.  Two call shapes: the reference's
+    ``set_optim_nstns_tair_norm(stnda, path_xval_ds)`` -- from the per-division MAE files under a directory -- and the
+    array form ``(stn_da, stn_ids, mae[12, nb, n], ladder)`` the GPU farms use."""
+    if mae is None and isinstance(stn_ids, (str, os.PathLike)):
+        return _set_optim_files(stn_da, os.fspath(stn_ids), get_optim_varname,
+                                "Optimal number of neighbors to use for monthly normal interpolation for month %d")
     return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_varname)[1]
 
 
-def set_optim_nstns_tair_anom(stn_da, stn_ids, mae, ladder=DFLT_LADDER):
-    """optimize.py:318-374 (the end of step23): writes ``optim_nnghs_anomMM``."""
+def set_optim_nstns_tair_anom(stn_da, stn_ids, mae=None, ladder=DFLT_LADDER):
+    """optimize.py:318-374 (the end of step23): writes ``optim_nnghs_anomMM``; same two call shapes."""
+    if mae is None and isinstance(stn_ids, (str, os.PathLike)):
+        return _set_optim_files(stn_da, os.fspath(stn_ids), get_optim_anom_varname,
+                                "Optimal number of neighbors to use for daily anomaly interpolation for month %d")
     return set_optim_nstns(stn_da.stns, stn_ids, mae, ladder, get_optim_anom_varname)[1]
 
 
