@@ -87,8 +87,14 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
     ap.add_argument("--int16-window", type=int, default=24, help="edge of the cell window whose packed int16 days are compared with the oracle")
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_tile / c5 / c3 records (N = 1)")
-    ap.add_argument("--configs", default="c4_tile,c5,c3", help="which of the other configurations to time (c3 = the full "
-                                                               "configs[2] grid; c3_strip = the 750x7000 strip of the strong record)")
+    ap.add_argument("--configs", default="c2_fitted,c4_tile,c5,c3,c4",
+                    help="which of the other configurations to time (c2_fitted = the headline tile under the variograms step21 -> "
+                         "step22 fit on its own database; c3 = the full configs[2] grid; c4 = configs[3] itself: the full grid x "
+                         "25 203 days streamed to pinned host memory; c3_strip = the 750x7000 strip of the strong record)")
+    ap.add_argument("--c4-tiles", type=int, default=0, help="c4 record: only the first N tiles of the deal (0 = all 323; tests)")
+    ap.add_argument("--c4-rows", type=int, default=0, help="c4 record on a cut of the grid (tests; 0 = the full 3250x7000 grid)")
+    ap.add_argument("--c4-cols", type=int, default=0)
+    ap.add_argument("--c4-years", type=int, default=69, help="c4 record: years of days from 1948 (69 = 1948-2016, 25 203 days)")
     ap.add_argument("--force-configs", action="store_true", help="time them also on a reduced --size (tests)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
                     help="auto: N = 1 headline (+ configs); N > 1 weak headline + a 'strong' record.  strong: the tile farm "
@@ -503,6 +509,171 @@ def strong_daily_run(env, args):
     return rec
 
 
+def c2_fitted_record(env, args, ctx, stn, grid, g, o, d_norm, d_stat, stream, headline_uk_ms, headline_value):
+    """The headline tile under the pipeline's OWN variograms: step21 (leave-one-out bandwidth
+    optimisation, step21:34-64) -> ``set_optim_nstns_tair_norm`` -> step22 (every station's variogram fitted with the
+    optimised bandwidths: nugget = min gamma, interp.R:304-359; step22:33-66) run on the C2 station database itself;
+    then the SAME tile, bandwidths and launches as the headline, with only the ``vario_*`` columns replaced by the fitted
+    ones -- so that ``uk_ms`` differs from the headline's by the systems routed to the fp64 covariance build alone."""
+    from topowx_amd import _lib, stationdb as sdb, xval
+    t0 = time.perf_counter()
+    work = sdb.StationDataWrkChk(stn.stns.copy(), "tmin", stn.days, None)
+    ids = xval.xval_station_ids(work)
+    kw = dict(stn_ids=ids, device=env.local)
+    _, mae = xval.optim_nstns_norms(work, "tmin", **kw)
+    xval.set_optim_nstns_tair_norm(work, ids, mae)
+    _, nug, psill, rng = xval.set_stn_variograms(work, "tmin", **kw)
+    fit_s = time.perf_counter() - t0
+    fitted = sdb.StationDataWrkChk(stn.stns.copy(), "tmin", stn.days, None)
+    for m in range(1, 13):
+        for par in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG):
+            name = sdb.get_krigparam_varname(m, par)
+            fitted.stns[name] = work.stns[name]
+    ctx.set_stations(_lib.TMIN, fitted, with_obs=False)
+    kern = []
+    steps = max(3, args.steps // 2)
+    elapsed = timed(env, lambda: ctx.interp_grid_dev(g, o, _lib.VAR_TMIN_BIT, stream), steps, 1,
+                    lambda keep: kern.append(ctx.timing()) if keep else ctx.timing())
+    status = d_stat.cpu().numpy()
+    ok = int((status == 0).sum())
+    fin = np.isfinite(nug) & np.isfinite(psill)
+    ratio = nug[fin] / np.where(psill[fin] > 0, psill[fin], np.nan)
+    ratio = ratio[np.isfinite(ratio)]
+    uk_ms = float(np.mean([t["uk_ms"] for t in kern]))
+    rec = {"value": ok * 12 * steps / elapsed, "unit": "cell-months/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "workload": "c2_fitted: the headline's C2 tile, bandwidths and launches; vario_nug / vario_psill / vario_rng of all "
+                       "%d cross-validated stations replaced by what step21 -> set_optim_nstns_tair_norm -> step22 fit on the same "
+                       "database (topowx_amd.xval; %d station-months fitted)" % (len(ids), int(np.isfinite(nug).sum())),
+           "cells_ok": ok, "cells_failed_by_status": {str(int(c)): int(n) for c, n in zip(*np.unique(status[status != 0], return_counts=True))},
+           "uk_ms": uk_ms, "uk_ms_headline": headline_uk_ms, "uk_ms_ratio_to_headline": uk_ms / headline_uk_ms,
+           "value_ratio_to_headline": (ok * 12 * steps / elapsed) / headline_value,
+           "uk_solves": int(kern[-1]["uk_solves"]), "systems_on_fp64_covariance_build": int(kern[-1]["uk_f64_solves"]),
+           "fitted_variograms": {"nug_over_psill_quantiles_5_25_50_75_95": [float(x) for x in np.quantile(ratio, [.05, .25, .5, .75, .95])] if ratio.size else None,
+                                 "frac_below_one_sixteenth": float((ratio < 1 / 16.).mean()) if ratio.size else None,
+                                 "pure_nugget_frac": float((rng[np.isfinite(rng)] == 0).mean()) if np.isfinite(rng).any() else None,
+                                 "range_km_quantiles_5_50_95": [float(x) for x in np.quantile(rng[np.isfinite(rng) & (rng > 0)], [.05, .5, .95])]
+                                 if (np.isfinite(rng) & (rng > 0)).any() else None},
+           "fit_s": fit_s}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as orc
+        orc.build()
+        n = 16
+        cores = os.cpu_count() or 1
+        r0 = c0 = max(0, args.size // 2 - n // 2)
+        ref = orc.interp_grid(orc.Db(fitted), None, orc.params(), grid, nthreads=cores, rows=slice(r0, r0 + n), cols=slice(c0, c0 + n))
+        got = d_norm[:, r0:r0 + n, c0:c0 + n].cpu().numpy().astype(np.float64)
+        okw = ref["status"] == 0
+        rec["parity_max_abs_degC"] = float(np.abs(got - ref["norm_tmin"])[:, okw].max()) if okw.any() else None
+        rec["parity_cells"] = int(okw.sum())
+        rec["status_equal_oracle"] = bool(np.array_equal(status[r0:r0 + n, c0:c0 + n], ref["status"]))
+    ctx.set_stations(_lib.TMIN, stn, with_obs=False)            # (the records after this one run on the headline table)
+    return rec
+
+
+def c4_full_record(env, args):
+    """BASELINE.json configs[3] ITSELF on one GPU: the full 3250x7000 seed-7 masked grid, 12 000-station
+    seed-2 tables with the 1948-2016 observations (25 203 days), every tile holding a valid cell through
+    ``driver.interp_tiles_streamed`` -- kernels of tile t + 1 over the copy-out of tile t, daily int16 + normals + SE to
+    pinned host memory, a discarding sink (the reference's workers hand each chunk to the writer rank, step25:177-196;
+    here the sink stands where the writer would).  Shape: step25:266-314,126-185.  PCIe-inclusive by construction."""
+    import datetime as dt
+    from topowx_amd import _lib, driver, synth
+    from topowx_amd.dates import get_days_metadata
+    T = args.strip_tile
+    t_s = time.perf_counter()
+    if args.c4_rows and args.c4_cols:      # (tests: a cut of the same generator, as the strip records)
+        grid = synth.make_grid("C3", nrows=args.c4_rows // T * T, ncols=args.c4_cols // T * T, lat_north=45.0, full_mask=False)
+    else:
+        grid = synth.make_grid("C3")
+    days = get_days_metadata(dt.date(1948, 1, 1), dt.date(1947 + args.c4_years, 12, 31))
+    nd = int(days.size)
+    seed = synth.CONFIGS["C3"][5]
+    tmin = synth.make_stations(grid["bbox"], args.strip_nstns, seed, "tmin", days, with_obs=True)
+    tmax = synth.make_stations(grid["bbox"], args.strip_nstns, seed, "tmax", days, with_obs=True)
+    ctx = _lib.Context(device=env.local)
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    tiles = driver.tile_list(grid["mask"], T, T)
+    mine = driver.assign_tiles(tiles, 1)[0]                       # the LPT deal at world 1: its order is the run order
+    if args.c4_tiles:
+        mine = mine[:args.c4_tiles]
+    setup_s = time.perf_counter() - t_s
+    # cells for the oracle check: four per tile from four tiles -- the first and the last of the run, the tile with the FEWEST
+    # valid cells (an edge of the mask) and one from the middle
+    by_valid = sorted(range(len(mine)), key=lambda q: mine[q][3])
+    pick_tiles = sorted({0, len(mine) - 1, by_valid[0], len(mine) // 2})
+    picks = {}
+    rng = np.random.default_rng(11)
+    for q in pick_tiles:
+        k, i, j, _ = mine[q]
+        rr, cc = np.nonzero(grid["mask"][i:i + T, j:j + T])
+        sel = rng.choice(rr.size, min(4, rr.size), replace=False)
+        picks[k] = [(int(rr[s]), int(cc[s])) for s in sel]
+    kept = {}
+    acc = {"bytes": 0, "ok": 0, "cells": 0, "fixed_cells": 0, "fixed_days": 0, "fail": {}}
+
+    def sink(k, arrays):
+        acc["bytes"] += sum(v.nbytes for v in arrays.values() if hasattr(v, "nbytes"))
+        st = arrays["status"]
+        valid = st != -1
+        acc["cells"] += int(valid.sum())
+        acc["ok"] += int((st == 0).sum())
+        for c, n in zip(*np.unique(st[valid & (st != 0)], return_counts=True)):
+            acc["fail"][int(c)] = acc["fail"].get(int(c), 0) + int(n)
+        ni = arrays["ninvalid"]
+        fx = (st == 0) & (ni > 0)
+        acc["fixed_cells"] += int(fx.sum())
+        acc["fixed_days"] += int(ni[fx].sum())
+        for (r, c) in picks.get(k, ()):
+            kept[(k, r, c)] = {n: np.array(arrays[n][..., r, c]) for n in ("daily_tmin", "daily_tmax", "norm_tmin", "norm_tmax",
+                                                                            "se_tmin", "se_tmax", "ninvalid", "status")}
+
+    driver.interp_tiles_streamed(ctx, grid, mine[:1], T, T, daily=True, sink=lambda k, a: None)     # warm-up: workspace, pinned slots
+    tile_ms = []
+    t0 = time.perf_counter()
+    _, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, mine, T, T, daily=True, sink=sink, tile_ms=tile_ms)
+    wall = time.perf_counter() - t0
+    ms = np.array([m for _, m in tile_ms])
+    units = acc["ok"] * nd * 2
+    rec = {"value": units / wall, "unit": "cell-days/s (Tmin + Tmax daily int16 + normals + SE + ninvalid, streamed to pinned host memory; "
+                                          "PCIe-inclusive, end to end)",
+           "workload": "c4: BASELINE.json configs[3] -- the FULL %dx%d seed-7 masked grid, %d stations per variable (seed %d), %d days "
+                       "(1948-01-01 .. %d-12-31), %d tiles of %dx%d in the LPT order of assign_tiles(world = 1), "
+                       "driver.interp_tiles_streamed with a discarding sink" % (grid["mask"].shape + (args.strip_nstns, seed, nd, 1947 + args.c4_years, len(mine), T, T)),
+           "n_gpus": 1, "wall_s": wall, "tiles": len(mine), "cells_valid": acc["cells"], "cells_ok": acc["ok"],
+           "cell_days": units, "failures_by_status": {str(k): v for k, v in sorted(acc["fail"].items())},
+           "cells_with_fixed_days": acc["fixed_cells"], "fixed_days": acc["fixed_days"],
+           "device_only_cell_days_per_s": units / (dev_ms * 1e-3), "device_ms_total": dev_ms,
+           "device_ms_per_tile": {"min": float(ms.min()), "median": float(np.median(ms)), "max": float(ms.max())},
+           "d2h_bytes": acc["bytes"], "d2h_GBps": acc["bytes"] / wall / 1e9,
+           "setup_s": setup_s}
+    if not args.no_cpu_baseline and kept:
+        from oracle import pyoracle as orc
+        orc.build()
+        dbn, dbx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
+        origin = {k: (i, j) for k, i, j, _ in mine}
+        worst_n, worst_lsb, flips, nvals, ninv_eq, stat_eq = 0.0, 0, 0, 0, True, True
+        for (k, r, c), got in kept.items():
+            i, j = origin[k]
+            want = orc.interp_grid(dbn, dbx, prm, grid, daily=True, nthreads=1, rows=slice(i + r, i + r + 1), cols=slice(j + c, j + c + 1))
+            stat_eq = stat_eq and int(want["status"][0, 0]) == int(got["status"])
+            if want["status"][0, 0] != 0:
+                continue
+            ninv_eq = ninv_eq and int(want["ninvalid"][0, 0]) == int(got["ninvalid"])
+            for n in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
+                worst_n = max(worst_n, float(np.abs(got[n].astype(np.float64) - want[n][:, 0, 0]).max()))
+            for n in ("daily_tmin", "daily_tmax"):
+                dd = np.abs(got[n].astype(np.int64) - want[n][:, 0, 0].astype(np.int64))
+                worst_lsb = max(worst_lsb, int(dd.max()))
+                flips += int((dd != 0).sum())
+                nvals += dd.size
+        rec["spot_check_vs_oracle"] = {"cells": len(kept), "tiles": len(picks), "tile_valid_cells": [mine[q][3] for q in pick_tiles],
+                                       "normals_max_abs_degC": worst_n, "int16_max_abs_lsb": worst_lsb,
+                                       "int16_values": nvals, "int16_differing": flips, "ninvalid_equal": ninv_eq, "status_equal": stat_eq}
+    ctx.close()
+    return rec
+
+
 def config5_record(env, args):
     """BASELINE.json configs[4]: leave-one-out cross-validation + bandwidth optimisation over all stations."""
     from topowx_amd import xval
@@ -738,6 +909,10 @@ def main():
     if world == 1 and not args.no_configs and (args.size == 250 or args.force_configs):
         want_cfg = [c for c in args.configs.split(",") if c]
         cfg = {}
+        if "c2_fitted" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c2_fitted"] = c2_fitted_record(env, args, ctx, stn, grid, g, o, d_norm, d_stat, stream, uk_ms, value)
+            cfg["c2_fitted"]["record_wall_s"] = time.perf_counter() - t1
         if "c4_tile" in want_cfg:
             t1 = time.perf_counter()
             cfg["c4_tile"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(1948, 1, 1), dt.date(2016, 12, 31),
@@ -767,6 +942,11 @@ def main():
             t1 = time.perf_counter()
             cfg["c3_strip"] = strip_run(env, args, args.strong_steps, 1, spot_check=True)
             cfg["c3_strip"]["record_wall_s"] = time.perf_counter() - t1
+        if "c4" in want_cfg:
+            t1 = time.perf_counter()
+            torch.cuda.empty_cache()
+            cfg["c4"] = c4_full_record(env, args)
+            cfg["c4"]["record_wall_s"] = time.perf_counter() - t1
         res["configs"] = cfg
     if ctx is not None:
         ctx.close()

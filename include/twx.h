@@ -111,6 +111,13 @@ typedef struct {
  * the packed int16 daily values that sit within that 1e-6 of a rounding boundary stop flipping by one count
  * (tests/test_gpu_closepairs.py).  For comparisons against other fp64 implementations; not needed for the 1e-4 degC bar. */
 #define TWX_FLAG_UK_F64_ALL 16
+/* fixer: every flagged cell through the full recompute (k_fix_cells) -- a test / diagnostic switch.  Default (flag
+ * clear): a cell with at most 256 invalid days is fixed from those days' +- fixer_tail windows alone (k_fix_sparse) when
+ * that path is usable -- both variables have observations, the normals period present in the day axis is at most 40 years,
+ * 2 fixer_tail + 1 <= 64 -- and by the full recompute otherwise; one predicate, evaluated on the host, decides for a whole
+ * call.  Both paths give the same fixed days and the same packed int16 values (the window means are summed in day order
+ * in both); their recomputed f8 normals can differ in the last bits (tests/test_gpu_parity.py). */
+#define TWX_FLAG_FIX_FULL 32
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
  * StationSelect's isnan(bad) mask: station_data.py:126-183,609,

@@ -100,3 +100,26 @@ def test_bench_other_configs_reduced():
     assert x["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4 and x["spot_check_vs_oracle"]["step21_values"] > 0
     s = c["c3_strip"]
     assert s["value"] > 0 and s["cells_ok"] == s["cells_valid"] and s["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4
+
+
+def test_bench_c2_fitted_and_c4_reduced():
+    """The two records added in round 5, on reduced sizes: ``c2_fitted`` (the headline tile under the variograms step21 ->
+    step22 fit on its own database: same systems, parity vs the oracle on the fitted table) and ``c4`` (every tile of a
+    masked grid streamed with daily output: counts, per-tile times, oracle check of cells from four tiles)."""
+    d = _run("--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1", "--no-daily", "--cpu-sample", "16",
+             "--force-configs", "--configs", "c2_fitted,c4", "--c4-rows", "150", "--c4-cols", "400", "--c4-years", "2",
+             "--strip-tile", "50", "--strip-nstns", "2500")
+    f = d["configs"]["c2_fitted"]
+    assert f["cells_ok"] + sum(f["cells_failed_by_status"].values()) == 64 * 64 and f["uk_solves"] > 0
+    assert f["value"] > 0 and f["uk_ms"] > 0 and 0 <= f["systems_on_fp64_covariance_build"] <= f["uk_solves"]
+    assert f["parity_max_abs_degC"] < 1e-4 and f["status_equal_oracle"] and f["parity_cells"] > 0
+    q = f["fitted_variograms"]["nug_over_psill_quantiles_5_25_50_75_95"]
+    assert q is not None and q == sorted(q)
+    c = d["configs"]["c4"]
+    assert c["tiles"] >= 4 and c["cells_ok"] + sum(c["failures_by_status"].values()) == c["cells_valid"]
+    assert c["cell_days"] == c["cells_ok"] * 731 * 2 and c["value"] > 0 and c["d2h_bytes"] > 0
+    assert c["device_ms_per_tile"]["min"] <= c["device_ms_per_tile"]["median"] <= c["device_ms_per_tile"]["max"]
+    s = c["spot_check_vs_oracle"]
+    assert s["cells"] >= 12 and s["tiles"] >= 3 and s["status_equal"] and s["ninvalid_equal"]
+    assert s["normals_max_abs_degC"] < 1e-4 and s["int16_max_abs_lsb"] <= 1
+    assert min(s["tile_valid_cells"]) <= max(s["tile_valid_cells"])

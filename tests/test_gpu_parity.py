@@ -470,3 +470,50 @@ def test_point_runs_share_candidate_lists(env):
     assert np.all(a[3] == 0)
     for x, y in zip(a[:4], b[:4]):
         assert np.array_equal(x[perm], y, equal_nan=True)
+
+
+@pytest.mark.parametrize("which", ["tail31_sparse", "tail40", "norm_years_43"])
+def test_fixer_limits_of_the_sparse_path_vs_oracle(env, orc, golden_case, which):
+    """``fixer_tail`` and the normals period are public parameters.  A window wider than a wave (tail 40) or a
+    normals period longer than the sparse kernel's 40-year table must send every flagged cell through the full
+    recompute -- not leave it unfixed: ninvalid == oracle, statuses 0, normals recomputed, daily values within 1 LSB.
+    And where the sparse path does run (tail 31: 63 lanes) it gives the full recompute's fixed days bit for bit
+    (TWX_FLAG_FIX_FULL forces the latter)."""
+    import datetime as dt
+    import make_golden
+    from topowx_amd import synth
+    from topowx_amd.dates import get_days_metadata
+    lib, grid = env["lib"], env["grid"]
+    if which == "norm_years_43":
+        days = get_days_metadata(dt.date(1950, 1, 1), dt.date(1992, 12, 31))
+        tmin = synth.make_stations(grid["bbox"], 260, 21, "tmin", days, with_obs=True)
+        tmax = make_golden.lowered_tmax(synth.make_stations(grid["bbox"], 260, 21, "tmax", days, with_obs=True))
+        tail, years, rs, cs = 15, (1950, 1992), slice(40, 43), slice(50, 54)
+    else:
+        tmin, tmax = golden_case[1], make_golden.lowered_tmax(golden_case[2])
+        tail, years, rs, cs = (31 if which == "tail31_sparse" else 40), (1981, 2010), slice(60, 66), slice(11, 19)
+    prm = orc.params(fixer_tail=tail, yr0=years[0], yr1=years[1])
+    want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), prm, grid, daily=True, nthreads=8, rows=rs, cols=cs)
+    outs = {}
+    for flags in (0, lib.FLAG_FIX_FULL):
+        ctx = lib.Context(fixer_tail=tail, norm_years=years, flags=flags)
+        ctx.set_stations(lib.TMIN, tmin)
+        ctx.set_stations(lib.TMAX, tmax)
+        outs[flags] = ctx.interp_grid(grid, daily=True, rows=rs, cols=cs)
+        ctx.close()
+    got = outs[0]
+    assert want["ninvalid"].max() > 0 and want["ninvalid"].max() <= 256          # the cells the sparse path would take
+    assert np.array_equal(got["status"], want["status"]) and np.all(got["status"] == 0)
+    assert np.array_equal(got["ninvalid"], want["ninvalid"])
+    for k in ("norm_tmin", "norm_tmax"):
+        assert np.abs(got[k].astype(np.float64) - want[k]).max() < TOL, k
+    for k in ("daily_tmin", "daily_tmax"):
+        dd = np.abs(got[k].astype(int) - want[k].astype(int))
+        assert dd.max() <= 1 and (dd == 0).mean() > 0.9999, k
+        assert (got[k] < 32000).all()                                              # no day left at tmin >= tmax garbage / fill
+    assert (got["daily_tmin"].astype(int) < got["daily_tmax"].astype(int)).mean() > 0.999
+    full = outs[lib.FLAG_FIX_FULL]
+    for k in ("daily_tmin", "daily_tmax", "ninvalid", "status"):
+        assert np.array_equal(got[k], full[k]), k                                  # sparse == full, packed values bit for bit
+    for k in ("norm_tmin", "norm_tmax"):
+        assert np.abs(got[k].astype(np.float64) - full[k]).max() <= 4e-6, k        # f4 normals: last bit of the f8 sum

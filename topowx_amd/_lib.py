@@ -27,6 +27,7 @@ FLAG_NO_HOST_SYNC = 2
 FLAG_DAILY_GATHER = 4
 FLAG_UK_FAST_ONLY = 8     # diagnostic: never use the fp64 covariance build (include/twx.h)
 FLAG_UK_F64_ALL = 16      # every kriging system on the fp64 covariance build (include/twx.h)
+FLAG_FIX_FULL = 32        # diagnostic: the fixer recomputes every flagged cell's whole series (include/twx.h)
 
 CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)",
                2: "Cannot determine the optimal # of neighbors to use!",

@@ -1027,6 +1027,8 @@ struct FixArgs {
     const int32_t *ncells_dev; // grid mode: number of flagged cells (k_compact_flags), read on the device
     const int32_t *inv_cnt;  // grid mode: [ncell] days with tmin >= tmax found by the daily kernels
     const int32_t *inv_day;  // grid mode: [ncell][TWX_INV_CAP] the first of them (chronological day index, unordered)
+    int sparse_ok;           // grid mode: k_fix_sparse can take the cells with <= TWX_INV_CAP invalid days (fix_sparse_usable, evaluated
+                             // ONCE on the host: both kernels and the launch decision read this one flag)
     double *scratch;        // [gridDim][2][ndays]
     int32_t *lists;         // [gridDim][ndays]
     double *series_min;     // twx_fix_pair: [nseries][ndays] in/out (chronological), else null
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
     const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
-        if (fa.inv_cnt[lc] <= TWX_INV_CAP && stn.ymsum && da.norm_ny > 0) continue;   // fixed from its windows by k_fix_sparse
+        if (fa.sparse_ok && fa.inv_cnt[lc] <= TWX_INV_CAP) continue;   // fixed from its windows by k_fix_sparse
         const int64_t c = wn.cell0 + lc;
         const int rr = (int)(c / src.X), qq = (int)(c % src.X);
         const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
@@ -1232,6 +1234,14 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
 // One work-group of 256 threads per flagged cell (grid-stride), scratch [gridDim][2][ndays] as k_fix_cells.
 // ---------------------------------------------------------------------------------
 #define TWX_NORM_NY_MAX 40
+// The ONE predicate of "the sparse path is usable" (host side: twx_hip.hip sets FixArgs.sparse_ok from it and skips the
+// launch otherwise): both variables' (month, year) observation sums exist, the normals period fits the LDS table, a
+// fixer window fits one wave.  A longer normals period (norm_yr0..norm_yr1 are public parameters) or fixer_tail > 31
+// sends every flagged cell through k_fix_cells.
+__host__ __device__ inline bool fix_sparse_usable(const void *ymsum_min, const void *ymsum_max, int norm_ny, int tail)
+{
+    return ymsum_min && ymsum_max && norm_ny > 0 && norm_ny <= TWX_NORM_NY_MAX && 2 * tail + 1 <= 64;
+}
 #define TWX_FIX_LCAP (TWX_MAX_NNGHS + 8)                     // entries of a month's (weight, station) list
 __global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx, GwrWs gn, GwrWs gx,
                                                     DayAxis da, twx_grid_out out, FixArgs fa)
@@ -1242,7 +1252,7 @@ __global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, Cell
     __shared__ int s_jl[12][2][TWX_FIX_LCAP];
     __shared__ int s_nl[12][2], s_err;
     __shared__ double s_ym[2][12][TWX_NORM_NY_MAX];          // per variable: sum of the (fixed) daily values of (month, year)
-    if (!stn.ymsum || da.norm_ny <= 0 || da.norm_ny > TWX_NORM_NY_MAX || 2 * da.tail + 1 > 64) return;   // (k_fix_cells takes every cell then)
+    if (!fa.sparse_ok) return;                               // (never launched then; k_fix_cells takes every cell)
     double *tmin = fa.scratch + (size_t)blockIdx.x * 2 * da.ndays;
     double *tmax = tmin + da.ndays;
     const int64_t yx = (int64_t)src.Y * src.X;
@@ -1304,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, Cell
         __syncthreads();
         // the fix itself: day order, earlier fixes feed later windows (interp_tair.py:177-195).  One wave: lane = day of
         // the window (raw values from the scratch, which is not written here; the days fixed so far -- found by bisection
-        // in the sorted list -- from LDS), wave sums instead of a 31-step serial scan
+        // in the sorted list -- from LDS)
         if (wvi == 0) {
             for (int q = 0; q < ninv; ++q) {
                 const int x = s_sorted[q];
@@ -1322,7 +1332,13 @@ __global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, Cell
                 }
                 const bool ok = in && a < b;
                 const int cnt = __popcll(__ballot(ok));
-                const double sum = wave_sum(ok ? b - a : 0.0);
+                // the window's sum of diurnal ranges in DAY order, as fix_series_block / twx_fix_pair / the oracle form it
+                // (a butterfly sum differs in the last bits, which moved a packed value by 1 LSB now and then: the fixed
+                // days of a cell must not depend on which of the two fixer kernels took it); a day outside the window or
+                // invalid contributes an exact + 0.0
+                const double dv = ok ? b - a : 0.0;
+                double sum = 0.0;
+                for (int i = 0; i < e - s0; ++i) sum += readlane_dv(dv, i);
                 if (cnt == 0) { if (lane == 0) s_err = 1; break; }
                 // this day's own (raw) values sit in lane x - s0
                 const double xa = readlane_dv(a, x - s0), xb = readlane_dv(b, x - s0);

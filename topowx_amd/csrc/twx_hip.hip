@@ -360,8 +360,6 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
     }
     HIPCHK(hipMemsetAsync(w.cellf64.p, 0, (size_t)ncell * 4, stream));
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
-    HIPCHK(ctx->stats.ensure(64));
-    hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
     int32_t small_host[32];                                  // [0] longest candidate list, [16..31] bucket counts
     const int32_t *cnt = nullptr;
     if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
@@ -372,6 +370,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
             return run_select_uk(ctx, v, src, cell0, ncell, tile0, ntile, ksel, need_gwr, stream, fit_vario,
                                  std::min((small_host[0] + 255) / 256 * 256, TWX_CAND_LDS_MAX));
     }
+    // launch statistics: only for the pass whose kriging launches run (a batch re-run with longer candidate lists must not
+    // count its buckets twice: bench.py quotes systems_on_fp64_covariance_build from these counters)
+    HIPCHK(ctx->stats.ensure(64));
+    hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
     if (cnt && cnt[TWX_BUCKET_F64] + cnt[TWX_BUCKET_F64 + 1] > 0) {
         // this batch has systems on the fp64 covariance build: the fp64 pair distances of their cells, once per cell
         // (110 KB of address space per cell: allocated on first need)
@@ -1319,10 +1321,14 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 FixArgs fa{};
                 fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count; fa.inv_cnt = d_icnt; fa.inv_day = d_iday;
                 fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
+                fa.sparse_ok = (!(ctx->p.flags & TWX_FLAG_FIX_FULL) &&
+                                fix_sparse_usable(ctx->var[0].dev.ymsum, ctx->var[1].dev.ymsum, ctx->da.norm_ny, ctx->da.tail)) ? 1 : 0;
                 EvScope ev(ctx, stream, EV_FIX);
-                // cells with at most TWX_INV_CAP invalid days: fixed from those days' windows; the others: whole series
-                hipLaunchKernelGGL(k_fix_sparse, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws,
-                                   ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
+                // cells with at most TWX_INV_CAP invalid days: fixed from those days' windows; the others (all of them when
+                // the sparse path is not usable: one predicate, evaluated here): whole series
+                if (fa.sparse_ok)
+                    hipLaunchKernelGGL(k_fix_sparse, dim3(nb), dim3(256), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws,
+                                       ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
                 hipLaunchKernelGGL(k_fix_cells, dim3(nb), dim3(TWX_FIX_THREADS), 0, stream, ctx->var[0].dev, ctx->var[1].dev, s0,
                                    ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->da, *o, fa);
             }

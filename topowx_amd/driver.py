@@ -170,12 +170,13 @@ def gather_mosaic_device(buf, assignment, shape, tile_y, tile_x, rank, world, ke
 
 
 def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
-                          writer_threads=1):
+                          writer_threads=1, tile_ms=None):
     """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
     tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
     workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
     returns (they are views of a pinned slot that is reused two tiles later); default: collect copies.
-    All tiles must have the shape tile_y x tile_x.  Returns (results or None, seconds, device_ms)."""
+    All tiles must have the shape tile_y x tile_x.  ``tile_ms``: a list that receives ``(tile_number, device_ms)`` per tile.
+    Returns (results or None, seconds, device_ms)."""
     import queue
     import threading
     import time
@@ -215,13 +216,19 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
             if pending is not None:
                 pk, pslot = pending
                 out = st.wait(pslot)            # tile t is on the host; tile t + 1 is already running
-                dev_ms += out.pop("device_ms")
+                ms = out.pop("device_ms")
+                dev_ms += ms
+                if tile_ms is not None:
+                    tile_ms.append((pk, ms))
                 q.put((pk, pslot, out))
             pending = (k, slot)
         if pending is not None:
             pk, pslot = pending
             out = st.wait(pslot)
-            dev_ms += out.pop("device_ms")
+            ms = out.pop("device_ms")
+            dev_ms += ms
+            if tile_ms is not None:
+                tile_ms.append((pk, ms))
             q.put((pk, pslot, out))
     finally:
         q.put(None)
