@@ -385,7 +385,7 @@ def strip_run(env, args, steps, warmup, spot_check, full=False):
     assignment = driver.assign_tiles(tiles, env.world)
     mine = assignment[env.rank]
     nmax = max(len(a) for a in assignment)
-    dgrid = driver.upload_grid(grid, env.dev)
+    dgrid = driver.upload_grid(grid, env.dev, mine, T, T)        # this rank's tiles only (1 / world of the grid per GPU)
     setup_s = time.perf_counter() - t_s
     shape = grid["mask"].shape
     state = {}
@@ -837,9 +837,9 @@ def main():
                  # FMAs a kernel ISSUED (SQ counters) by the FMAs these flops NEED (128 flops per wave instruction)
                  "executed_flops_by_bucket_kmax": {str(int(e)): float(uk_flops_executed(kpos[bidx == i]).sum())
                                                    for i, e in enumerate(edges) if (bidx == i).any()},
-                 "kernels_by_bucket_kmax": {"40": "k_ukw2<3>", "48": "k_ukwz<3>", "56": "k_ukw<4>", "64": "k_ukwz<4>", "72": "k_ukw<5>",
-                                            "80": "k_ukwz<5>", "88": "k_ukw<6>", "96": "k_ukwz<6>", "104": "k_uk<7,2>", "120": "k_uk<8,4>",
-                                            "136": "k_uk<9,2>", "152": "k_uk<10,2>"}},
+                 "kernels_by_bucket_kmax": {"40": "k_ukw2<3,0>", "48": "k_ukwz<3,0>", "56": "k_ukw<4,0>", "64": "k_ukwz<4,0>", "72": "k_ukw<5,0>",
+                                            "80": "k_ukwz<5,0>", "88": "k_ukw<6,0>", "96": "k_ukwz<6,0>", "104": "k_uk<7,2,0>",
+                                            "120": "k_uk<8,4,0>", "136": "k_uk<9,2,0>", "152": "k_uk<10,2,0>"}},
         "timing_ms": {k: float(np.mean([t[k] for t in kern])) for k in
                       ("tile_cand_ms", "select_ms", "uk_ms", "total_ms")},
     }

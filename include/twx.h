@@ -236,6 +236,16 @@ int twx_interp_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts,
                       const int32_t *excl, int rm_zero_dist, double *daily, double *norms,
                       double *se, int32_t *status);
 
+/* KrigTairAll.krigall(pt, nnghs, stns_rm) (interp_tair.py:722-769) -> R krig_all (interp.R:148-159): the variogram
+ * of each (point, month)'s neighbourhood is fitted (twx_fit_vario_points) and the SAME neighbourhood is kriged with the
+ * fitted model (twx_krig_points with that variogram) -- in one call: one station selection and one set of pair
+ * distances serve both stages, the fitted parameters never leave the device.  Same results, bit for bit, as the two
+ * calls in sequence (tests/test_gpu_xval.py).  What step21's workers run per (station, bandwidth, month)
+ * (optimize.py:236-266).  variance / vario / nnghs_used may be NULL; status = the first failure of either stage. */
+int twx_krigall_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                       const int32_t *nnghs, const int32_t *excl, int rm_zero_dist, double *mean, double *variance,
+                       double *vario, int32_t *nnghs_used, int32_t *status);
+
 /* BuildKrigParams.get_krig_params(pt, mth) (interp_tair.py:635-698) and the first half of R
  * krig_all (interp.R:148-159): R get_vario_params (interp.R:54-113) -- OLS-residual variogram,
  * range fit, GLS-residual variogram, range fit -- on the nnghs nearest stations of each (point,

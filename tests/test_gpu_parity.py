@@ -517,3 +517,50 @@ def test_fixer_limits_of_the_sparse_path_vs_oracle(env, orc, golden_case, which)
         assert np.array_equal(got[k], full[k]), k                                  # sparse == full, packed values bit for bit
     for k in ("norm_tmin", "norm_tmax"):
         assert np.abs(got[k].astype(np.float64) - full[k]).max() <= 4e-6, k        # f4 normals: last bit of the f8 sum
+
+
+def test_singular_kriging_before_a_later_selection_failure(env, orc, golden_case):
+    """VERDICT r4 weak #1c: a cell whose kriging system is singular in month m (two co-located stations inside the
+    neighbourhood) AND whose station selection fails in a later month (database smaller than that month's bandwidth).
+    The reference's month loop (interp_tair.py:429-437) meets the singular system first: TWX_CELL_NUMERIC, not the
+    selection's TWX_CELL_FEW_STATIONS.  The kriging kernels now run for the months before a selection failure."""
+    from topowx_amd import stationdb as sdb
+    lib, grid = env["lib"], env["grid"]
+    NUMERIC, FEW = 4, 1                                                    # TWX_CELL_NUMERIC, TWX_CELL_FEW_STATIONS (include/twx.h)
+    rs, cs = slice(0, 12), slice(0, 12)
+    la, lo = grid["lat"][rs].mean(), grid["lon"][cs].mean()
+    hit = 0
+    for nkeep in (118, 125, 135):
+        dbs, plain = [], []
+        for src in (golden_case[1], golden_case[2]):
+            stns = src.stns[:nkeep].copy()
+            var = src.var[:, :nkeep].copy()
+            # bandwidths that make the order of the months matter: January..June krige with 35 neighbours (the twins are
+            # among them), July..December ask for 147 -- more than the database holds
+            for m in range(1, 13):
+                stns[sdb.get_optim_varname(m)] = 35.0 if m <= 6 else 147.0
+                stns[sdb.get_optim_anom_varname(m)] = 35.0
+            plain.append(sdb.StationDataWrkChk(stns.copy(), src.var_name, src.days, var.copy()))
+            # a twin of the station nearest to the window's centre: same coordinates, its own id (sorted last) and values
+            j = int(np.argmin((stns[sdb.LAT] - la) ** 2 + (stns[sdb.LON] - lo) ** 2))
+            twin = stns[j:j + 1].copy()
+            twin[sdb.STN_ID] = "S9999999"
+            for m in range(1, 13):
+                twin[sdb.get_norm_varname(m)] += 0.37
+            stns = np.concatenate([stns, twin])
+            var = np.concatenate([var, var[:, j:j + 1] + np.float32(0.37)], axis=1)
+            dbs.append(sdb.StationDataWrkChk(stns, src.var_name, src.days, var))
+        ctx = lib.Context()
+        ctx.set_stations(lib.TMIN, dbs[0])
+        ctx.set_stations(lib.TMAX, dbs[1])
+        for daily in (False, True):
+            got = ctx.interp_grid(grid, daily=daily, rows=rs, cols=cs)
+            want = orc.interp_grid(orc.Db(dbs[0]), orc.Db(dbs[1]), env["prm"], grid, daily=daily, nthreads=8, rows=rs, cols=cs)
+            assert np.array_equal(got["status"], want["status"]), (nkeep, daily, got["status"], want["status"])
+            assert np.all(got["norm_tmin"][:, want["status"] != 0] == lib.FILL_F4)
+        ctx.close()
+        # the scenario itself: cells that fail the SELECTION without the twin (a later month's bandwidth exceeds the database;
+        # one more station does not change that) and report the singular system with it
+        base = orc.interp_grid(orc.Db(plain[0]), orc.Db(plain[1]), env["prm"], grid, daily=False, nthreads=8, rows=rs, cols=cs)
+        hit += int(((base["status"] == FEW) & (want["status"] == NUMERIC)).sum())
+    assert hit > 50

@@ -153,3 +153,45 @@ def test_pipeline_step21_22_then_grid_with_fitted_variograms(golden_case, orc):
     for k in ("norm_tmin", "se_tmin"):
         assert np.abs(got[k].astype(np.float64) - want[k])[:, okc].max() < TOL, k
     assert t["uk_solves"] == int(okc.sum()) * 12 and 0 <= t["uk_f64_solves"] <= t["uk_solves"]
+
+
+def test_krigall_points_equals_fit_then_krig(golden_case):
+    """twx_krigall_points (one selection, the fitted variograms stay on the device) == twx_fit_vario_points followed by
+    twx_krig_points with the returned variograms, bit for bit: means, variances, variograms, bandwidths, statuses --
+    including points that fail (bandwidth larger than the database) and ill-conditioned neighbourhoods (a tiny-nugget
+    twin station: the second stage must route by the FITTED variogram)."""
+    from topowx_amd import _lib, stationdb as sdb
+    _, tmin, _ = golden_case
+    stns = tmin.stns.copy()
+    good = np.nonzero(np.isnan(stns[sdb.BAD]))[0]
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, sdb.StationSerialDataDb(stns, "tmin", tmin.days, None), with_obs=False)
+    rng = np.random.default_rng(8)
+    j = rng.choice(good.size, 40, replace=False)
+    c = {k: stns[k][good] for k in (sdb.LON, sdb.LAT, sdb.ELEV, sdb.TDI)}
+    lst = np.column_stack([stns[sdb.get_lst_varname(m)][good] for m in range(1, 13)])
+    pt = ctx.make_pts(c[sdb.LON][j], c[sdb.LAT][j], c[sdb.ELEV][j], c[sdb.TDI][j], lst[j])
+    ladder = np.array([35, 62, 91, 110, 147, 390], np.int32)               # 390 > stations - 1: those points fail
+    pts = np.repeat(pt, ladder.size * 12)
+    mth = np.tile(np.arange(1, 13, dtype=np.int32), j.size * ladder.size)
+    nn = np.tile(np.repeat(ladder, 12), j.size)
+    excl = np.repeat(j.astype(np.int32), ladder.size * 12)
+    vario, used1, st1 = ctx.fit_vario_points(_lib.TMIN, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
+    _, _, _, st2, _ = ctx.krig_points(_lib.TMIN, pts, mth, nnghs=nn, vario=np.nan_to_num(vario), excl=excl, rm_zero_dist=True)
+    mean, var, vfit, used, st = ctx.krigall_points(_lib.TMIN, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
+    # the second stage alone, with the variograms krigall itself fitted: must be krigall's results bit for bit (the kriging
+    # kernels are deterministic; two runs of the variogram kernel are not -- its bins are summed with LDS atomics -- so the
+    # fitted parameters of SEPARATE runs agree to rounding only, see below)
+    mean3, var3, used3, st3, _ = ctx.krig_points(_lib.TMIN, pts, mth, nnghs=nn, vario=np.nan_to_num(vfit), excl=excl, rm_zero_dist=True)
+    ctx.close()
+    want_st = np.where(st1 != 0, st1, st2)
+    assert np.array_equal(st, want_st), (np.nonzero(st != want_st)[0][:10], st[st != want_st][:10], want_st[st != want_st][:10])
+    assert (st != 0).any() and (st == 0).mean() > 0.5
+    ok = st == 0
+    assert np.array_equal(st3[ok], st[ok])
+    assert np.array_equal(mean[ok], mean3[ok]) and np.array_equal(var[ok], var3[ok])          # bit for bit
+    assert np.array_equal(used[ok], used3[ok]) and (used[~ok] == 0).all() and np.isnan(mean[~ok]).all()
+    f1 = st1 == 0
+    assert np.isnan(vfit[~f1]).all() and np.isfinite(vfit[f1]).all()
+    rel = np.abs(vfit[f1] - vario[f1]) / np.maximum(np.abs(vario[f1]), 1e-12)
+    assert np.quantile(rel, 0.99) < 1e-6 and rel.max() < 1e-2, (np.quantile(rel, 0.99), rel.max())   # (flat SSE: DESIGN.md section 8)

@@ -14,14 +14,19 @@ RES = os.path.join(ROOT, "topowx_amd", "libtwxhip.resources.txt")
 # kernel -> (resident waves per SIMD the tuning assumes, scratch bytes per lane tolerated)
 # gfx950: 512 VGPRs per SIMD lane, allocated in granules of 8: waves w fit when VGPRs + AGPRs <= (512 / w) & ~7.
 EXPECT = {
-    "k_ukw<4>": (4, 0), "k_ukw<5>": (3, 0), "k_ukw<6>": (2, 0),
-    "k_ukw2<3>": (3, 0), "k_ukwz<3>": (4, 0), "k_ukwz<4>": (3, 0), "k_ukwz<5>": (2, 0), "k_ukwz<6>": (2, 0),
+    "k_ukw<4, 0>": (4, 0), "k_ukw<5, 0>": (3, 0), "k_ukw<6, 0>": (2, 0),
+    "k_ukw2<3, 0>": (3, 0), "k_ukwz<3, 0>": (4, 0), "k_ukwz<4, 0>": (3, 0), "k_ukwz<5, 0>": (2, 0), "k_ukwz<6, 0>": (2, 0),
     "k_uk<7, 2, 0>": (3, 0), "k_uk<8, 4, 0>": (4, 0), "k_uk<9, 2, 0>": (2, 0),
     # 160 rows on two waves: 220 VGPRs of matrix alone; measured faster with 4 systems per CU and a few spilled
     # registers of the build phase than with 3 (profiles/README.md, round 2): a bounded allowance, not a free pass
     "k_uk<10, 2, 0>": (2, 128),
-    # fp64-build variants (ill-conditioned systems only, not tuned): call frames of the out-of-line covariance function
-    "k_uk<7, 2, 1>": (3, 0), "k_uk<10, 2, 1>": (2, 160), "k_uk<7, 2, 2>": (1, 64), "k_uk<10, 2, 2>": (1, 64),
+    # fp64-build variants (ill-conditioned systems only): the SAME residency as the fast kernels of their size -- the inline fp64
+    # exponential costs a few spilled registers of the build phase in four of them (bounded allowances); <.., 2>: call frames
+    # of the out-of-line covariance function
+    "k_ukw2<3, 1>": (3, 0), "k_ukwz<3, 1>": (4, 0), "k_ukw<4, 1>": (4, 32), "k_ukwz<4, 1>": (3, 0), "k_ukw<5, 1>": (3, 32),
+    "k_ukwz<5, 1>": (2, 0), "k_ukw<6, 1>": (2, 0), "k_ukwz<6, 1>": (2, 32),
+    "k_uk<7, 2, 1>": (3, 0), "k_uk<8, 4, 1>": (4, 0), "k_uk<9, 2, 1>": (2, 0), "k_uk<10, 2, 1>": (2, 160),
+    "k_uk<7, 2, 2>": (1, 64), "k_uk<10, 2, 2>": (1, 64),
     "k_tile_dist<0>": (4, 0), "k_tile_dist<1>": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4, 0>": (4, 0), "k_select<1, 1>": (2, 0), "k_tile_cand": (4, 0),
     "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (6, 0), "k_daily_tile_gather": (4, 0),
@@ -73,4 +78,5 @@ def test_daily_tile_keeps_three_workgroups_per_cu(table):
 
 def test_no_kernel_uses_dynamic_scratch_unexpectedly(table):
     spilled = {k: r["scratch"] for k, r in table.items() if r["scratch"] > 0}
-    assert set(spilled) <= {"k_uk<10, 2, 0>", "k_uk<10, 2, 1>", "k_uk<7, 2, 2>", "k_uk<10, 2, 2>"}, spilled
+    assert set(spilled) <= {"k_uk<10, 2, 0>", "k_uk<10, 2, 1>", "k_uk<7, 2, 2>", "k_uk<10, 2, 2>", "k_ukw<4, 1>", "k_ukw<5, 1>",
+                            "k_ukwz<6, 1>"}, spilled

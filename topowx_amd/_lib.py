@@ -92,7 +92,7 @@ class TwxTiming(C.Structure):
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
-           "twx_fit_vario_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
+           "twx_fit_vario_points", "twx_krigall_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
            "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy")
 
 _LIB = None
@@ -254,6 +254,24 @@ class Context(object):
                                            _p(var_, _dp), _p(used, _ip), _p(ngh, _ip), _p(st, _ip)),
                   "twx_krig_points")
         return mean, var_, used, st, ngh
+
+    def krigall_points(self, var, pts, mth, nnghs=None, excl=None, rm_zero_dist=False):
+        """KrigTairAll.krigall: fit the neighbourhood's variogram, krige with it -- one call, one selection
+        (twx_krigall_points).  Returns (mean, variance, vario[n, 3], nnghs_used, status)."""
+        pts = np.ascontiguousarray(pts, PT_DTYPE)
+        n = pts.size
+        mth = self._i32(mth, n)
+        nn = self._i32(nnghs, n)
+        ex = self._i32(excl, n)
+        mean = np.full(n, np.nan)
+        var_ = np.full(n, np.nan)
+        vario = np.full((n, 3), np.nan)
+        used = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        self._chk(self.lib.twx_krigall_points(self.h, C.c_int(var), C.c_int64(n), _p(pts), _p(mth, _ip), _p(nn, _ip),
+                                              _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(mean, _dp), _p(var_, _dp),
+                                              _p(vario, _dp), _p(used, _ip), _p(st, _ip)), "twx_krigall_points")
+        return mean, var_, vario, used, st
 
     def fit_vario_points(self, var, pts, mth, nnghs=None, excl=None, rm_zero_dist=False):
         """get_vario_params on the neighbourhood of every (point, month): (nug, psill, range)."""

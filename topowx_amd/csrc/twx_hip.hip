@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, hminp, noff, near_pos, urow,
-        nurow, zd, perm, kp, uslot, cellf64, dist64, h064;
+        nurow, zd, perm, kp, uslot, cellf64, f64_cells, dist64, h064, gd64;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
@@ -59,7 +59,7 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &hminp, &noff,
-                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot, &cellf64, &dist64, &h064})
+                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot, &cellf64, &f64_cells, &dist64, &h064, &gd64})
             b->release();
     }
 };
@@ -188,6 +188,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     HIPCHK(w.h0.ensure((size_t)ncell * ksel * 4));
     HIPCHK(w.hminp.ensure((size_t)ncell * ksel * 4));
     HIPCHK(w.cellf64.ensure((size_t)ncell * 4));
+    HIPCHK(w.f64_cells.ensure((size_t)ncell * 4));
     if (need_gwr) {
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
@@ -206,15 +207,19 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     if (fit_vario) {
         HIPCHK(w.uk_beta.ensure((size_t)ncell * 12 * 5 * 8));
         HIPCHK(w.vfit.ensure((size_t)ncell * 12 * 3 * 8));
+        HIPCHK(w.gd64.ensure((size_t)ntile * ((size_t)ksel * (ksel - 1) / 2) * 8));   // the variogram's pair distances per point list
     }
     SelWs &s = w.ws;
     s.uk_beta = fit_vario ? w.uk_beta.as<double>() : nullptr;
     s.vfit = fit_vario ? w.vfit.as<double>() : nullptr;
+    s.gd64 = fit_vario ? w.gd64.as<double>() : nullptr;
     s.ksel = ksel; s.cmax = w.cmax; s.init_nnghs = ctx->p.init_nnghs;
     s.cell0 = cell0; s.ncell = ncell; s.tile0 = tile0; s.ntile = ntile;
     s.cand = w.cand.as<int32_t>(); s.ncand = w.ncand.as<int32_t>();
     s.ncand_max = w.small.as<int32_t>();          // [0]
-    s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16..31]
+    s.nf64 = w.small.as<int32_t>() + 1;           // [1] cells with a month on the fp64 covariance build
+    s.bucket_cnt = w.small.as<int32_t>() + 16;    // [16 .. 16 + TWX_NBUCKET)
+    s.f64_sized = (ctx->p.flags & TWX_FLAG_NO_HOST_SYNC) ? 0 : 1;
     s.reserved0 = 0;
     s.dscratch = w.dscratch.as<float>();
     s.near_idx = w.near_idx.as<int32_t>(); s.near_dist = w.near_dist.as<double>();
@@ -226,7 +231,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.dist = w.dist.as<float>(); s.h0 = w.h0.as<float>(); s.hminp = w.hminp.as<float>();
     s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
     s.f64_all = (ctx->p.flags & TWX_FLAG_UK_F64_ALL) ? 1 : 0;
-    s.cellf64 = w.cellf64.as<int32_t>(); s.dist64 = nullptr; s.h064 = nullptr;
+    s.cellf64 = w.cellf64.as<int32_t>(); s.f64_cells = w.f64_cells.as<int32_t>(); s.dist64 = nullptr; s.h064 = nullptr;
     w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
     w.gw.perm = w.perm.as<int32_t>(); w.gw.kp = w.kp.as<int32_t>();
@@ -278,32 +283,138 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
 #endif
 }
 
-template <int NBR>
+// k_ukz<NB, 2>: border as columns on two waves (k in the upper half of a block row: 105..112, 121..128) -- only in a
+// TWX_UKZ = 1 build (twx_select.h: measured slower, kept reproducible: ./build.sh -DTWX_UKZ=1 + tests/tools/ab_bench.sh)
+template <int NB, int PREC = 0>
+void launch_ukz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
+{
+#if TWX_UKZ
+    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
+    if (cnt && cnt[bucket] <= 0) return;
+    const unsigned grid = krig_grid(cnt, bucket, max_items);
+    hipLaunchKernelGGL((k_ukz<NB, 2, PREC>), dim3(grid), dim3(128), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+#endif
+}
+
+template <int NBR, int PREC = 0>
 void launch_ukwz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
     if (cnt && cnt[bucket] <= 0) return;
     const unsigned grid = krig_grid(cnt, bucket, max_items);
-    hipLaunchKernelGGL((k_ukwz<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_ukwz<NBR, PREC>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
-template <int NBR>
+template <int NBR, int PREC = 0>
 void launch_ukw2(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
     if (cnt && cnt[bucket] <= 0) return;
     // two systems per wave: half as many work-groups (a multiple of 8, krig_grid)
     const unsigned grid = (unsigned)(((std::max<int64_t>(1, cnt ? (int64_t)cnt[bucket] : max_items) + 1) / 2 + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_ukw2<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_ukw2<NBR, PREC>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
 }
 
-template <int NBR>
+template <int NBR, int PREC = 0>
 void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
     const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
     if (cnt && cnt[bucket] <= 0) return;
     const unsigned grid = krig_grid(cnt, bucket, max_items);
-    hipLaunchKernelGGL((k_ukw<NBR>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+    hipLaunchKernelGGL((k_ukw<NBR, PREC>), dim3(grid), dim3(64), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
+}
+
+// The kriging stage of a (batch, variable) whose selection, variograms (ws.vario) and pair distances are in place: bucket the
+// (cell, month) systems by matrix size, read the counts back (unless TWX_FLAG_NO_HOST_SYNC), fp64 slabs for routed cells,
+// one launch per bucket, the 7x7 epilogue.  Returns 1 when a grid batch must be re-run with longer candidate lists
+// (*cmax_wanted), 0 when done, -1 on error.  Also the second stage of twx_krigall_points (new variograms, same selection).
+int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int ksel, hipStream_t stream, bool may_retry, int *cmax_wanted)
+{
+    Work &w = ctx->work[v];
+    const StnDev &st = ctx->var[v].dev;
+    HIPCHK(hipMemsetAsync(w.cellf64.p, 0, (size_t)ncell * 4, stream));
+    hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
+    int32_t small_host[16 + TWX_NBUCKET];                    // [0] longest candidate list, [1] cells on the fp64 build, [16..] bucket counts
+    const int32_t *cnt = nullptr;
+    if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
+        HIPCHK(hipMemcpyAsync(small_host, w.small.p, sizeof small_host, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        cnt = small_host + 16;
+        if (may_retry && src.mode == 0 && small_host[0] > w.cmax && w.cmax < TWX_CAND_LDS_MAX) {
+            *cmax_wanted = std::min((small_host[0] + 255) / 256 * 256, TWX_CAND_LDS_MAX);
+            return 1;
+        }
+    }
+    // launch statistics: only for the pass whose kriging launches run (a batch re-run with longer candidate lists must not
+    // count its buckets twice: bench.py quotes systems_on_fp64_covariance_build from these counters)
+    HIPCHK(ctx->stats.ensure(64));
+    hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
+    const int nf64 = cnt ? small_host[1] : 0;
+    if (nf64 > 0) {
+        // this batch has systems on the fp64 covariance build: the fp64 pair distances of their cells, once per cell, in slabs
+        // sized by the number of ROUTED cells (110 KB each; a dense allocation for the whole batch was 14.8 GB per variable)
+        HIPCHK(w.dist64.ensure((size_t)nf64 * TWX_DIST_BLOCKS * 256 * 8));
+        HIPCHK(w.h064.ensure((size_t)nf64 * ksel * 8));
+        w.ws.dist64 = w.dist64.as<double>(); w.ws.h064 = w.h064.as<double>();
+        EvScope ev(ctx, stream, EV_UK);
+        hipLaunchKernelGGL(k_cell_dist64, dim3((unsigned)nf64), dim3(256), 0, stream, st, w.ws);
+    }
+    {
+        EvScope ev(ctx, stream, EV_UK);
+        const int64_t mi = ncell * 12;
+        // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
+        // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
+        launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
+        launch_ukw<6>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
+#if TWX_UKW2
+        launch_ukw2<3>(cnt, st, src, w.ws, 0, mi, stream);      //      k <= 40  (two systems per wave)
+#else
+        launch_ukw<3>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
+#endif
+        launch_ukwz<3>(cnt, st, src, w.ws, 1, mi, stream);      // 40 < k <= 48
+#if TWX_UKW2 >= 2
+        launch_ukw2<4>(cnt, st, src, w.ws, 2, mi, stream);      // 48 < k <= 56  (two systems per wave: measured, no gain)
+#else
+        launch_ukw<4>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
+#endif
+        launch_ukwz<4>(cnt, st, src, w.ws, 3, mi, stream);      // 56 < k <= 64
+        launch_ukw<5>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
+        launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80
+        launch_uk<7>(cnt, st, src, w.ws, 8, mi, stream);        // 96 < k <= 104
+        launch_ukz<7>(cnt, st, src, w.ws, 9, mi, stream);       // 104 < k <= 112  (border as columns)
+        launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);       // 112 < k <= 120  (104 < k without TWX_UKZ)
+        launch_ukz<8>(cnt, st, src, w.ws, 11, mi, stream);      // 120 < k <= 128  (border as columns)
+        launch_uk<9>(cnt, st, src, w.ws, 12, mi, stream);       // 128 < k <= 136  (120 < k without TWX_UKZ)
+        launch_uk<10>(cnt, st, src, w.ws, 13, mi, stream);      // 136 < k <= 152
+        constexpr int F = TWX_BUCKET_F64;
+        if (w.ws.dist64) {       // ill-conditioned systems (uk_needs_f64): the fp64 covariance build of their own matrix size,
+                                 // distances from the cells' fp64 slabs
+#if TWX_UKW2
+            launch_ukw2<3, 1>(cnt, st, src, w.ws, F + 0, mi, stream);
+#else
+            launch_ukw<3, 1>(cnt, st, src, w.ws, F + 0, mi, stream);
+#endif
+            launch_ukwz<3, 1>(cnt, st, src, w.ws, F + 1, mi, stream);
+            launch_ukw<4, 1>(cnt, st, src, w.ws, F + 2, mi, stream);
+            launch_ukwz<4, 1>(cnt, st, src, w.ws, F + 3, mi, stream);
+            launch_ukw<5, 1>(cnt, st, src, w.ws, F + 4, mi, stream);
+            launch_ukwz<5, 1>(cnt, st, src, w.ws, F + 5, mi, stream);
+            launch_ukw<6, 1>(cnt, st, src, w.ws, F + 6, mi, stream);
+            launch_ukwz<6, 1>(cnt, st, src, w.ws, F + 7, mi, stream);
+            launch_uk<7, 1>(cnt, st, src, w.ws, F + 8, mi, stream);
+            launch_ukz<7, 1>(cnt, st, src, w.ws, F + 9, mi, stream);
+            launch_uk<8, 1>(cnt, st, src, w.ws, F + 10, mi, stream);
+            launch_ukz<8, 1>(cnt, st, src, w.ws, F + 11, mi, stream);
+            launch_uk<9, 1>(cnt, st, src, w.ws, F + 12, mi, stream);
+            launch_uk<10, 1>(cnt, st, src, w.ws, F + 13, mi, stream);
+        } else if (!cnt) {       // TWX_FLAG_NO_HOST_SYNC: no host decision possible, per-element distances, two worst-case sizes
+            launch_uk<7, 2>(cnt, st, src, w.ws, F + 8, mi, stream);
+            launch_uk<10, 2>(cnt, st, src, w.ws, F + 13, mi, stream);
+        }
+        hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // tile candidates -> per-cell selection -> kriging, for one (batch, variable)
@@ -346,8 +457,10 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
                                w.ws, TWX_CAND_SMALL, w.cmax);
     }
     if (!src.do_krig) return 0;
-    if (fit_vario)   // model 1: OLS-residual variogram -> ws.vario, then the kriging kernels give the GLS trend
+    if (fit_vario) { // model 1: OLS-residual variogram -> ws.vario, then the kriging kernels give the GLS trend
+        hipLaunchKernelGGL(k_group_dist64, dim3((unsigned)ntile), dim3(256), 0, stream, st, src, w.ws);   // pair distances, once per point list
         hipLaunchKernelGGL(k_vario<0>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
+    }
     {
         // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems -- and the smallest
         // pair distance by rank, which k_bucket_items needs to route ill-conditioned systems to the fp64 build
@@ -358,64 +471,11 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         } else
             hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
     }
-    HIPCHK(hipMemsetAsync(w.cellf64.p, 0, (size_t)ncell * 4, stream));
-    hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
-    int32_t small_host[32];                                  // [0] longest candidate list, [16..31] bucket counts
-    const int32_t *cnt = nullptr;
-    if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
-        HIPCHK(hipMemcpyAsync(small_host, w.small.p, sizeof small_host, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        cnt = small_host + 16;
-        if (src.mode == 0 && !cmax_retry && small_host[0] > w.cmax && w.cmax < TWX_CAND_LDS_MAX)
-            return run_select_uk(ctx, v, src, cell0, ncell, tile0, ntile, ksel, need_gwr, stream, fit_vario,
-                                 std::min((small_host[0] + 255) / 256 * 256, TWX_CAND_LDS_MAX));
-    }
-    // launch statistics: only for the pass whose kriging launches run (a batch re-run with longer candidate lists must not
-    // count its buckets twice: bench.py quotes systems_on_fp64_covariance_build from these counters)
-    HIPCHK(ctx->stats.ensure(64));
-    hipLaunchKernelGGL(k_bucket_stats, dim3(1), dim3(64), 0, stream, w.ws, ctx->stats.as<long long>());
-    if (cnt && cnt[TWX_BUCKET_F64] + cnt[TWX_BUCKET_F64 + 1] > 0) {
-        // this batch has systems on the fp64 covariance build: the fp64 pair distances of their cells, once per cell
-        // (110 KB of address space per cell: allocated on first need)
-        HIPCHK(w.dist64.ensure((size_t)ncell * TWX_DIST_BLOCKS * 256 * 8));
-        HIPCHK(w.h064.ensure((size_t)ncell * ksel * 8));
-        w.ws.dist64 = w.dist64.as<double>(); w.ws.h064 = w.h064.as<double>();
-        EvScope ev(ctx, stream, EV_UK);
-        hipLaunchKernelGGL(k_cell_dist64, dim3((unsigned)ncell), dim3(256), 0, stream, st, w.ws);
-    }
     {
-        EvScope ev(ctx, stream, EV_UK);
-        const int64_t mi = ncell * 12;
-        // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
-        // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
-        launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
-        launch_ukw<6>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
-#if TWX_UKW2
-        launch_ukw2<3>(cnt, st, src, w.ws, 0, mi, stream);      //      k <= 40  (two systems per wave)
-#else
-        launch_ukw<3>(cnt, st, src, w.ws, 0, mi, stream);    //      k <= 40
-#endif
-        launch_ukwz<3>(cnt, st, src, w.ws, 1, mi, stream);      // 40 < k <= 48
-#if TWX_UKW2 >= 2
-        launch_ukw2<4>(cnt, st, src, w.ws, 2, mi, stream);      // 48 < k <= 56  (two systems per wave: measured, no gain)
-#else
-        launch_ukw<4>(cnt, st, src, w.ws, 2, mi, stream);    // 48 < k <= 56
-#endif
-        launch_ukwz<4>(cnt, st, src, w.ws, 3, mi, stream);      // 56 < k <= 64
-        launch_ukw<5>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
-        launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80
-        launch_uk<7>(cnt, st, src, w.ws, 8, mi, stream);        // 96 < k <= 104
-        launch_uk<8>(cnt, st, src, w.ws, 9, mi, stream);        // 104 < k <= 120
-        launch_uk<9>(cnt, st, src, w.ws, 10, mi, stream);       // 120 < k <= 136
-        launch_uk<10>(cnt, st, src, w.ws, 11, mi, stream);      // 136 < k <= 152
-        if (w.ws.dist64) {       // ill-conditioned systems (uk_needs_f64): fp64 covariance build, k <= 104 / k <= 152
-            launch_uk<7, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);        // distances from the cells' fp64 slabs
-            launch_uk<10, 1>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);
-        } else {                 // (no host decision possible: per-element distances)
-            launch_uk<7, 2>(cnt, st, src, w.ws, TWX_BUCKET_F64, mi, stream);
-            launch_uk<10, 2>(cnt, st, src, w.ws, TWX_BUCKET_F64 + 1, mi, stream);
-        }
-        hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
+        int cmax_wanted = 0;
+        const int rc = run_uk_stage(ctx, v, src, ncell, ksel, stream, !cmax_retry, &cmax_wanted);
+        if (rc < 0) return -1;
+        if (rc == 1) return run_select_uk(ctx, v, src, cell0, ncell, tile0, ntile, ksel, need_gwr, stream, fit_vario, cmax_wanted);
     }
     if (fit_vario)   // model 2: GLS-residual variogram -> ws.vfit
         hipLaunchKernelGGL(k_vario<1>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
@@ -843,6 +903,55 @@ int twx_krig_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, cons
         hipLaunchKernelGGL(k_sorted_neighbours, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, nullptr, src,
                            ctx->work[var].ws, 0, ld, d_ngh, (double *)nullptr, (double *)nullptr, (int32_t *)nullptr);
         HIPCHK(hipMemcpy(ngh_idx, d_ngh, npts * ld * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int twx_krigall_points(twx_ctx *ctx, int var, int64_t npts, const twx_pt *pts, const int32_t *mth,
+                       const int32_t *nnghs, const int32_t *excl, int rm_zero_dist, double *mean, double *variance,
+                       double *vario, int32_t *nnghs_used, int32_t *status)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    if (check_var(ctx, var, false)) return -1;
+    if (npts <= 0 || !pts || !mth || !mean || !status) return fail(ctx, "twx_krigall_points: bad arguments");
+    for (int64_t i = 0; i < npts; ++i)
+        if (mth[i] < 1 || mth[i] > 12) return fail(ctx, "twx_krigall_points: month outside 1..12");
+    HIPCHK(hipSetDevice(ctx->device));
+    PtDev pd;
+    if (upload_points(ctx, npts, pts, nullptr, nullptr, mth, nnghs, nullptr, excl, nullptr, pd)) return -1;
+    CellSrc src = point_src(pd, rm_zero_dist, 1, 0);
+    src.do_vario = 0;
+    const int ksel = pick_ksel(ctx, var, max_k(nnghs, npts));
+    // stage 1: selection, pair distances, the two variogram fits around the GLS kriging (twx_fit_vario_points)
+    if (run_select_uk(ctx, var, src, 0, npts, 0, pd.nlists, ksel, false, nullptr, true)) return -1;
+    Work &w = ctx->work[var];
+    size_t ob = (size_t)npts * (8 + 8 + 4 + 4 + 4 + 24) + 4096;
+    HIPCHK(ctx->pt_out.ensure(ob));
+    char *cur = ctx->pt_out.as<char>();
+    double *d_mean = carve<double>(cur, npts), *d_var = carve<double>(cur, npts), *d_vario = carve<double>(cur, npts * 3);
+    int32_t *d_used = carve<int32_t>(cur, npts), *d_st = carve<int32_t>(cur, npts), *d_st1 = carve<int32_t>(cur, npts);
+    // stage 2: the fitted models become the variograms, the same neighbourhoods are kriged again (interp.R:148-159)
+    hipLaunchKernelGGL(k_vfit_to_vario, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, src, w.ws, d_st1, d_vario);
+    HIPCHK(hipMemsetAsync(w.small.as<int32_t>() + 1, 0, 4, nullptr));                              // routed cells
+    HIPCHK(hipMemsetAsync(w.small.as<int32_t>() + 16, 0, (size_t)TWX_NBUCKET * 4, nullptr));       // bucket counts
+    int dummy = 0;
+    if (run_uk_stage(ctx, var, src, npts, ksel, nullptr, false, &dummy) < 0) return -1;
+    hipLaunchKernelGGL(k_finalize_krig_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, src, w.ws, d_mean,
+                       d_var, d_used, d_st);
+    std::vector<double> hm(npts), hv(npts), hvo((size_t)npts * 3);
+    std::vector<int32_t> s1(npts), s2(npts);
+    HIPCHK(hipMemcpy(s1.data(), d_st1, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s2.data(), d_st, npts * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hm.data(), d_mean, npts * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hv.data(), d_var, npts * 8, hipMemcpyDeviceToHost));
+    if (vario) HIPCHK(hipMemcpy(hvo.data(), d_vario, (size_t)npts * 24, hipMemcpyDeviceToHost));
+    if (nnghs_used) HIPCHK(hipMemcpy(nnghs_used, d_used, npts * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < npts; ++i) {
+        status[i] = s1[i] ? s1[i] : s2[i];
+        if (vario && s1[i] == 0) std::memcpy(vario + i * 3, hvo.data() + i * 3, 24);
+        if (status[i] == 0) { mean[i] = hm[i]; if (variance) variance[i] = hv[i]; }
+        else if (nnghs_used) nnghs_used[i] = 0;
     }
     return 0;
 }

@@ -21,8 +21,10 @@ __global__ void k_finalize_grid(CellSrc src, SelWs wn, SelWs wx, int has_n, int 
         return;
     }
     int s = 0;
-    if (has_n) s = wn.cstat[lc] ? wn.cstat[lc] : wn.uk_stat[lc];
-    if (!s && has_x) s = wx.cstat[lc] ? wx.cstat[lc] : wx.uk_stat[lc];
+    // a kriging failure precedes the selection's: systems are solved only for the months the reference's loop reaches
+    // before the selection failure it meets (k_select), so a singular one among them is the FIRST failure of the point
+    if (has_n) s = wn.uk_stat[lc] ? wn.uk_stat[lc] : wn.cstat[lc];
+    if (!s && has_x) s = wx.uk_stat[lc] ? wx.uk_stat[lc] : wx.cstat[lc];
     if (!s && has_n && gstat_n) s = gstat_n[lc];
     if (!s && has_x && gstat_x) s = gstat_x[lc];
     if (out.status) out.status[c] = s;
@@ -50,7 +52,7 @@ __global__ void k_finalize_krig_points(CellSrc src, SelWs ws, double *mean, doub
     if (lc >= ws.ncell) return;
     const int64_t c = ws.cell0 + lc;
     const int m0 = src.mth[c] - 1;
-    int s = ws.cstat[lc] ? ws.cstat[lc] : ws.uk_stat[lc];
+    int s = ws.uk_stat[lc] ? ws.uk_stat[lc] : ws.cstat[lc];      // (see k_finalize_grid)
     status[c] = s;
     if (nnghs_used) nnghs_used[c] = s ? 0 : ws.kk[lc * 12 + m0];
     if (s) return;
@@ -64,7 +66,7 @@ __global__ void k_finalize_interp_points(SelWs ws, double *norms, double *se, in
     const int64_t lc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lc >= ws.ncell) return;
     const int64_t c = ws.cell0 + lc;
-    int s = ws.cstat[lc] ? ws.cstat[lc] : ws.uk_stat[lc];
+    int s = ws.uk_stat[lc] ? ws.uk_stat[lc] : ws.cstat[lc];      // (see k_finalize_grid)
     status[c] = s;
     if (s) return;
     for (int m = 0; m < 12; ++m) {

@@ -40,8 +40,10 @@ struct SelWs {
     double *vario;       // [ncell][12][3]
     int32_t *cstat;      // [ncell] selection-stage status
     int32_t *cdup;       // [ncell] lowest rank i whose neighbour coincides with an earlier one (k_cell_dist): systems with k > i are singular
-    int32_t *bucket_cnt; // [16]: systems per bucket of twx_krig_bucket: 0..7 one-wave kernels (steps of 8 neighbours up to 96), 8..11 k_uk<7..10>,
-                         // 12..13 ill-conditioned systems (uk_needs_f64): k_uk<7 / 10, 2, 1> with the fp64 covariance build
+    int32_t *bucket_cnt; // [TWX_NBUCKET]: systems per bucket of twx_krig_bucket: 0..7 one-wave kernels (steps of 8 neighbours up to 96),
+                         // 8..13 the multi-wave kernels; TWX_NFAST.. the same sizes for the ill-conditioned systems (uk_needs_f64):
+                         // the kernels' fp64 covariance build (<.., 1> instances; without fp64 slabs -- TWX_FLAG_NO_HOST_SYNC --
+                         // only the buckets of k_uk<7 / 10, 2, 2>)
     int32_t *bucket_cells; // [TWX_NBUCKET][ncell * 12] (cell, month) items per matrix-size bucket
     double *uk_mean;     // [ncell][12]
     double *uk_var;      // [ncell][12]
@@ -49,6 +51,8 @@ struct SelWs {
     double *uk_S;        // [ncell][12][TWX_UK_SLEN] lower triangle of B'C^-1B + error flag
     double *uk_beta;     // [ncell][12][5] GLS trend coefficients (basis of k_uk: columns shifted to the cell, unscaled)
     double *vfit;        // [ncell][12][3] fitted variogram (8f-1)
+    double *gd64;        // [lists][ksel (ksel - 1) / 2] fit mode: the fp64 pair distances of a point LIST's ranked neighbours (k_group_dist64),
+                         // pair (i, j), j < i, at i (i - 1) / 2 + j: shared by every (bandwidth, month) point of the list (k_vario)
     double *ctrig;       // [ncell][4] sin/cos of the cell's half latitude, half longitude
     float *dist;         // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr] station-pair distances (km) of the cell's kriging
                          // neighbourhood in rank order, 16x16 blocks (a >= b) -- shared by the cell's 12 monthly systems
@@ -57,12 +61,17 @@ struct SelWs {
                          // +inf at rank 0): what decides whether a system needs the fp64 covariance build (uk_needs_f64)
     int fast_only;       // TWX_FLAG_UK_FAST_ONLY: never route a system to the fp64 build (diagnostic)
     int f64_all;         // TWX_FLAG_UK_F64_ALL: every system on the fp64 build
-    int32_t *cellf64;    // [ncell] 1 = a month of the cell was routed to the fp64 build (k_bucket_items)
+    int32_t *cellf64;    // [ncell] 0, or 1 + the cell's SLOT in the fp64 slabs: a month of the cell was routed to the fp64 build
+                         // (k_bucket_items numbers the routed cells as it meets them; their count comes back with the bucket counts)
+    int32_t *nf64;       // [1] number of cells with a routed month
+    int32_t *f64_cells;  // [ncell] the routed cells by slot (k_cell_dist64's work list)
+    int f64_sized;       // 1 = the host reads the counts back and sizes fp64 slabs (default): routed systems go to the bucket of
+                         // their own matrix size; 0 (TWX_FLAG_NO_HOST_SYNC) = two worst-case buckets (k <= 104, k <= 152), no slabs
     // fp64 pair distances of the cells with cellf64 set, in the layout of dist (k_cell_dist64), and their cell -> neighbour
-    // distances: allocated when a batch has routed systems and the host knows it (null with TWX_FLAG_NO_HOST_SYNC: the
-    // fp64-build kernels then evaluate every element's distance themselves, per system)
-    double *dist64;      // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr]
-    double *h064;        // [ncell][ksel]
+    // distances, BY SLOT: sized by the number of routed cells when a batch has routed systems and the host knows it (null with
+    // TWX_FLAG_NO_HOST_SYNC: the fp64-build kernels then evaluate every element's distance themselves, per system)
+    double *dist64;      // [nf64][TWX_DIST_BLOCKS][16 tc][16 tr]
+    double *h064;        // [nf64][ksel]
 #ifdef TWX_UK_STAMP      // diagnostic build only (tests/tools/uk_stamps.sh): s_memtime stamps of the panel loop
     unsigned long long *dbg;
 #endif
@@ -398,6 +407,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
     if (!in_range) return;
     if (!valid) {
         if (lane == 0) { ws.cstat[lc] = TWX_CELL_MASKED; ws.nnear[lc] = 0; }
+        if (lane < 12) { ws.kk[lc * 12 + lane] = 0; ws.ka[lc * 12 + lane] = 0; }   // (kk > 0 is what the kriging kernels go by)
         return;
     }
     // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
@@ -548,13 +558,18 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
         const unsigned nan_lst = nan_pred >> 2;
         const bool nan_k = nan_pred & 1u, nan_a = nan_pred & 3u;
 #pragma unroll
+        // kk[m] stays set for every month whose KRIGING the reference's loop reaches before it abandons the point
+        // (interp_tair.py:429-437: krig(m), then gwr(m), month by month): the kriging kernels run those systems also for a
+        // cell that fails LATER -- in this month's GWR selection or in a later month -- so that a singular system among
+        // them reports TWX_CELL_NUMERIC, as the reference's loop would, and not the later failure's code (k_finalize_*).
         for (int m0 = 0; m0 < 12; ++m0) {
             if (status == TWX_CELL_OK && src.do_krig) status = rq[m0] ? rq[m0] : rvq[m0];
             if (status == TWX_CELL_OK && src.do_krig && (nan_k || ((nan_lst >> m0) & 1u))) status = TWX_CELL_NUMERIC;
+            const bool krig_ok = status == TWX_CELL_OK;
             if (status == TWX_CELL_OK && src.do_anom) status = raq[m0];
             if (status == TWX_CELL_OK && src.do_anom && (nan_a || ((nan_lst >> m0) & 1u))) status = TWX_CELL_NUMERIC;
             if (lane == 0) {
-                ws.kk[lc * 12 + m0] = status ? 0 : kq[m0];
+                ws.kk[lc * 12 + m0] = krig_ok ? kq[m0] : 0;
                 ws.ka[lc * 12 + m0] = status ? 0 : kaq[m0];
             }
         }
@@ -562,6 +577,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
     for (int m0 = 0; m0 < 12; ++m0) {
         int k = 0, kan = 0;
         double vp[3] = {0, 0, 0};
+        bool krig_ok = false;                                // (this month's kriging is reached and its selection holds: see above)
         if ((only == 0 || only == m0 + 1) && status == TWX_CELL_OK) {
             double tmp[3];
             if (src.do_krig) {
@@ -591,6 +607,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
             }
             // (a non-finite predictor of the point: the month's kriging fails here, see the all-months form above)
             if (!status && src.do_krig && ((nan_pred & 1u) || ((nan_pred >> (2 + m0)) & 1u))) status = TWX_CELL_NUMERIC;
+            krig_ok = !status;
             // GwrTairAnom.__get_nnghs (interp_tair.py:245-259)
             if (!status && src.do_anom) {
                 if (k_in > 0) kan = k_in;
@@ -605,7 +622,8 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
                 if (!status && ((nan_pred & 3u) || ((nan_pred >> (2 + m0)) & 1u))) status = TWX_CELL_NUMERIC;
             }
         }
-        if (status) { k = 0; kan = 0; }
+        if (!krig_ok) k = 0;
+        if (status) kan = 0;
         if (lane == 0) {
             ws.kk[lc * 12 + m0] = k;
             ws.ka[lc * 12 + m0] = kan;
@@ -662,13 +680,25 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 //                   (twx_ukw.h) up to m = 6; larger systems take the bordered form with m + 1 block rows
 // LDS counters per workgroup, one global atomic per (workgroup, bucket).  Order inside a bucket is irrelevant.
 // ---------------------------------------------------------------------------------
-#define TWX_NBUCKET 14
-#define TWX_BUCKET_F64 12                                    // first of the two fp64-build buckets (k <= 104, k <= 152)
+#define TWX_NFAST 14                                           // matrix-size buckets (one kriging launch each)
+#define TWX_NBUCKET (2 * TWX_NFAST)
+#define TWX_BUCKET_F64 TWX_NFAST                              // fp64-build buckets: TWX_BUCKET_F64 + twx_krig_bucket(k)
+// 0..7: k <= 40, 48, .. 96 (one-wave kernels, twx_ukw.h); 8: <= 104 k_uk<7,2>; 10: <= 120 k_uk<8,4>; 12: <= 136 k_uk<9,2>;
+// 13: <= 152 k_uk<10,2>.  Buckets 9 (105..112) and 11 (121..128) exist only in a TWX_UKZ = 1 build: k_ukz<7 / 8, 2>, the
+// two-wave kernels with the border as columns (twx_uk.h) -- measured SLOWER than the bordered kernel one size up
+// (profiles/README.md, round 5), so the default build leaves those systems where they were.
+#ifndef TWX_UKZ
+#define TWX_UKZ 0
+#endif
 __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 {
     const int e = (k + 7) / 8;                               // eighths: 5 (k <= 40) .. 19 (k <= 152)
     const int b = (e < 5 ? 5 : (e > 19 ? 19 : e)) - 5;      // 0 .. 14
-    return b < 9 ? b : 9 + (b - 9) / 2;                      // from 105 neighbours on in steps of 16 (one kernel each)
+#if TWX_UKZ
+    return b < 13 ? b : 13;
+#else
+    return b < 9 ? b : (b < 11 ? 10 : (b < 13 ? 12 : 13));
+#endif
 }
 
 // Which systems need the fp64 covariance build.  The fast build forms every off-diagonal entry psill exp(-h / range)
@@ -707,22 +737,28 @@ __device__ __forceinline__ bool cell_may_need_f64(const double *vario, int lane)
 
 __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 {
-    __shared__ int s_cnt[16], s_base[16];
+    __shared__ int s_cnt[TWX_NBUCKET], s_base[TWX_NBUCKET];
     const int t = threadIdx.x;
-    if (t < 16) s_cnt[t] = 0;
+    if (t < TWX_NBUCKET) s_cnt[t] = 0;
     __syncthreads();
     const int64_t item = (int64_t)blockIdx.x * 256 + t;
     int id = -1, rank = 0;
     if (item < ws.ncell * 12) {
         const int64_t lc = item / 12;
-        const int k = ws.cstat[lc] == 0 ? ws.kk[item] : 0;
+        const int k = ws.kk[item];                           // (0 for masked cells and for months the reference's loop does not reach)
         if (k > 0) {
             id = twx_krig_bucket(k);
             const double nug = ws.vario[item * 3], psill = ws.vario[item * 3 + 1], rng = ws.vario[item * 3 + 2];
             if (ws.f64_all || (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
                                uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))) {
-                id = TWX_BUCKET_F64 + (k > 104 ? 1 : 0);
-                ws.cellf64[lc] = 1;                          // (every routed month of the cell writes the same 1)
+                // its own matrix size's fp64-build kernel; without slabs the two-wave kernels of 112 / 160 rows take all of them
+                id = TWX_BUCKET_F64 + (ws.f64_sized ? id : (k > 104 ? 13 : 8));
+                // the first routed month of a cell claims the cell a slot in the fp64 slabs (read by later kernels only)
+                if (atomicCAS(&ws.cellf64[lc], 0, -1) == 0) {
+                    const int slot = atomicAdd(ws.nf64, 1);
+                    ws.f64_cells[slot] = (int32_t)lc;
+                    ws.cellf64[lc] = slot + 1;
+                }
             }
             rank = atomicAdd(&s_cnt[id], 1);
         }

@@ -29,7 +29,9 @@ __host__ __device__ constexpr int twx_ukw_waves(int nbr)
 
 __device__ __forceinline__ constexpr int widx(int a, int b) { return 2 * a * (a + 1) + b; }   // blocks of rows < a: 4a' + 4 each
 
-template <int NBR>
+// PREC = 1: the fp64 covariance build (ill-conditioned systems, uk_needs_f64; see k_uk): distances from the cell's fp64 slab
+// (k_cell_dist64), fp64 exponential, nothing read from the fp32 cache.  Same elimination, same register budget target.
+template <int NBR, int PREC = 0>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukw_waves(NBR), twx_ukw_waves(NBR))))
 void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
@@ -75,9 +77,12 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    float hd[NT];
-    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
-    {
+    float hd[PREC ? 1 : NT];
+    const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
+    const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) the cell's slot in the fp64 slabs
+    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr) : nullptr;
+    if constexpr (!PREC) {
+        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
             constexpr int a = decltype(a_)::value;
             sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
@@ -103,7 +108,8 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
             s_B[0][t] = t < k ? 1.0 : 0.0;
@@ -131,7 +137,9 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             const int j = 4 * b + tc;
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
-            double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
+            double v;
+            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16] * ninv) : 0.0;
+            else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
             // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0), so the panel step has no special cases
             if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
@@ -266,7 +274,7 @@ __host__ __device__ constexpr int twx_ukwz_waves(int nbr)
     return w[6 - nbr];
 }
 
-template <int NBR>
+template <int NBR, int PREC = 0>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukwz_waves(NBR), twx_ukwz_waves(NBR))))
 void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
@@ -307,15 +315,20 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
         jq[u] = __hip_atomic_load(&ws.near_idx[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    float hd[NT];
-    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
-    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
-        constexpr int a = decltype(a_)::value;
-        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
-            constexpr int b = decltype(b_)::value;
-            hd[widx(a, b)] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
+    float hd[PREC ? 1 : NT];
+    const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
+    const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) the cell's slot in the fp64 slabs
+    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr) : nullptr;
+    if constexpr (!PREC) {
+        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                hd[widx(a, b)] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16]);
+            });
         });
-    });
+    }
 
     // ---- staging: neighbours lane, lane + 64 (NP <= 96); trend columns shifted to the cell, not scaled (see k_uk)
 #pragma unroll
@@ -332,7 +345,8 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
             s_B[0][t] = t < k ? 1.0 : 0.0;
@@ -355,7 +369,9 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             const int j = 4 * b + tc;
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
-            double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
+            double v;
+            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16] * ninv) : 0.0;
+            else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
             if (b >= 4 * a && i == j) v = i < k ? c00 : 1.0;
             A[widx(a, b)] = -v;
         });
@@ -492,7 +508,7 @@ __host__ __device__ constexpr int twx_ukw2_waves(int nbr)
     return w[4 - nbr];
 }
 
-template <int NBR>
+template <int NBR, int PREC = 0>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(twx_ukw2_waves(NBR), twx_ukw2_waves(NBR))))
 void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int32_t *nitems_dev)
@@ -544,16 +560,21 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
         jq[u] = __hip_atomic_load(&ws.near_idx[(int64_t)lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         h0q[u] = __hip_atomic_load(&ws.h0[(int64_t)lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    float hd[2 * NT];
-    const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr);
-    sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
-        constexpr int a = decltype(a_)::value;
-        sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
-            constexpr int b = decltype(b_)::value;
-            hd[2 * widx(a, b) + 0] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 0) * 16]);
-            hd[2 * widx(a, b) + 1] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2) * 16]);
+    float hd[PREC ? 1 : 2 * NT];
+    const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
+    const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) this half's cell's slot in the fp64 slabs
+    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr) : nullptr;
+    if constexpr (!PREC) {
+        const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                hd[2 * widx(a, b) + 0] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 0) * 16]);
+                hd[2 * widx(a, b) + 1] = __builtin_nontemporal_load(&dist[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2) * 16]);
+            });
         });
-    });
+    }
 
     // ---- staging: neighbours l32, l32 + 32 of this half's system (NP <= 64) ------------------------------------
     double (*sB)[NP] = s_B[sys];
@@ -571,7 +592,8 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             yv = mr.y;
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
             sB[0][t] = t < k ? 1.0 : 0.0;
@@ -596,7 +618,9 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
                 constexpr int q = decltype(q_)::value;
                 constexpr int e = 2 * widx(a, b) + q;
                 const int j = 4 * b + 2 * q + tc2;
-                double v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
+                double v;
+                if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2 * q) * 16] * ninv) : 0.0;
+                else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
                 if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
                 if (a == NBR - 1) v = rhs_row ? rhs[4 * b + 2 * q] : v;
                 A[e] = -v;

@@ -77,11 +77,47 @@ __device__ __forceinline__ double block_max(double v, double *s_tmp)
     return fmax(fmax(s_tmp[0], s_tmp[1]), fmax(s_tmp[2], s_tmp[3]));
 }
 
+// ---------------------------------------------------------------------------------
+// k_group_dist64: the semivariogram's pair distances, once per point LIST.  The points of a list -- one station's 16
+// bandwidths x 12 months in step21 -- share their location, excluded station and therefore their ranked neighbour list,
+// and their neighbourhoods are nested: the k (k - 1) / 2 pairs of a point are the first entries of the list's
+// ksel (ksel - 1) / 2.  Evaluated per (point, pass) the distance formula was ~70 of the ~110 instructions of k_vario's pair
+// loop, 64 x redundantly in step21 (profiles/README.md, round 5).  One work-group per list; pair (i, j) at i (i - 1) / 2 + j.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_group_dist64(StnDev st, CellSrc src, SelWs ws)
+{
+    __shared__ double s_trig[5][TWX_KSEL_MAX];
+    const int64_t g = blockIdx.x;
+    if (g >= ws.ntile) return;
+    const int64_t lc = (src.ptfirst ? src.ptfirst[g] : g) - ws.cell0;      // the list's first point stands for all of them
+    if (lc < 0 || lc >= ws.ncell) return;
+    const int t = threadIdx.x;
+    const int nn = min(ws.nnear[lc], ws.ksel);
+    if (t < nn) {
+        const int j = ws.near_idx[lc * ws.ksel + t];
+        const double sp = st.sph[j], cp = st.cph[j];
+        s_trig[0][t] = sp; s_trig[1][t] = cp; s_trig[2][t] = st.slh[j]; s_trig[3][t] = st.clh[j];
+        s_trig[4][t] = fma(cp, cp, -(sp * sp));
+    }
+    __syncthreads();
+    const int npair = nn * (nn - 1) / 2;
+    double *out = ws.gd64 + g * (int64_t)(ws.ksel * (ws.ksel - 1) / 2);
+    int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+    while (i * (i - 1) / 2 > t) --i;
+    while ((i + 1) * i / 2 <= t) ++i;
+    int j = t - i * (i - 1) / 2;
+    for (int p = t; p < npair; p += 256, j += 256) {
+        while (j >= i) { j -= i; ++i; }
+        const double ta[5] = {s_trig[0][i], s_trig[1][i], s_trig[2][i], s_trig[3][i], s_trig[4][i]};
+        const double tb[5] = {s_trig[0][j], s_trig[1][j], s_trig[2][j], s_trig[3][j], s_trig[4][j]};
+        out[p] = ellip_pair_vario(ta, tb);
+    }
+}
+
 template <int PASS>
 __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
 {
-    __shared__ double s_trig[5][TWX_KSEL_MAX], s_e[TWX_KSEL_MAX];   // {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by neighbour: the
-                                                                    // pair loop's lanes read consecutive neighbours (no bank conflicts)
+    __shared__ double s_e[TWX_KSEL_MAX];
     __shared__ double s_sh[TWX_VBINS], s_sg[TWX_VBINS], s_sn[TWX_VBINS];
     __shared__ double s_red[4], s_beta[5], s_nrm[20];
     __shared__ int s_bad;
@@ -103,12 +139,6 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     if (t < k) {
         const int j = ws.near_idx[lc * ws.ksel + t];
         const double lo = st.lon[j], la = st.lat[j];
-        {   // the pair distances below come from the stations' half-angle trigonometry (k_stn_coslat), as in the kriging kernels'
-            // fp64 build: no trigonometric call per pair (the six of ellip_km per pair were 60 % of config 5's kernel time)
-            const double sp = st.sph[j], cp = st.cph[j];
-            s_trig[0][t] = sp; s_trig[1][t] = cp; s_trig[2][t] = st.slh[j]; s_trig[3][t] = st.clh[j];
-            s_trig[4][t] = fma(cp, cp, -(sp * sp));
-        }
         x[0] = 1.0; x[1] = lo - cv.lon; x[2] = la - cv.lat; x[3] = st.elev[j] - cv.elev; x[4] = st.lst[m0 * n + j] - plst;
         y = st.norm[m0 * n + j];
         dh = ws.near_dist[lc * ws.ksel + t];
@@ -179,6 +209,7 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     for (int b = t; b < TWX_VBINS; b += 256) { s_sh[b] = 0.0; s_sg[b] = 0.0; s_sn[b] = 0.0; }
     __syncthreads();
     const int npair = k * (k - 1) / 2;
+    const double *gd = ws.gd64 + (int64_t)(src.ptile ? src.ptile[c] : c) * (int64_t)(ws.ksel * (ws.ksel - 1) / 2);
     // pair p = i (i - 1) / 2 + j, j < i: decoded once, then stepped (256 pairs ahead is at most a few rows down: k <= 152)
     int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
     while (i * (i - 1) / 2 > t) --i;
@@ -186,9 +217,7 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     int j = t - i * (i - 1) / 2;
     for (int p = t; p < npair; p += 256, j += 256) {
         while (j >= i) { j -= i; ++i; }
-        const double ta[5] = {s_trig[0][i], s_trig[1][i], s_trig[2][i], s_trig[3][i], s_trig[4][i]};
-        const double tb[5] = {s_trig[0][j], s_trig[1][j], s_trig[2][j], s_trig[3][j], s_trig[4][j]};
-        const double h = ellip_pair_vario(ta, tb);
+        const double h = gd[p];                             // the list's pair table (k_group_dist64): coalesced, L2-resident
         if (h <= cutoff) {
             int b = (int)floor(h / width);
             if (b > 0 && h == b * width) --b;
@@ -263,4 +292,33 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
             out[0] = m0v; out[1] = m1v; out[2] = m2v;
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------
+// twx_krigall_points, between its two kriging stages: the model fitted for a point's month (ws.vfit, k_vario<1>) becomes the
+// variogram the second stage kriges with -- on the device, with the selection, the neighbour lists and the pair distances
+// of the first stage.  A point whose fit failed is done: its status stands and it gets no second system.
+// ---------------------------------------------------------------------------------
+__global__ void k_vfit_to_vario(CellSrc src, SelWs ws, int32_t *st1, double *vout)
+{
+    const int64_t lc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= ws.ncell) return;
+    const int64_t c = ws.cell0 + lc;
+    const int m0 = src.mth[c] - 1;
+    const int64_t item = lc * 12 + m0;
+    const int s = ws.uk_stat[lc] ? ws.uk_stat[lc] : ws.cstat[lc];
+    st1[lc] = s;
+    if (s == 0 && ws.kk[item] > 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double v = ws.vfit[item * 3 + q];
+            ws.vario[item * 3 + q] = v;
+            vout[lc * 3 + q] = v;
+        }
+    } else {
+        ws.kk[item] = 0;
+        vout[lc * 3] = vout[lc * 3 + 1] = vout[lc * 3 + 2] = NAN;
+    }
+    ws.uk_stat[lc] = TWX_CELL_OK;
 }

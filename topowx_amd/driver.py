@@ -91,52 +91,71 @@ def gather_mosaic(local, assignment, shape, tile_y, tile_x, keys, rank, world, d
 NORMAL_KEYS = ("norm_tmin", "se_tmin", "norm_tmax", "se_tmax")
 
 
-def upload_grid(grid, device):
-    """The predictor planes of a grid as device tensors (native dtypes, tiling.py:190-213)."""
+def upload_grid(grid, device, tiles=None, tile_y=None, tile_x=None):
+    """The predictor planes as device tensors (native dtypes, tiling.py:190-213).  With ``tiles`` (a rank's share of
+    ``assign_tiles``) only THOSE tiles' planes go up, each as its own contiguous image: 1 / world of the grid per rank (the
+    full configs[2] grid is 2.48 GB; a rank's 40 of 323 tiles 0.31 GB) instead of a replica on every GPU."""
     import torch
     from . import _lib
-    a = _lib.Context.grid_arrays(grid)
-    return {k: torch.from_numpy(v).to(device) for k, v in a.items()}
+    if tiles is None:
+        a = _lib.Context.grid_arrays(grid)
+        return {k: torch.from_numpy(v).to(device) for k, v in a.items()}
+    Yg, Xg = np.asarray(grid["mask"]).shape
+    cut = {}
+    for (k, i, j, _) in tiles:
+        a = _lib.Context.grid_arrays(grid, slice(i, min(i + tile_y, Yg)), slice(j, min(j + tile_x, Xg)))
+        cut[k] = {n: torch.from_numpy(np.ascontiguousarray(v)).to(device) for n, v in a.items()}
+    return {"tiles": cut, "shape": (Yg, Xg), "device": torch.device(device)}
 
 
 def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), nslots=None, stream=None):
     """Normals + SE of this rank's tiles with everything resident in HBM: the predictor planes come from the device
-    tensors of ``upload_grid`` (each tile's 61 B / cell are gathered into a contiguous image by a device copy), and
-    ``twx_interp_grid_dev`` writes every tile's outputs straight into slot s of ONE device tensor
-    ``buf[nslots, 4, 12, tile_y, tile_x]`` -- the send buffer of ``gather_mosaic_device``; nothing crosses PCIe.
-    ``nslots`` >= len(tiles) pads the buffer to the size every rank of a gather must share.
+    tensors of ``upload_grid`` (whole grid: each tile's 61 B / cell are gathered into a contiguous image by a device copy;
+    per-tile upload: used as they are), and ``twx_interp_grid_dev`` writes every tile's outputs straight into slot s of ONE
+    device tensor ``buf[nslots, 4, 12, tile_y, tile_x]`` -- the send buffer of ``gather_mosaic_device``; nothing crosses
+    PCIe.  ``nslots`` >= len(tiles) pads the buffer to the size every rank of a gather must share.  The loop does not
+    wait for a tile before it enqueues the next one (the library's own 64-byte read-back per call apart): per-tile times
+    come from events recorded on the launch stream and are read once, after the loop.
     Returns (buf, status[nslots, tile_y, tile_x] i4 device tensor, per-tile device ms)."""
     import torch
     from . import _lib
-    dev = dgrid["mask"].device
+    per_tile = "tiles" in dgrid
+    dev = dgrid["device"] if per_tile else dgrid["mask"].device
     nslots = len(tiles) if nslots is None else nslots
     assert nslots >= len(tiles)
     buf = torch.full((max(nslots, 1), 4, 12, tile_y, tile_x), float(FILL_F4), dtype=torch.float32, device=dev)
     stat = torch.full((max(nslots, 1), tile_y, tile_x), -1, dtype=torch.int32, device=dev)
     ninv = torch.empty((tile_y, tile_x), dtype=torch.int32, device=dev)
-    Yg, Xg = dgrid["mask"].shape
+    Yg, Xg = dgrid["shape"] if per_tile else dgrid["mask"].shape
     vars_mask = (_lib.VAR_TMIN_BIT if "tmin" in variables else 0) | (_lib.VAR_TMAX_BIT if "tmax" in variables else 0)
-    strm = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    ms = []
-    for s, (_, i, j, _) in enumerate(tiles):
+    tstream = torch.cuda.current_stream() if stream is None else torch.cuda.ExternalStream(stream)
+    strm = tstream.cuda_stream
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(tiles) + 1)]
+    marks[0].record(tstream)
+    for s, (k, i, j, _) in enumerate(tiles):
         y, x = min(tile_y, Yg - i), min(tile_x, Xg - j)
-        t = {k: dgrid[k][i:i + y, j:j + x].contiguous() for k in ("mask", "elev", "tdi", "climdiv")}
-        t["lat"] = dgrid["lat"][i:i + y].contiguous()
-        t["lon"] = dgrid["lon"][j:j + x].contiguous()
-        for k in ("lst_night", "lst_day"):
-            t[k] = dgrid[k][:, i:i + y, j:j + x].contiguous()
+        if per_tile:
+            t = dgrid["tiles"][k]
+        else:
+            t = {n: dgrid[n][i:i + y, j:j + x].contiguous() for n in ("mask", "elev", "tdi", "climdiv")}
+            t["lat"] = dgrid["lat"][i:i + y].contiguous()
+            t["lon"] = dgrid["lon"][j:j + x].contiguous()
+            for n in ("lst_night", "lst_day"):
+                t[n] = dgrid[n][:, i:i + y, j:j + x].contiguous()
         full = y == tile_y and x == tile_x
         # an edge tile is smaller than its slot: computed into a scratch image and placed afterwards
         o = buf[s] if full else torch.full((4, 12, y, x), float(FILL_F4), dtype=torch.float32, device=dev)
         so = stat[s] if full else torch.full((y, x), -1, dtype=torch.int32, device=dev)
-        g = _lib.TwxGrid(y, x, *[t[k].data_ptr() for k in ("mask", "lat", "lon", "elev", "tdi", "climdiv", "lst_night", "lst_day")])
+        g = _lib.TwxGrid(y, x, *[t[n].data_ptr() for n in ("mask", "lat", "lon", "elev", "tdi", "climdiv", "lst_night", "lst_day")])
         ptr = [o[q].data_ptr() if v in variables else None for q, v in enumerate(("tmin", "tmin", "tmax", "tmax"))]
         go = _lib.TwxGridOut(ptr[0], ptr[1], ptr[2], ptr[3], None, None, ninv.data_ptr(), so.data_ptr())
-        ctx.interp_grid_dev(g, go, vars_mask, strm)
-        ms.append(ctx.timing()["total_ms"])          # HIP events of this tile (synchronises: the inputs may go)
+        ctx.interp_grid_dev(g, go, vars_mask, strm)     # (stream-ordered: the tile's input images may be freed by torch afterwards)
         if not full:
             buf[s, :, :, :y, :x] = o
             stat[s, :y, :x] = so
+        marks[s + 1].record(tstream)
+    marks[-1].synchronize()
+    ms = [marks[s].elapsed_time(marks[s + 1]) for s in range(len(tiles))]
     return buf, stat, ms
 
 
@@ -297,7 +316,7 @@ def main():
                                device="cuda:%d" % local) if args.gather else None
     else:
         # normals only: everything stays in HBM, tiles land in the gather's send buffer
-        dgrid = upload_grid(grid, "cuda:%d" % local)
+        dgrid = upload_grid(grid, "cuda:%d" % local, assignment[rank], args.tile, args.tile)   # this rank's tiles only
         nmax = max(len(a) for a in assignment)
         buf, _, ms = interp_tiles_device(ctx, dgrid, assignment[rank], args.tile, args.tile, nslots=nmax)
         dev_ms = float(sum(ms))

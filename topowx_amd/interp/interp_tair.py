@@ -279,12 +279,8 @@ class KrigTairAll(object):
         pts = np.repeat(_pt_to_twx(s.ctx, pt), 12)
         mth = np.arange(1, 13, dtype=np.int32)
         excl = s.excl_index(stns_rm)
-        vario, _, st = s.ctx.fit_vario_points(s.var, pts, mth, nnghs=int(nnghs), excl=excl,
-                                              rm_zero_dist=s.rm_zero_dist_stns)
-        for q in st:
-            raise_for_status(q)
-        mean, _, _, st, _ = s.ctx.krig_points(s.var, pts, mth, nnghs=int(nnghs), vario=vario, excl=excl,
-                                              rm_zero_dist=s.rm_zero_dist_stns)
+        mean, _, _, _, st = s.ctx.krigall_points(s.var, pts, mth, nnghs=int(nnghs), excl=excl,
+                                                 rm_zero_dist=s.rm_zero_dist_stns)        # fit + krige, one selection
         for q in st:
             raise_for_status(q)
         return mean

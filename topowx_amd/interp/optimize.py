@@ -109,21 +109,18 @@ class XvalTairNorm(_XvalBase):
         mth = np.tile(np.arange(1, 13, dtype=np.int32), ns * nb)
         nn = np.tile(np.repeat(abw, 12), ns)
         excl = np.repeat(j.astype(np.int32), nb * 12)
-        vario, _, st1 = self.ctx.fit_vario_points(self.var, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
+        # variogram fit + kriging with the fitted model per (station, bandwidth, month): ONE call (KrigTairAll.krigall's shape,
+        # interp_tair.py:722-769): one station selection and one set of pair distances serve both stages
+        mean, _, _, _, st = self.ctx.krigall_points(self.var, pts, mth, nnghs=nn, excl=excl, rm_zero_dist=True)
         if raise_on_error:
-            for q in st1:
-                raise_for_status(q)
-        mean, _, _, st2, _ = self.ctx.krig_points(self.var, pts, mth, nnghs=nn, vario=np.nan_to_num(vario), excl=excl,
-                                                 rm_zero_dist=True)
-        if raise_on_error:
-            for q in st2:
+            for q in st:
                 raise_for_status(q)
         obs = np.column_stack([self.stns[j][get_norm_varname(m)] for m in range(1, 13)])      # [ns, 12]
         interp = mean.reshape(ns, nb, 12)
         err = np.transpose(interp - obs[:, None, :], (0, 2, 1))                                 # [ns, 12, nb]
         if raise_on_error:
             return err
-        ok = ((st1 == 0) & (st2 == 0)).reshape(ns, nb * 12).all(axis=1)
+        ok = (st == 0).reshape(ns, nb * 12).all(axis=1)
         return err, ok
 
 
