@@ -2,6 +2,7 @@
 layout ``StationSerialDataDb`` reads (station_data.py:547-616), in BOTH containers -- NetCDF-4 on libhdf5
 (``topowx_amd.h5nc``) and classic netCDF on scipy -- compared field by field.  CPU only."""
 import datetime as dt
+import os
 
 import numpy as np
 import pytest
@@ -461,3 +462,52 @@ def test_create_climdiv_optim_nstns_db_keeps_the_reference_call_shape(tmp_path, 
     np.testing.assert_array_equal(nghs, ladder)
     np.testing.assert_array_equal(mae[:, :, 1], np.abs(err))
     assert np.isnan(mae[:, :, 0]).all() and np.isnan(mae[:, :, 2]).all()        # never written -> fill -> masked
+
+
+def test_without_libhdf5_the_classic_container_takes_over(tmp_path):
+    """A machine without libhdf5 (simulated: TWX_HDF5_DISABLE): writers fall back to classic netCDF with ONE warning, classic
+    files read as before, and a NetCDF-4 file is refused with a message that names the library -- never a silent misread."""
+    import subprocess
+    import sys
+    nc4 = str(tmp_path / "db4.nc")
+    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 1, 5))
+    grid = synth.make_grid("C1", nrows=20, ncols=20)
+    db = synth.make_stations(grid["bbox"], 12, 2, "tmin", days, with_obs=True)
+    if h5nc.available():
+        ncio.write_station_db(nc4, db, format="NETCDF4")
+    code = r"""
+import sys, warnings
+sys.path.insert(0, %r)
+import datetime as dt, numpy as np
+from topowx_amd import h5nc, ncio, synth, stationdb as sdb
+from topowx_amd.dates import get_days_metadata
+assert not h5nc.available()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    assert ncio.default_format() == "NETCDF3_64BIT" and ncio.default_format() == "NETCDF3_64BIT"
+assert len(w) == 1 and "libhdf5" in str(w[0].message)
+days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1981, 1, 5))
+grid = synth.make_grid("C1", nrows=20, ncols=20)
+db = synth.make_stations(grid["bbox"], 12, 2, "tmin", days, with_obs=True)
+p = %r
+ncio.write_station_db(p, db)                       # default container: classic now
+assert ncio.file_format(p) == "NETCDF3_64BIT"
+back = sdb.StationSerialDataDb(p, "tmin")
+assert np.array_equal(back.var, db.var) and np.array_equal(back.stn_ids, db.stn_ids)
+import os
+if os.path.exists(%r):
+    try:
+        sdb.StationSerialDataDb(%r, "tmin")
+        raise SystemExit("a NetCDF-4 file was opened without libhdf5")
+    except IOError as e:
+        assert "libhdf5" in str(e), e
+try:
+    ncio.open_dataset(p + ".x", "w", "NETCDF4")
+    raise SystemExit("NETCDF4 written without libhdf5")
+except IOError as e:
+    assert "libhdf5" in str(e)
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "db3.nc"), nc4, nc4)
+    env = dict(os.environ, TWX_HDF5_DISABLE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:] + r.stdout[-500:]

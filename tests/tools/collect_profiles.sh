@@ -15,8 +15,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/dfetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-configs --stream-tiles 0 > $OUT/dfetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dwrite -o w --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-configs --stream-tiles 0 > $OUT/dwrite.log 2>&1
 python3 tests/tools/reduce_profiles.py $OUT > /dev/null
+# (on the box's copy of the tree; install_profiles.sh does it at home.  TWX_ROUND_TAG=r5 names the file the bench lines will cite;
+# without it the newest committed file is overwritten and cited under its old name)
 NEWEST=$(ls profiles/r*_bench_hbm_traffic.json 2>/dev/null | sort | tail -1)
-[ -n "$NEWEST" ] && cp $OUT/hbm_traffic.json $NEWEST        # (on the box's copy of the tree; install_profiles.sh does it at home)
+[ -n "${TWX_ROUND_TAG:-}" ] && NEWEST=profiles/${TWX_ROUND_TAG}_bench_hbm_traffic.json
+[ -n "$NEWEST" ] && cp $OUT/hbm_traffic.json $NEWEST
 # (2) the bench line and the kernel summaries
 python3 bench.py --steps 20 --warmup 3 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 # headline workload alone (the daily record would mix other batch shapes into the same kernels' averages)

@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 # the C4 tile's counter passes first (bench.py's configs.c4_tile.traffic quotes the newest profiles/r*_c4_daily_traffic.json)
 bash tests/tools/collect_c4_traffic.sh > gpurun_out/collect_c4.log 2>&1
 NEWEST=$(ls profiles/r*_c4_daily_traffic.json 2>/dev/null | sort | tail -1)
+[ -n "${TWX_ROUND_TAG:-}" ] && NEWEST=profiles/${TWX_ROUND_TAG}_c4_daily_traffic.json      # (see collect_profiles.sh)
 [ -n "$NEWEST" ] && cp gpurun_out/prof_c4/c4_daily_traffic.json $NEWEST
 bash tests/tools/collect_profiles.sh > gpurun_out/collect_profiles.log 2>&1
 python3 bench.py --steps 6 --warmup 2 --daily-years 69 --stream-tiles 4 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/prof_round/c4_stream_daily.json

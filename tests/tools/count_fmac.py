@@ -54,3 +54,26 @@ for k in (40, 52, 60, 68, 76, 84, 96, 104, 112, 120, 136, 147):
     useful=sum(4*(n-4*p-4)*(n-4*p-3)/2 for p in range(-(-k//4)))/64
     cur=count_n(n,k,16,4); zv=zvar(k); t=count_n(n,k,4,16)
     print(k, "ideal %.0f cur %d (%.2f)  Z %d (%.2f)  T %d (%.2f)  best/cur %.2f" % (useful, cur, cur/useful, zv, zv/useful, t, t/useful, min(cur,zv,t)/cur))
+print("---- round 5: multi-wave kernels, bordered (k_uk<NB, NW>) against border-as-columns with REPLICATED border registers (k_ukz<NB, NW>)")
+def uk(NB, NW, k, z=False):
+    """fmac wave-instructions per SYSTEM of the panel updates, as the kernels unroll them (twx_uk.h): 4 per live block and
+    panel; z: + 8 per live block row and panel and wave for the border columns, + 8 per panel for the 7x7 corner."""
+    CB = 4 * NW
+    NBC = 16 * NB // CB
+    a_tot = z_tot = 0
+    for bc in range(NBC):
+        ncb = k - CB * bc
+        if ncb <= 0:
+            continue
+        a0 = CB * bc // 16
+        for s in range(min(NW, (ncb + 3) // 4)):
+            for wvp in range(NW):
+                for a in range(a0, NB):
+                    a_tot += 4 * max(0, 16 * (a + 1) // CB - (bc + 1)) + (4 if wvp > s else 0)
+                    z_tot += 8 if z else 0
+                z_tot += 8 if (z and wvp == 0) else 0
+    return a_tot, z_tot
+for name, NB, NW, k, z in (("k_uk<8,4>  k=110", 8, 4, 110, False), ("k_ukz<7,2> k=110", 7, 2, 110, True), ("k_uk<9,2>  k=121", 9, 2, 121, False),
+                           ("k_ukz<8,2> k=121", 8, 2, 121, True), ("k_uk<7,2>  k=100", 7, 2, 100, False)):
+    a, zt = uk(NB, NW, k, z)
+    print("%-18s matrix %5d + border %5d = %5d fmac instructions per system" % (name, a, zt, a + zt))

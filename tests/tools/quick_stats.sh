@@ -20,7 +20,7 @@ for r in rows:
         lines.append((float(r["AverageNs"]) / 1e3, int(r["Calls"]), k))
 for us, n, k in sorted(lines, reverse=True):
     print("%10.1f us x %3d  %s" % (us, n, k))
-krig = sum(us for us, n, k in lines if k.startswith(("k_uk<", "k_ukw<", "k_ukwz<", "k_ukw2<", "k_tile_dist", "k_cell_dist")))
+krig = sum(us for us, n, k in lines if k.startswith(("k_uk<", "k_ukz<", "k_ukw<", "k_ukwz<", "k_ukw2<", "k_tile_dist", "k_cell_dist")))
 print("kriging kernels (sum of averages): %.3f ms" % (krig / 1e3))
 try:
     d = json.loads(open(os.path.join(out, "bench_profiled.json")).read())
