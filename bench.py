@@ -87,9 +87,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
     ap.add_argument("--int16-window", type=int, default=24, help="edge of the cell window whose packed int16 days are compared with the oracle")
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_tile / c5 / c3 records (N = 1)")
-    ap.add_argument("--configs", default="c2_fitted,c4_tile,c5,c3,c4",
+    ap.add_argument("--configs", default="c2_fitted,c4_tile,c5,c3,c3_fitted,c4",
                     help="which of the other configurations to time (c2_fitted = the headline tile under the variograms step21 -> "
-                         "step22 fit on its own database; c3 = the full configs[2] grid; c4 = configs[3] itself: the full grid x "
+                         "step22 fit on its own database; c3 = the full configs[2] grid; c3_fitted = the same under the variograms step21 -> step22 fit on its 12 000-station tables; c4 = configs[3] itself: the full grid x "
                          "25 203 days streamed to pinned host memory; c3_strip = the 750x7000 strip of the strong record)")
     ap.add_argument("--c4-tiles", type=int, default=0, help="c4 record: only the first N tiles of the deal (0 = all 323; tests)")
     ap.add_argument("--c4-rows", type=int, default=0, help="c4 record on a cut of the grid (tests; 0 = the full 3250x7000 grid)")
@@ -363,7 +363,7 @@ def shared_stations(env, key, build):
 # =====================================================================================================================
 # the tile farm of topowx_amd.driver on ONE fixed masked grid (strong scaling; at N = 1 the c3 / c3_strip records)
 # =====================================================================================================================
-def strip_run(env, args, steps, warmup, spot_check, full=False):
+def strip_run(env, args, steps, warmup, spot_check, full=False, fitted=False):
     """BASELINE.json configs[2] shape on a strip of the seed-7 masked CONUS-shaped grid: Tmin + Tmax normals + SE of
     every valid cell, tiles dealt to the ranks with driver.assign_tiles (LPT), every rank's tiles computed device-
     resident into the send buffer of ONE dist.gather (RCCL over xGMI) that assembles the four mosaics on rank 0.
@@ -378,6 +378,11 @@ def strip_run(env, args, steps, warmup, spot_check, full=False):
         grid = synth.make_grid("C3", nrows=args.strip_rows, ncols=args.strip_cols, lat_north=45.0, full_mask=False)
     tmin = shared_stations(env, "strip_tmin", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmin"))
     tmax = shared_stations(env, "strip_tmax", lambda: synth.make_stations(grid["bbox"], args.strip_nstns, synth.CONFIGS["C3"][5], "tmax"))
+    fit_info = None
+    if fitted:   # the same grid and bandwidths under the variograms step21 -> step22 fit on these very tables (6 stations per deg^2)
+        tmin, fi_n = fit_table_variograms(env, tmin, "tmin")
+        tmax, fi_x = fit_table_variograms(env, tmax, "tmax")
+        fit_info = {"tmin": fi_n, "tmax": fi_x}
     ctx = _lib.Context(device=env.local)
     ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
     ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
@@ -391,9 +396,12 @@ def strip_run(env, args, steps, warmup, spot_check, full=False):
     state = {}
     dev_ms, gather_ms, tile_wall = [], [], []
 
+    ukstats = {}
+
     def step():
         t0 = time.perf_counter()
-        buf, stat, ms = driver.interp_tiles_device(ctx, dgrid, mine, T, T, nslots=nmax)
+        ukstats.clear()
+        buf, stat, ms = driver.interp_tiles_device(ctx, dgrid, mine, T, T, nslots=nmax, stats=ukstats if fitted else None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if env.world > 1:
@@ -436,6 +444,14 @@ def strip_run(env, args, steps, warmup, spot_check, full=False):
                 "frac_of_peak": ALG_BYTES_PER_CELL_MONTH_2V * units * steps / elapsed / 1e9 / (HBM_PEAK_GBS * env.world)},
         "setup_s": setup_s,
     }
+    if fitted:
+        rec["workload"] = rec["workload"].replace("c3: ", "c3_fitted: ", 1) + (
+            "; vario_nug / vario_psill / vario_rng of both tables replaced by what step21 -> set_optim_nstns_tair_norm -> step22 fit on them")
+        rec["fitted_variograms"] = fit_info
+        rec["uk_solves"] = int(ukstats.get("uk_solves", 0))
+        rec["systems_on_fp64_covariance_build"] = int(ukstats.get("uk_f64_solves", 0))
+        rec["frac_on_fp64_covariance_build"] = rec["systems_on_fp64_covariance_build"] / max(1, rec["uk_solves"])
+        rec["note"] = "per-tile statistics are read back in this record (one host wait per tile): compare value with configs.c3"
     if env.rank == 0 and args.dump_mosaic:
         np.savez(args.dump_mosaic, **{k: v.cpu().numpy() for k, v in state["mosaic"].items()})
     if env.rank == 0 and spot_check and not args.no_cpu_baseline:
@@ -509,26 +525,42 @@ def strong_daily_run(env, args):
     return rec
 
 
+def fit_table_variograms(env, stn, var):
+    """step21 -> set_optim_nstns_tair_norm -> step22 on a copy of a station table; returns a copy of ``stn`` whose vario_* columns
+    are the fitted ones (bandwidth columns untouched, so that the systems are those of the un-fitted run) + the fit statistics."""
+    from topowx_amd import stationdb as sdb, xval
+    t0 = time.perf_counter()
+    work = sdb.StationDataWrkChk(stn.stns.copy(), var, stn.days, None)
+    ids = xval.xval_station_ids(work)
+    kw = dict(stn_ids=ids, device=env.local)
+    _, mae = xval.optim_nstns_norms(work, var, **kw)
+    xval.set_optim_nstns_tair_norm(work, ids, mae)
+    _, nug, psill, rng = xval.set_stn_variograms(work, var, **kw)
+    fitted = sdb.StationDataWrkChk(stn.stns.copy(), var, stn.days, None)
+    for m in range(1, 13):
+        for par in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG):
+            name = sdb.get_krigparam_varname(m, par)
+            fitted.stns[name] = work.stns[name]
+    fin = np.isfinite(nug) & np.isfinite(psill)
+    ratio = nug[fin] / np.where(psill[fin] > 0, psill[fin], np.nan)
+    ratio = ratio[np.isfinite(ratio)]
+    okr = np.isfinite(rng) & (rng > 0)
+    info = {"stations_fitted": int(len(ids)), "station_months_fitted": int(np.isfinite(nug).sum()), "fit_s": time.perf_counter() - t0,
+            "nug_over_psill_quantiles_5_25_50_75_95": [float(x) for x in np.quantile(ratio, [.05, .25, .5, .75, .95])] if ratio.size else None,
+            "frac_below_one_sixteenth": float((ratio < 1 / 16.).mean()) if ratio.size else None,
+            "pure_nugget_frac": float((rng[np.isfinite(rng)] == 0).mean()) if np.isfinite(rng).any() else None,
+            "range_km_quantiles_5_50_95": [float(x) for x in np.quantile(rng[okr], [.05, .5, .95])] if okr.any() else None}
+    return fitted, info
+
+
 def c2_fitted_record(env, args, ctx, stn, grid, g, o, d_norm, d_stat, stream, headline_uk_ms, headline_value):
     """The headline tile under the pipeline's OWN variograms: step21 (leave-one-out bandwidth
     optimisation, step21:34-64) -> ``set_optim_nstns_tair_norm`` -> step22 (every station's variogram fitted with the
     optimised bandwidths: nugget = min gamma, interp.R:304-359; step22:33-66) run on the C2 station database itself;
     then the SAME tile, bandwidths and launches as the headline, with only the ``vario_*`` columns replaced by the fitted
     ones -- so that ``uk_ms`` differs from the headline's by the systems routed to the fp64 covariance build alone."""
-    from topowx_amd import _lib, stationdb as sdb, xval
-    t0 = time.perf_counter()
-    work = sdb.StationDataWrkChk(stn.stns.copy(), "tmin", stn.days, None)
-    ids = xval.xval_station_ids(work)
-    kw = dict(stn_ids=ids, device=env.local)
-    _, mae = xval.optim_nstns_norms(work, "tmin", **kw)
-    xval.set_optim_nstns_tair_norm(work, ids, mae)
-    _, nug, psill, rng = xval.set_stn_variograms(work, "tmin", **kw)
-    fit_s = time.perf_counter() - t0
-    fitted = sdb.StationDataWrkChk(stn.stns.copy(), "tmin", stn.days, None)
-    for m in range(1, 13):
-        for par in (sdb.VARIO_NUG, sdb.VARIO_PSILL, sdb.VARIO_RNG):
-            name = sdb.get_krigparam_varname(m, par)
-            fitted.stns[name] = work.stns[name]
+    from topowx_amd import _lib
+    fitted, fi = fit_table_variograms(env, stn, "tmin")
     ctx.set_stations(_lib.TMIN, fitted, with_obs=False)
     kern = []
     steps = max(3, args.steps // 2)
@@ -536,24 +568,16 @@ def c2_fitted_record(env, args, ctx, stn, grid, g, o, d_norm, d_stat, stream, he
                     lambda keep: kern.append(ctx.timing()) if keep else ctx.timing())
     status = d_stat.cpu().numpy()
     ok = int((status == 0).sum())
-    fin = np.isfinite(nug) & np.isfinite(psill)
-    ratio = nug[fin] / np.where(psill[fin] > 0, psill[fin], np.nan)
-    ratio = ratio[np.isfinite(ratio)]
     uk_ms = float(np.mean([t["uk_ms"] for t in kern]))
     rec = {"value": ok * 12 * steps / elapsed, "unit": "cell-months/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
            "workload": "c2_fitted: the headline's C2 tile, bandwidths and launches; vario_nug / vario_psill / vario_rng of all "
                        "%d cross-validated stations replaced by what step21 -> set_optim_nstns_tair_norm -> step22 fit on the same "
-                       "database (topowx_amd.xval; %d station-months fitted)" % (len(ids), int(np.isfinite(nug).sum())),
+                       "database (topowx_amd.xval; %d station-months fitted)" % (fi["stations_fitted"], fi["station_months_fitted"]),
            "cells_ok": ok, "cells_failed_by_status": {str(int(c)): int(n) for c, n in zip(*np.unique(status[status != 0], return_counts=True))},
            "uk_ms": uk_ms, "uk_ms_headline": headline_uk_ms, "uk_ms_ratio_to_headline": uk_ms / headline_uk_ms,
            "value_ratio_to_headline": (ok * 12 * steps / elapsed) / headline_value,
            "uk_solves": int(kern[-1]["uk_solves"]), "systems_on_fp64_covariance_build": int(kern[-1]["uk_f64_solves"]),
-           "fitted_variograms": {"nug_over_psill_quantiles_5_25_50_75_95": [float(x) for x in np.quantile(ratio, [.05, .25, .5, .75, .95])] if ratio.size else None,
-                                 "frac_below_one_sixteenth": float((ratio < 1 / 16.).mean()) if ratio.size else None,
-                                 "pure_nugget_frac": float((rng[np.isfinite(rng)] == 0).mean()) if np.isfinite(rng).any() else None,
-                                 "range_km_quantiles_5_50_95": [float(x) for x in np.quantile(rng[np.isfinite(rng) & (rng > 0)], [.05, .5, .95])]
-                                 if (np.isfinite(rng) & (rng > 0)).any() else None},
-           "fit_s": fit_s}
+           "fitted_variograms": {k: v for k, v in fi.items() if k != "fit_s"}, "fit_s": fi["fit_s"]}
     if not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         orc.build()
@@ -938,6 +962,10 @@ def main():
             t1 = time.perf_counter()
             cfg["c3"] = strip_run(env, args, args.c3_steps, 1, spot_check=True, full=True)
             cfg["c3"]["record_wall_s"] = time.perf_counter() - t1
+        if "c3_fitted" in want_cfg:
+            t1 = time.perf_counter()
+            cfg["c3_fitted"] = strip_run(env, args, 1, 1, spot_check=True, full=not args.force_configs, fitted=True)   # (tests: the strip)
+            cfg["c3_fitted"]["record_wall_s"] = time.perf_counter() - t1
         if "c3_strip" in want_cfg:
             t1 = time.perf_counter()
             cfg["c3_strip"] = strip_run(env, args, args.strong_steps, 1, spot_check=True)

@@ -107,8 +107,8 @@ def test_bench_c2_fitted_and_c4_reduced():
     step22 fit on its own database: same systems, parity vs the oracle on the fitted table) and ``c4`` (every tile of a
     masked grid streamed with daily output: counts, per-tile times, oracle check of cells from four tiles)."""
     d = _run("--size", "64", "--nstns", "2500", "--steps", "2", "--warmup", "1", "--no-daily", "--cpu-sample", "16",
-             "--force-configs", "--configs", "c2_fitted,c4", "--c4-rows", "150", "--c4-cols", "400", "--c4-years", "2",
-             "--strip-tile", "50", "--strip-nstns", "2500")
+             "--force-configs", "--configs", "c2_fitted,c4,c3_fitted", "--c4-rows", "150", "--c4-cols", "400", "--c4-years", "2",
+             "--strip-tile", "50", "--strip-nstns", "2500", "--strip-rows", "100", "--strip-cols", "400")
     f = d["configs"]["c2_fitted"]
     assert f["cells_ok"] + sum(f["cells_failed_by_status"].values()) == 64 * 64 and f["uk_solves"] > 0
     assert f["value"] > 0 and f["uk_ms"] > 0 and 0 <= f["systems_on_fp64_covariance_build"] <= f["uk_solves"]
@@ -123,3 +123,7 @@ def test_bench_c2_fitted_and_c4_reduced():
     assert s["cells"] >= 12 and s["tiles"] >= 3 and s["status_equal"] and s["ninvalid_equal"]
     assert s["normals_max_abs_degC"] < 1e-4 and s["int16_max_abs_lsb"] <= 1
     assert min(s["tile_valid_cells"]) <= max(s["tile_valid_cells"])
+    t = d["configs"]["c3_fitted"]                      # (reduced: the strip instead of the full configs[2] grid)
+    assert t["cells_ok"] == t["cells_valid"] and t["uk_solves"] == t["cells_ok"] * 24
+    assert 0 <= t["systems_on_fp64_covariance_build"] <= t["uk_solves"] and t["value"] > 0
+    assert t["spot_check_vs_oracle"]["max_abs_degC"] < 1e-4 and set(t["fitted_variograms"]) == {"tmin", "tmax"}

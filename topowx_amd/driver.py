@@ -108,14 +108,16 @@ def upload_grid(grid, device, tiles=None, tile_y=None, tile_x=None):
     return {"tiles": cut, "shape": (Yg, Xg), "device": torch.device(device)}
 
 
-def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), nslots=None, stream=None):
+def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), nslots=None, stream=None, stats=None):
     """Normals + SE of this rank's tiles with everything resident in HBM: the predictor planes come from the device
     tensors of ``upload_grid`` (whole grid: each tile's 61 B / cell are gathered into a contiguous image by a device copy;
     per-tile upload: used as they are), and ``twx_interp_grid_dev`` writes every tile's outputs straight into slot s of ONE
     device tensor ``buf[nslots, 4, 12, tile_y, tile_x]`` -- the send buffer of ``gather_mosaic_device``; nothing crosses
     PCIe.  ``nslots`` >= len(tiles) pads the buffer to the size every rank of a gather must share.  The loop does not
     wait for a tile before it enqueues the next one (the library's own 64-byte read-back per call apart): per-tile times
-    come from events recorded on the launch stream and are read once, after the loop.
+    come from events recorded on the launch stream and are read once, after the loop.  ``stats``: a dict that accumulates the
+    library's launch statistics (``uk_solves``, ``uk_f64_solves``) over the tiles -- a diagnostic: it reads them after every
+    tile, which waits for the tile.
     Returns (buf, status[nslots, tile_y, tile_x] i4 device tensor, per-tile device ms)."""
     import torch
     from . import _lib
@@ -150,6 +152,10 @@ def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "t
         ptr = [o[q].data_ptr() if v in variables else None for q, v in enumerate(("tmin", "tmin", "tmax", "tmax"))]
         go = _lib.TwxGridOut(ptr[0], ptr[1], ptr[2], ptr[3], None, None, ninv.data_ptr(), so.data_ptr())
         ctx.interp_grid_dev(g, go, vars_mask, strm)     # (stream-ordered: the tile's input images may be freed by torch afterwards)
+        if stats is not None:
+            t_ = ctx.timing()
+            for key in ("uk_solves", "uk_f64_solves"):
+                stats[key] = stats.get(key, 0) + int(t_[key])
         if not full:
             buf[s, :, :, :y, :x] = o
             stat[s, :y, :x] = so
