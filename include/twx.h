@@ -101,12 +101,12 @@ typedef struct {
 /* kriging: never route a system to the fp64 covariance build (diagnostic switch; tests/tools/gpu_closepair_scan.py
  * measures the fast build's error with it).  Default (flag clear): a system whose amplification
  * psill / (2 (nug + psill (1 - exp(-hmin / range)))) -- hmin = smallest distance between two of its neighbours --
- * exceeds 8 has its covariance matrix built from fp64 distances and fp64 exponentials (k_uk<NB, 2, 1>) instead of the
+ * exceeds 8 has its covariance matrix built from fp64 distances and fp64 exponentials (the <.., 1> instance of the kernel of its matrix size) instead of the
  * fp32 pair-distance cache + v_exp_f32: station pairs a few hundred metres apart with a nugget near 0 are legal
  * inputs of interp.R:223-231,256 (nugget = min gamma, interp.R:304-359) and amplify the fp32 rounding of an entry
  * beyond the 1e-4 degC parity bar (measured: tests/test_gpu_closepairs.py). */
 #define TWX_FLAG_UK_FAST_ONLY 8
-/* kriging: EVERY system on the fp64 covariance build (2.8 x the kriging time): the normals then agree with an fp64
+/* kriging: EVERY system on the fp64 covariance build (2.1 x the kriging time): the normals then agree with an fp64
  * evaluation of the reference's formulas to ~1e-11 degC instead of ~1e-6 (one ulp of the f4 outputs), and the 2e-5 of
  * the packed int16 daily values that sit within that 1e-6 of a rounding boundary stop flipping by one count
  * (tests/test_gpu_closepairs.py).  For comparisons against other fp64 implementations; not needed for the 1e-4 degC bar. */

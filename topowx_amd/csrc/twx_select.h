@@ -710,7 +710,7 @@ __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 // (measured on the GPU, tests/tools/gpu_closepair_scan.py with the fast build forced: error <= ~8e-7 amp degC on ten
 // disagreeing pairs 50-300 m apart: 7.6e-6 at amp 10, 5e-5 at amp 100, 2.4e-3 at amp 9 000).  The reference's nugget is
 // min(gamma) of an empirical variogram (interp.R:304-359): nothing bounds it away from 0, and step20 removes only exact
-// duplicates (step20:51-57).  Systems with amp > TWX_F64_AMP are routed to k_uk<NB, 2, 1>: fp64 distances from the
+// duplicates (step20:51-57).  Systems with amp > TWX_F64_AMP are routed to the <.., 1> instance of their kernel: fp64 distances from the
 // stations' half-angle trigonometry, fp64 exp.  A pure-nugget model has no off-diagonal entries to perturb.
 #ifndef TWX_F64_AMP
 #define TWX_F64_AMP 8.0

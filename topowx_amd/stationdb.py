@@ -201,8 +201,13 @@ class _StnVariable(object):
         col = self._db.stns[self.name]
         col[key] = np.where(v == self._fill, np.nan, v) if self._fill is not None else v
         if self._fvar is not None:
-            out = np.where(np.isnan(col), self._fill, col) if self._fill is not None else col
-            self._fvar[:] = out.astype(self._fvar.dtype)
+            def packed(a):
+                a = np.asarray(a, np.float64)
+                return (np.where(np.isnan(a), self._fill, a) if self._fill is not None else a).astype(self._fvar.dtype)
+            if isinstance(key, (int, np.integer, slice)):
+                self._fvar[key] = packed(col[key])              # one station / a run of stations: only that hyperslab (step22:104-110
+            else:                                               # assigns station by station: the whole column each time would be O(n^2))
+                self._fvar[:] = packed(col)
 
     def __getitem__(self, key):
         return np.ma.masked_invalid(self._db.stns[self.name][key])
