@@ -170,7 +170,9 @@ typedef struct {
 } twx_grid_out;
 
 /* Device time of the kernels of the last grid call, measured with HIP events on
- * the call's stream (ms); filled when the call has completed. */
+ * the call's stream (ms); filled when the call has completed.  The system
+ * counters (uk_solves, uk_launches, uk_f64_solves) are those of the last entry
+ * call, grid or points; the times are 0 after a point entry. */
 typedef struct {
     float tile_cand_ms, select_ms, uk_ms, gwr_ms, daily_ms, fix_ms, total_ms;
     int64_t cells;        /* unmasked cells processed */

@@ -198,6 +198,41 @@ def test_close_pairs_leave_one_out(env, orc):
     assert worst < TOL, worst
 
 
+def test_routing_bound_covers_every_close_pair(env):
+    """What routes a system to the fp64 covariance build is a LOWER BOUND of the smallest pair distance inside its
+    neighbourhood -- the smallest distance of any of its neighbours to that neighbour's nearest other station of the
+    table (k_stn_nn, k_select: SelWs.hminp) -- so a system whose neighbourhood holds a close pair is always routed,
+    and one whose close partner fell just outside the neighbourhood is routed too (the safe side).  Counted here
+    against the exact rule and against the bound, both restated in numpy on the neighbour lists the library returns."""
+    from oracle import pyoracle as po
+    ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
+    c = env["odb"].cols
+    lon, lat = np.asarray(c["lon"]), np.asarray(c["lat"])
+    D = po.grt_circle_dist(lon[:, None], lat[:, None], lon[None, :], lat[None, :])
+    np.fill_diagonal(D, np.inf)
+    nn = D.min(axis=1)
+    cells = np.concatenate([env["cells"], np.argwhere(np.asarray(grid["mask"]) != 0)[::23][:300]])
+    pts = _pts(ctx, grid, cells)
+    nug, psill, rng = 0.0, 1.0, 40.0
+
+    def needs(h):                                            # uk_needs_f64 (twx_select.h), amplification > 8
+        return 16.0 * (nug + psill * -np.expm1(-h / rng)) < psill
+
+    for k in (40, 112):
+        _, _, used, st, ngh = ctx.krig_points(lib.TMIN, pts, 3, nnghs=k, vario=[(nug, psill, rng)] * pts.size, want_idx=True)
+        routed = ctx.timing()["uk_f64_solves"]
+        exact = bound = 0
+        for i in range(pts.size):
+            if used[i] != k:
+                continue
+            idx = ngh[i, :k]
+            exact += bool(needs(D[np.ix_(idx, idx)].min()))
+            bound += bool(needs(nn[idx].min()))
+        assert exact >= 3 and bound >= exact, (k, exact, bound)
+        assert abs(routed - bound) <= 2, (k, routed, bound, exact)       # (fp32 distances on the device: a tie at the threshold)
+        assert bound <= 1.5 * exact + 5, (k, exact, bound)               # the bound is rarely loose
+
+
 def test_every_system_on_the_fp64_build_matches_the_oracle_to_the_last_f4_bit(golden_case, orc):
     """TWX_FLAG_UK_F64_ALL: with fp64 pair distances and exponentials for EVERY system the normals agree with the oracle to
     ~1e-11 degC, i.e. the f4 outputs are the same bits (the default build is one f4 ulp off in about half of them), and the

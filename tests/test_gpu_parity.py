@@ -355,7 +355,7 @@ def test_krig_every_matrix_size_bucket(env, orc):
     model and a long-range one."""
     ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
     ks = [7, 8, 9, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 63, 64, 65, 71, 72, 73, 79, 80, 81, 87, 88, 89,
-          95, 96, 97, 103, 104, 105, 110, 111, 112, 113, 119, 120, 121, 127, 128, 129, 135, 136, 137, 143, 144, 145, 147, 150, 152]
+          95, 96, 97, 103, 104, 105, 106, 110, 111, 112, 113, 119, 120, 121, 122, 127, 128, 129, 135, 136, 137, 138, 143, 144, 145, 147, 150, 152]
     cells = np.argwhere(np.asarray(grid["mask"]) != 0)[::37][:len(ks)]
     assert len(cells) == len(ks)
     pts = _pts(ctx, grid, cells, "tmin")

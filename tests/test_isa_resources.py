@@ -27,7 +27,7 @@ EXPECT = {
     "k_ukwz<5, 1>": (2, 0), "k_ukw<6, 1>": (2, 0), "k_ukwz<6, 1>": (2, 32),
     "k_uk<7, 2, 1>": (3, 0), "k_uk<8, 4, 1>": (4, 0), "k_uk<9, 2, 1>": (2, 0), "k_uk<10, 2, 1>": (2, 160),
     "k_uk<7, 2, 2>": (1, 64), "k_uk<10, 2, 2>": (1, 64),
-    "k_tile_dist<0>": (4, 0), "k_tile_dist<1>": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
+    "k_tile_dist": (4, 0), "k_stn_nn": (4, 0), "k_cell_dist": (4, 0), "k_uk_solve": (4, 0),
     "k_select<4, 0>": (4, 0), "k_select<1, 1>": (2, 0), "k_tile_cand": (4, 0),
     "k_gwr_z": (4, 0), "k_gwr_z_cell": (4, 0), "k_tile_uidx": (4, 0), "k_perm": (4, 0), "k_daily_tile": (6, 0), "k_daily_tile_gather": (4, 0),
     "k_daily_grid": (4, 0), "k_fix_cells": (4, 0), "k_fix_sparse": (2, 0),
@@ -73,7 +73,7 @@ def test_daily_tile_keeps_three_workgroups_per_cu(table):
     # needs <= 53.3 KB each
     assert table["k_daily_tile"]["lds"] <= LDS_PER_CU // 3
     # the pair table of k_tile_dist takes nearly all of a CU's LDS by design (one work-group per CU)
-    assert table["k_tile_dist<0>"]["lds"] <= LDS_PER_CU
+    assert table["k_tile_dist"]["lds"] <= LDS_PER_CU
 
 
 def test_no_kernel_uses_dynamic_scratch_unexpectedly(table):

@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KRIG = ("k_uk<", "k_ukz<", "k_ukw<", "k_ukwz<", "k_ukw2<", "k_cell_dist", "k_tile_dist")   # (prefix: k_tile_dist<0>, <1>)   # the kernels behind bench.py's uk_ms
+KRIG = ("k_uk<", "k_ukz<", "k_ukw<", "k_ukwz<", "k_ukw2<", "k_cell_dist", "k_tile_dist")   # the kernels behind bench.py's uk_ms
 DAILY = ("k_daily_tile", "k_tile_union", "k_tile_uidx", "k_perm", "k_row_offsets", "k_daily_ok", "k_daily_grid")   # ... daily_ms
 DAILY_ONLY = DAILY + ("k_gwr_z", "k_gwr_z_cell", "k_fix_cells", "k_fix_sparse", "k_compact_flags")
 

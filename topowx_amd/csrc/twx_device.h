@@ -27,6 +27,8 @@ struct StnDev {
     const double4 *stat_s;                                      // [n] station record (lon, lat, elev, tdi)
     const double2 *mon_s;                                       // [n][12] (lst, norm)
     const double *coslat;                                       // cos(lat * TWX_DEG2RAD) [n] (k_stn_coslat; k_tile_cand's fp32 bound)
+    const float *nn_km;                                         // [n] distance to the nearest OTHER station of the table (k_stn_nn): a
+                                                                // lower bound of the pair distances inside any neighbourhood (SelWs.hminp)
     const float *obs;                                           // [n][ndays_mm] month-major days, or null
     const double *ymsum;                                        // [n][12][norm_ny] sum of a station's observations over every (month, year) of
                                                                 // the normals period (k_fix_sparse), or null

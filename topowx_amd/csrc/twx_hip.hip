@@ -462,13 +462,11 @@ int run_select_uk(twx_ctx *ctx, int v, const CellSrc &src, int64_t cell0, int64_
         hipLaunchKernelGGL(k_vario<0>, dim3((unsigned)(ncell * 12)), dim3(256), 0, stream, st, src, w.ws);
     }
     {
-        // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems -- and the smallest
-        // pair distance by rank, which k_bucket_items needs to route ill-conditioned systems to the fp64 build
+        // pair distances of every cell's largest neighbourhood, shared by its 12 monthly systems
         EvScope ev(ctx, stream, EV_UK);
-        if (w.ws.near_pos && !long_lists) {     // grid mode: per tile, from a table of the tile's station pairs; hminp in a launch of its own
-            hipLaunchKernelGGL(k_tile_dist<0>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
-            hipLaunchKernelGGL(k_tile_dist<1>, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
-        } else
+        if (w.ws.near_pos && !long_lists)       // grid mode: per tile, from a table of the tile's station pairs
+            hipLaunchKernelGGL(k_tile_dist, dim3((unsigned)(ntile * TWX_TD_PARTS)), dim3(64 * TWX_TD_WAVES), 0, stream, st, src, w.ws);
+        else
             hipLaunchKernelGGL(k_cell_dist, dim3((unsigned)ncell), dim3(256), 0, stream, st, src, w.ws);
     }
     {
@@ -667,7 +665,7 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     const size_t n = (size_t)t->n;
     // one allocation: 4 static + 7 monthly + 4 trig columns + cos(lat) (filled on the device) + the station-major
     // copies of optim_nnghs / optim_nnghs_anom ([n][12]) and of the variogram parameters ([n][12][4])
-    const size_t ncol = 4 + 7 * 12 + 4 + 1 + 12 + 12 + 48;
+    const size_t ncol = 4 + 7 * 12 + 4 + 1 + 12 + 12 + 48 + 1;   // (+ nn_km: n floats in a column of their own, filled on the device)
     // ... + station records: (lon, lat, elev, tdi)[n] and (lst, norm)[n][12], 32-byte aligned behind the columns: what
     // the kriging / GWR staging reads of a neighbour comes with two or three 16-byte loads instead of five gathers
     const size_t rec0 = (ncol * n + 3) / 4 * 4;              // (in doubles)
@@ -718,11 +716,13 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
     s.coslat = tcol + 4 * n;
     s.optim_s = tcol + 5 * n; s.optim_anom_s = s.optim_s + 12 * n; s.vario_s = s.optim_anom_s + 12 * n;
     s.stat_s = reinterpret_cast<const double4 *>(d + rec0); s.mon_s = reinterpret_cast<const double2 *>(d + rec0 + 4 * n);
+    s.nn_km = reinterpret_cast<const float *>(s.vario_s + 48 * n);
     hipLaunchKernelGGL(k_stn_coslat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.lat, const_cast<double *>(s.coslat), (int)n);
+    hipLaunchKernelGGL(k_stn_nn, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, s, const_cast<float *>(s.nn_km));
     HIPCHK(hipGetLastError());
     // a setup call: wait here, so that no later launch on a non-blocking stream (twx_stream_*, a caller's stream in
     // twx_interp_grid_dev) can read cos(lat) -- k_tile_cand's conservative radius -- before it is written, and so
-    // that an asynchronous fault of this kernel is reported by this call
+    // that an asynchronous fault of these kernels is reported by this call
     HIPCHK(hipStreamSynchronize(nullptr));
     s.obs = nullptr; s.ymsum = nullptr;
     vd.n = (int)n; vd.kmax = s.kmax; vd.has_obs = false;
@@ -791,6 +791,8 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
 {
     ctx->ev_used = 0;   // point entries do not report kernel timing: recycle the event pool
     ctx->have_total = false;
+    HIPCHK(ctx->stats.ensure(64));                           // ... but they do count their systems (twx_get_timing: uk_solves, uk_f64_solves
+    HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 64, nullptr));    // of the LAST entry call, grid or points)
     size_t bytes = (size_t)npts * (sizeof(twx_pt) + 5 * 4 + 4 * 8) + 8192;
     HIPCHK(ctx->pt_in.ensure(bytes));
     char *cur = ctx->pt_in.as<char>();

@@ -57,8 +57,9 @@ struct SelWs {
     float *dist;         // [ncell][TWX_DIST_BLOCKS][16 tc][16 tr] station-pair distances (km) of the cell's kriging
                          // neighbourhood in rank order, 16x16 blocks (a >= b) -- shared by the cell's 12 monthly systems
     float *h0;           // [ncell][ksel] cell -> neighbour distance (km, sp/gstat formula)
-    float *hminp;        // [ncell][ksel] smallest pair distance among the neighbours of ranks <= r (k_cell_dist / k_tile_dist;
-                         // +inf at rank 0): what decides whether a system needs the fp64 covariance build (uk_needs_f64)
+    float *hminp;        // [ncell][ksel] lower bound of the smallest pair distance among the neighbours of ranks <= r: the running
+                         // minimum of their distances to their nearest other station (StnDev.nn_km; k_select) -- what decides
+                         // whether a system needs the fp64 covariance build (uk_needs_f64)
     int fast_only;       // TWX_FLAG_UK_FAST_ONLY: never route a system to the fp64 build (diagnostic)
     int f64_all;         // TWX_FLAG_UK_F64_ALL: every system on the fp64 build
     int32_t *cellf64;    // [ncell] 0, or 1 + the cell's SLOT in the fp64 slabs: a month of the cell was routed to the fp64 build
@@ -410,6 +411,24 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
         if (lane < 12) { ws.kk[lc * 12 + lane] = 0; ws.ka[lc * 12 + lane] = 0; }   // (kk > 0 is what the kriging kernels go by)
         return;
     }
+    // what routes a system to the fp64 covariance build (uk_needs_f64): a lower bound of the smallest pair distance among
+    // the neighbours of ranks <= r -- the running minimum of the stations' distances to their nearest other station
+    // (k_stn_nn; exact unless a neighbour's nearest partner lies outside the neighbourhood, and then on the safe side:
+    // the system is routed).  Three gathers and three wave scans per cell, against a second pass over the tile's pair
+    // table (rounds 3-5: k_tile_dist<1>, 0.26 ms per tile batch of a run on fitted variograms).
+    if (src.do_krig) {
+        float run = __builtin_inff();
+        for (int r0 = 0; r0 < ws.ksel; r0 += 64) {
+            const int r = r0 + lane;
+            const int s = r < nnear ? sni[r] : -1;
+            float v = s >= 0 ? st.nn_km[s] : __builtin_inff();
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v = fminf(v, __shfl_up(v, o, 64));   // (lanes < o get their own value back)
+            v = fminf(v, run);
+            if (r < ws.ksel) ws.hminp[lc * ws.ksel + r] = v;
+            run = __shfl(v, 63, 64);
+        }
+    }
     // phase 3: monthly smoothing (a3, a4) in the reference's order: krig then gwr per month
     int status = too_many ? TWX_CELL_CAND_OVERFLOW : TWX_CELL_OK;
     const int only = (src.mode == 1 && src.mth) ? src.mth[c] : 0;
@@ -678,6 +697,10 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 //                   column stays out of the 4-column panel that holds the first border column): k_ukw<m> / k_uk<m>
 //   k >  16 m - 8   the border would open a block row of its own: k_ukwz<m> keeps it as columns beside NP = 16 m C rows
 //                   (twx_ukw.h) up to m = 6; larger systems take the bordered form with m + 1 block rows
+// (k = 16 m - 7 in the bordered form -- a last panel of ONE C column beside three border columns, their pivots masked --
+// was built in round 5 and taken out again: no value of the bandwidth ladder 35, 39, 43, 47, 52, 57, 63, 69, 76, 84, 92,
+// 101, 111, 122, 134, 147 (optimize.py:376-405) is of that form -- 122 needs 129 rows, not 128 -- and the masks on the
+// pivot chain cost every multi-wave kernel ~5 %: DESIGN.md section 10.)
 // LDS counters per workgroup, one global atomic per (workgroup, bucket).  Order inside a bucket is irrelevant.
 // ---------------------------------------------------------------------------------
 #define TWX_NFAST 14                                           // matrix-size buckets (one kriging launch each)
@@ -715,8 +738,8 @@ __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 #ifndef TWX_F64_AMP
 #define TWX_F64_AMP 8.0
 #endif
-// necessary condition (1 - exp(.) >= 0): the nugget alone must be below psill / 16.  The distance kernels record hminp
-// only for cells with such a month, and k_bucket_items reads it only then (the synthetic benchmark never does).
+// necessary condition (1 - exp(.) >= 0): the nugget alone must be below psill / 16; k_bucket_items reads hminp only
+// then (the synthetic benchmark never does).
 __device__ __forceinline__ bool uk_may_need_f64(double nug, double psill, double rng)
 {
     return rng > 0.0 && psill > 0.0 && (2.0 * TWX_F64_AMP) * nug < psill;

@@ -94,14 +94,6 @@ __device__ __attribute__((noinline)) float ellip_pair_far(double Sd, double cc, 
     return (float)(2 * w * TWX_WGS84_A * (1 + TWX_WGS84_F * H1 * sF2 * cG2 - TWX_WGS84_F * H2 * cF2 * sG2));
 }
 
-// inclusive running minimum over the 16 lanes of a DPP row (lane n: min of lanes 0..n of its row)
-__device__ __forceinline__ float row_scan_min(float v)
-{
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v = fminf(v, __shfl_up(v, o, 16));   // (lanes < o get their own value back)
-    return v;
-}
-
 // WGS84 great-circle distance (sp / gstat) of two points from the
 // sines / cosines of their half latitudes and half longitudes plus cos(lat).
 // With F = (p1+p2)/2, G = (p1-p2)/2, L = (l1-l2)/2:
@@ -132,6 +124,26 @@ __device__ __forceinline__ float ellip_pair_fast(double sp1, double cp1, double 
     const float H2 = (R3 + 1.f) * __builtin_amdgcn_rcpf(2.f * S);
     const float corr = (float)TWX_WGS84_F * (H1 * sF2 * cG2 - H2 * cF2 * g2);
     return (2.f * (float)TWX_WGS84_A) * (rs * P) * (1.f + corr);
+}
+
+// ---------------------------------------------------------------------------------
+// k_stn_nn (twx_set_stations, once per table): every station's distance to its nearest OTHER station, in the cache's
+// fp32 formula.  min over the ranks < k of a neighbourhood is a lower bound of the smallest pair distance INSIDE it
+// (exact unless a station's nearest partner lies outside the neighbourhood): what routes a system to the fp64 covariance
+// build (uk_needs_f64; k_select stores the running minimum by rank, SelWs.hminp).  One lane per station; the partner
+// loop is wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_stn_nn(StnDev st, float *nn)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, ii = min(i, st.n - 1);
+    const double sp = st.sph[ii], cp = st.cph[ii], sl = st.slh[ii], cl = st.clh[ii], cph = fma(cp, cp, -(sp * sp));
+    float m = __builtin_inff();
+    for (int j = 0; j < st.n; ++j) {
+        const double sp2 = st.sph[j], cp2 = st.cph[j];
+        const float h = ellip_pair_fast(sp, cp, sl, cl, cph, sp2, cp2, st.slh[j], st.clh[j], fma(cp2, cp2, -(sp2 * sp2)));
+        if (j != ii) m = fminf(m, h);                        // (a station without coordinates: NaN, ignored by fminf)
+    }
+    if (i < st.n) nn[i] = m;
 }
 
 // ---- fp64 covariance build of the ill-conditioned systems (uk_needs_f64, twx_select.h) -------------------------------
@@ -214,11 +226,9 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
     __shared__ double s_trig[TWX_KSEL_MAX * 4];
     __shared__ double s_cphi[TWX_KSEL_MAX];
     __shared__ int s_dup;                                    // lowest rank whose neighbour coincides with an earlier one
-    __shared__ int s_rmin[TWX_KSEL_MAX];                     // per rank i: min over j < i of h(i, j), as float bits (h >= 0)
     const int64_t lc = blockIdx.x;
     if (lc >= ws.ncell) return;                              // (a cell without a system to krige has kmax = 0 below)
     const int t = threadIdx.x, tr = t & 15, tc = t >> 4;
-    if (t < TWX_KSEL_MAX) s_rmin[t] = 0x7f800000;
     int kmax = 0;
 #pragma unroll
     for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
@@ -246,14 +256,12 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
         const bool iv = i < kmax;
         const double spi = iv ? s_trig[i * 4] : 0.0, cpi = iv ? s_trig[i * 4 + 1] : 1.0;
         const double sli = iv ? s_trig[i * 4 + 2] : 0.0, cli = iv ? s_trig[i * 4 + 3] : 1.0, cphi = iv ? s_cphi[i] : 1.0;
-        float rm = __builtin_inff();
         for (int b = 0; b <= a; ++b) {
             const int j = 16 * b + tc;
             float h = 1.f;                                   // diagonal / outside the neighbourhood: any h > 0 (masked by the build)
             if (iv && j < kmax && i != j) {
                 h = ellip_pair_fast(spi, cpi, sli, cli, cphi, s_trig[j * 4], s_trig[j * 4 + 1], s_trig[j * 4 + 2],
                                     s_trig[j * 4 + 3], s_cphi[j]);
-                if (j < i) rm = fminf(rm, h);
                 // coincident neighbours: c(0) = full sill in both rows, i.e. every system holding both is singular
                 // (gstat fails there).  Such systems are flagged by rank (k > cdup) instead of through their pivots,
                 // and the cached distance stays positive so that the build's masks (-inf * h) never see 0.
@@ -261,25 +269,9 @@ __global__ __launch_bounds__(256) void k_cell_dist(StnDev st, CellSrc src, SelWs
             }
             __builtin_nontemporal_store(h, &out[(a * (a + 1) / 2 + b) * 256 + t]);   // t = tc * 16 + tr
         }
-        if (iv) atomicMin(&s_rmin[i], __float_as_int(rm));
     }
     __syncthreads();
     if (t == 0) ws.cdup[lc] = s_dup;
-    // smallest pair distance among the neighbours of ranks <= r (uk_needs_f64 reads entry k - 1 of a system of k);
-    // only for a cell with a month whose nugget is small enough for the fp64 build to be possible at all
-    // (fit mode -- ws.vfit set -- kriges a second time with variograms that do not exist yet, twx_krigall_points: always)
-    if (t < 64 && (cell_may_need_f64(ws.vario + lc * 36, t) || ws.vfit != nullptr)) {
-        float run = __builtin_inff();
-        for (int r0 = 0; r0 < kmax; r0 += 64) {
-            const int r = r0 + t;
-            float v = r < kmax ? __int_as_float(s_rmin[r]) : __builtin_inff();
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) v = fminf(v, __shfl_up(v, o, 64));
-            v = fminf(v, run);
-            if (r < kmax) ws.hminp[lc * ws.ksel + r] = v;
-            run = __shfl(v, 63, 64);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -337,13 +329,6 @@ __global__ __launch_bounds__(256) void k_cell_dist64(StnDev st, SelWs ws)
 #ifndef TWX_TD_PARTS
 #define TWX_TD_PARTS 2      // work-groups per tile (row bands of the tile: a smaller union per table)
 #endif
-// HM = 0: the cache (dist, h0, cdup).  HM = 1: only hminp -- the smallest pair distance among a cell's neighbours by rank,
-// which routes a system to the fp64 covariance build (uk_needs_f64) -- and only for cells with a month whose nugget
-// makes that possible (uk_may_need_f64): a second, separate launch whose work-groups leave at once when no cell of
-// their tile part qualifies (the synthetic benchmark: all of them).  Kept out of the cache kernel on purpose: with the
-// row minima in its block loop -- even behind a per-cell branch, even as a second instance of the loop -- the cache
-// kernel ran 616 -> 668...695 us per C2 step.
-template <int HM>
 __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, CellSrc src, SelWs ws)
 {
     constexpr int NTH = 64 * TWX_TD_WAVES;
@@ -351,7 +336,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
     __shared__ uint16_t s_slot[TWX_CAND_MAX];                // candidate position -> 1 + number in the union (0: not used)
     __shared__ double s_trig[TWX_TD_U * 5];                  // sin / cos of half latitude and longitude, cos(latitude)
     __shared__ uint16_t s_ur[TWX_TD_WAVES][TWX_KSEL_MAX];    // per wave: union number by rank, of the wave's current cell
-    __shared__ int s_cnt[TWX_TD_WAVES], s_base, s_dup[TWX_TD_WAVES], s_any;
+    __shared__ int s_cnt[TWX_TD_WAVES], s_base, s_dup[TWX_TD_WAVES];
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t tl = blockIdx.x / TWX_TD_PARTS;            // local tile; this work-group takes one part of its cells
@@ -362,29 +347,17 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
     const int ncl = src.ts * src.ts;                         // cells per tile (<= 64)
     const int ci0 = ncl * part / TWX_TD_PARTS, ci1 = ncl * (part + 1) / TWX_TD_PARTS;
     const int ncand = min(ws.ncand[tl], ws.cmax);
-    // local cell of the tile's ci-th cell and its largest monthly neighbourhood (wave-uniform; -1 / 0: nothing to do);
-    // HM: only the cells that can need the fp64 build
+    // local cell of the tile's ci-th cell and its largest monthly neighbourhood (wave-uniform; -1 / 0: nothing to do)
     auto cell_of = [&](int ci, int &kmax) __attribute__((always_inline)) -> int64_t {
         kmax = 0;
         const int rr = r0 + ci / src.ts, qq = q0 + ci % src.ts;
         if (rr >= src.Y || qq >= src.X) return -1;
         const int64_t lc = (int64_t)rr * src.X + qq - ws.cell0;
         if (lc < 0 || lc >= ws.ncell) return -1;                // (kmax = 0: nothing to krige -- masked, or failed before any kriging)
-        if (HM && !cell_may_need_f64(ws.vario + lc * 36, lane)) return -1;
 #pragma unroll
         for (int m = 0; m < 12; ++m) kmax = max(kmax, ws.kk[lc * 12 + m]);
         return lc;
     };
-    if constexpr (HM) {                                      // does any cell of this part qualify?
-        if (t == 0) s_any = 0;
-        __syncthreads();
-        for (int ci = ci0 + wv; ci < ci1; ci += TWX_TD_WAVES) {
-            int kmax;
-            if (cell_of(ci, kmax) >= 0 && kmax > 0 && lane == 0) s_any = 1;
-        }
-        __syncthreads();
-        if (!s_any) return;
-    }
     for (int p = t; p < ncand; p += NTH) s_slot[p] = 0;
     if (t == 0) s_base = 0;
     __syncthreads();
@@ -442,28 +415,24 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
         const int64_t lc = cell_of(ci, kmax);
         if (kmax <= 0) continue;
         uint16_t *ur = s_ur[wv];
-        if (!HM && lane == 0) s_dup[wv] = 0x7fffffff;
+        if (lane == 0) s_dup[wv] = 0x7fffffff;
         const double *ct = ws.ctrig + lc * 4;
         const double ccph = fma(ct[1], ct[1], -(ct[0] * ct[0]));
         for (int r = lane; r < kmax; r += 64) {
             const int u = (int)s_slot[ws.near_pos[lc * ws.ksel + r]] - 1;
             ur[r] = (uint16_t)u;
-            if constexpr (!HM) {
-                const double *bq = &trig[u * 5];
-                ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
-            }
+            const double *bq = &trig[u * 5];
+            ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
         }
         __builtin_amdgcn_wave_barrier();
         const int nbk = max((kmax + 15) >> 4, 2);            // (two block rows at least: see k_cell_dist)
         float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
         const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
-        float run = __builtin_inff();                        // (HM) smallest pair distance among the rows above this block row
         for (int a = 0; a < nbk; ++a) {
             const int i = 16 * a + tr;
             const bool iv = i < kmax;
             const int ui = iv ? ur[i] : 0, ti = ui * (ui + 1) / 2;
             const double *pa = &trig[ui * 5];
-            float rm = __builtin_inff();                     // (HM) min over j < i of h(i, j) (this lane's columns)
             for (int b = 0; b <= a; ++b) {
                 float *ob = out + (a * (a + 1) / 2 + b) * 256 + lane;
 #pragma unroll
@@ -477,23 +446,15 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
                             const double *pb = &trig[uj * 5];
                             h = ellip_pair_fast(pa[0], pa[1], pa[2], pa[3], pa[4], pb[0], pb[1], pb[2], pb[3], pb[4]);
                         }
-                        if (HM && j < i) rm = fminf(rm, h);
                         // coincident neighbours: see k_cell_dist
-                        if (!HM && h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
+                        if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
-                    if constexpr (!HM) __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
+                    __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
                 }
-            }
-            if constexpr (HM) {                              // row minimum over the four lane columns, running minimum down the rows
-                rm = fminf(rm, __shfl_xor(rm, 16, 64));
-                rm = fminf(rm, __shfl_xor(rm, 32, 64));
-                rm = fminf(row_scan_min(rm), run);
-                if (lane < 16 && iv) ws.hminp[lc * ws.ksel + i] = rm;
-                run = __shfl(rm, 15, 64);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (!HM && lane == 0) ws.cdup[lc] = s_dup[wv];
+        if (lane == 0) ws.cdup[lc] = s_dup[wv];
     }
 }
 
