@@ -200,6 +200,42 @@ def test_single_variable_daily_equals_two_variable_run(golden_case):
     assert np.array_equal(one_n["norm_tmin"], both["norm_tmin"]) and np.array_equal(one_x["se_tmax"], both["se_tmax"])
 
 
+def test_packed_cluster_union_of_thousands(golden_case):
+    """4 000 stations packed into the footprint of HALF a tile (4 x 8 cells, ~30 km2) with 148 neighbours everywhere:
+    neighbouring cells then share few neighbours, and the stations the 32 cells of the half-tile krige with number
+    thousands -- more than any shared LDS staging could hold (rounds 3-4 staged the union's trigonometry in the pair
+    table's space: room for 3 289).  k_tile_dist's per-element path stages per wave, by rank, whatever the union.
+    Grid path == point path (k_cell_dist) bit for bit."""
+    from topowx_amd import _lib, stationdb as sdb, synth
+    grid, _, _ = golden_case
+    stn = synth.make_stations(grid["bbox"], 4050, 5, "tmin", expand_deg=0.3)
+    rng = np.random.default_rng(9)
+    lat, lon = np.asarray(grid["lat"]), np.asarray(grid["lon"])
+    dlat, dlon = abs(lat[1] - lat[0]), abs(lon[1] - lon[0])
+    n = 4000
+    stn.stns[sdb.LAT][:n] = rng.uniform(min(lat[32], lat[35]) - dlat / 2, max(lat[32], lat[35]) + dlat / 2, n)
+    stn.stns[sdb.LON][:n] = rng.uniform(min(lon[40], lon[47]) - dlon / 2, max(lon[40], lon[47]) + dlon / 2, n)
+    for m in range(1, 13):
+        stn.stns[sdb.get_optim_varname(m)] = 148.0
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, stn, with_obs=False)
+    rs, cs = slice(32, 40), slice(40, 48)
+    got = ctx.interp_grid(grid, variables=("tmin",), daily=False, rows=rs, cols=cs)
+    kk = ctx.last_bandwidths(_lib.TMIN)
+    cells = np.array([(r, c) for r in range(rs.start, rs.stop) for c in range(cs.start, cs.stop)])
+    pts = ctx.make_pts(lon[cells[:, 1]], lat[cells[:, 0]], grid["elev"][cells[:, 0], cells[:, 1]],
+                       grid["tdi"][cells[:, 0], cells[:, 1]], grid["lst_night"][:, cells[:, 0], cells[:, 1]].T)
+    idx, _, _, st_k = ctx.knn(_lib.TMIN, lon[cells[:32, 1]], lat[cells[:32, 0]], 148)
+    _, norms, se, st = ctx.interp_points(_lib.TMIN, pts, daily=False)
+    ctx.close()
+    assert np.all(st_k == 0) and np.unique(idx).size > 3289, np.unique(idx).size   # the half-tile's union
+    assert np.array_equal(got["status"].ravel(), st)
+    ok = st == 0
+    assert ok.sum() >= 32 and np.all(kk[kk > 0] == 148)
+    assert np.array_equal(got["norm_tmin"].reshape(12, -1)[:, ok], norms[ok].T.astype(np.float32))
+    assert np.array_equal(got["se_tmin"].reshape(12, -1)[:, ok], se[ok].T.astype(np.float32))
+
+
 def test_dense_stations_large_tile_unions(golden_case, orc):
     """k_tile_dist's second path: a tile whose cells krige with more than 256 distinct stations does not fit the LDS pair
     table and evaluates the distance formula per element instead.  30 000 stations around the 100 x 100 grid (1.4 per

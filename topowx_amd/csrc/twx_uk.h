@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void k_cell_dist64(StnDev st, SelWs ws)
 // neighbourhoods of a tile's cells draw on the same ~200 stations, so the pair distances of that UNION are evaluated
 // once per tile into an LDS table (lower triangle, fp32, <= TWX_TD_U stations: 129 KB of gfx950's 160 KB) and every
 // cell's rank-ordered blocks are gathered from it: ~15 x fewer evaluations of the distance formula than per cell.
-// A tile whose union is larger evaluates the formula per element from the union's trigonometry staged in the same
-// LDS space.  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
+// A tile whose union is larger evaluates the formula per element, every wave from the trigonometry of its own cell's
+// neighbours staged in a slice of the same LDS space (any union size: the candidate list bounds it at 4 096).  Same values as k_cell_dist (the formula is symmetric in its two points up to the order of two products).
 // ---------------------------------------------------------------------------------
 #ifndef TWX_TD_U
 #define TWX_TD_U 256
@@ -368,8 +368,7 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
         for (int r = lane; r < kmax; r += 64) s_slot[ws.near_pos[lc * ws.ksel + r]] = 1;
     }
     __syncthreads();
-    // (2) number them in list order, (3) stage their trigonometry (beside the table, or in its place when the union is
-    //     too large for one: the space holds 3 289 stations)
+    // (2) number them in list order, (3) stage their trigonometry beside the table (when the union fits one)
     for (int p0 = 0; p0 < ncand; p0 += NTH) {
         const int p = p0 + t;
         const bool f = p < ncand && s_slot[p] != 0;
@@ -387,8 +386,11 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
     const int nu = s_base;
     if (nu == 0) return;
     const bool table = nu <= TWX_TD_U;
-    double *trig = table ? s_trig : reinterpret_cast<double *>(s_T);
-    for (int p = t; p < ncand; p += NTH) {
+    // without a table every wave stages the trigonometry of ITS cell's neighbours, by rank, in a slice of the table's space
+    // (a union of the whole part has no bound that fits: up to TWX_CAND_MAX stations)
+    static_assert(sizeof(s_T) >= (size_t)TWX_TD_WAVES * TWX_KSEL_MAX * 5 * sizeof(double), "per-wave trigonometry does not fit the table's space");
+    double *trig = table ? s_trig : reinterpret_cast<double *>(s_T) + (size_t)wv * (TWX_KSEL_MAX * 5);
+    for (int p = t; table && p < ncand; p += NTH) {
         const int u = (int)s_slot[p] - 1;
         if (u >= 0) {
             const int j = ws.cand[tl * ws.cmax + p];
@@ -419,38 +421,56 @@ __global__ __launch_bounds__(64 * TWX_TD_WAVES) void k_tile_dist(StnDev st, Cell
         const double *ct = ws.ctrig + lc * 4;
         const double ccph = fma(ct[1], ct[1], -(ct[0] * ct[0]));
         for (int r = lane; r < kmax; r += 64) {
-            const int u = (int)s_slot[ws.near_pos[lc * ws.ksel + r]] - 1;
+            const int u = table ? (int)s_slot[ws.near_pos[lc * ws.ksel + r]] - 1 : r;
             ur[r] = (uint16_t)u;
-            const double *bq = &trig[u * 5];
+            double *bq = &trig[u * 5];
+            if (!table) {
+                const int j = ws.near_idx[lc * ws.ksel + r];
+                const double sp = st.sph[j], cp = st.cph[j];
+                bq[0] = sp; bq[1] = cp; bq[2] = st.slh[j]; bq[3] = st.clh[j]; bq[4] = fma(cp, cp, -(sp * sp));
+            }
             ws.h0[lc * ws.ksel + r] = ellip_pair_fast(ct[0], ct[1], ct[2], ct[3], ccph, bq[0], bq[1], bq[2], bq[3], bq[4]);
         }
         __builtin_amdgcn_wave_barrier();
         const int nbk = max((kmax + 15) >> 4, 2);            // (two block rows at least: see k_cell_dist)
         float *out = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256);
-        const int tr = lane & 15, tq = lane >> 4;            // element e = 64 q + lane of a block: row tr, column 4 q + tq
+        // a lane takes the elements e = 4 lane .. 4 lane + 3 of a block (element order [column][row]: column lane / 4, rows
+        // 4 (lane % 4) ..): ONE 16-byte store per lane and block instead of four 4-byte ones (the kernel is bound by these writes)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const int tc = lane >> 2, r4 = 4 * (lane & 3);
         for (int a = 0; a < nbk; ++a) {
-            const int i = 16 * a + tr;
-            const bool iv = i < kmax;
-            const int ui = iv ? ur[i] : 0, ti = ui * (ui + 1) / 2;
-            const double *pa = &trig[ui * 5];
+            int ui[4], ti[4];
+            bool iv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * a + r4 + q;
+                iv[q] = i < kmax;
+                ui[q] = iv[q] ? ur[i] : 0;
+                ti[q] = ui[q] * (ui[q] + 1) / 2;
+            }
             for (int b = 0; b <= a; ++b) {
-                float *ob = out + (a * (a + 1) / 2 + b) * 256 + lane;
+                const int j = 16 * b + tc;
+                const bool jv = j < kmax;
+                const int uj = jv ? ur[j] : 0, tj = uj * (uj + 1) / 2;
+                const double *pb = &trig[uj * 5];
+                f4v hv;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int j = 16 * b + 4 * q + tq;
+                    const int i = 16 * a + r4 + q;
                     float h = 1.f;                           // diagonal / outside the neighbourhood: any h > 0 (masked by the build)
-                    if (iv && j < kmax && i != j) {
-                        const int uj = ur[j];
-                        if (table) h = s_T[ui > uj ? ti + uj : uj * (uj + 1) / 2 + ui];
+                    if (iv[q] && jv && i != j) {
+                        if (table) h = s_T[ui[q] > uj ? ti[q] + uj : tj + ui[q]];
                         else {
-                            const double *pb = &trig[uj * 5];
+                            const double *pa = &trig[ui[q] * 5];
                             h = ellip_pair_fast(pa[0], pa[1], pa[2], pa[3], pa[4], pb[0], pb[1], pb[2], pb[3], pb[4]);
                         }
                         // coincident neighbours: see k_cell_dist
                         if (h == 0.f) { atomicMin(&s_dup[wv], max(i, j)); h = 1e-30f; }
                     }
-                    __builtin_nontemporal_store(h, &ob[64 * q]);   // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
+                    hv[q] = h;
                 }
+                // streamed: 2.2 GB per C2 step that no L2 can hold (-1.3 % kriging time)
+                __builtin_nontemporal_store(hv, reinterpret_cast<f4v *>(out + (a * (a + 1) / 2 + b) * 256 + 4 * lane));
             }
         }
         __builtin_amdgcn_wave_barrier();
