@@ -40,6 +40,41 @@ def test_knn_matches_reference_station_select(env, golden):
             np.testing.assert_allclose(wgt, golden["sel_wgt"][sel][:, :k], rtol=1e-10, atol=1e-12)
 
 
+def test_knn_ties_rank_in_table_order(golden_case, orc):
+    """Equal distances (co-located stations: step20 removes exact duplicates of ID, not of place) rank in table order,
+    as the oracle's selection does, wherever the tie falls -- inside the neighbourhood, on its last rank, across it.
+    k_select ranks by counting the strictly nearer candidates and ranks again, ties in list order, only when that
+    leaves a hole; every k from 3 to 60 moves the boundary across the triplets of this table."""
+    from topowx_amd import _lib, stationdb as sdb
+    grid, tmin, _ = golden_case
+    stns = tmin.stns.copy()
+    rng = np.random.default_rng(4)
+    src = rng.choice(stns.size, 60, replace=False)
+    for a in src[:40]:                                        # 40 twins and 20 triplets, scattered over the table
+        b = (a + 1 + rng.integers(0, stns.size - 1)) % stns.size
+        stns[sdb.LON][b], stns[sdb.LAT][b] = stns[sdb.LON][a], stns[sdb.LAT][a]
+    for a in src[40:]:
+        for _ in range(2):
+            b = (a + 1 + rng.integers(0, stns.size - 1)) % stns.size
+            stns[sdb.LON][b], stns[sdb.LAT][b] = stns[sdb.LON][a], stns[sdb.LAT][a]
+    db = sdb.StationDataWrkChk(stns, "tmin", tmin.days, None)
+    odb = orc.Db(db)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, db, with_obs=False)
+    cells = np.argwhere(np.asarray(grid["mask"]) != 0)[::151][:24]
+    lon, lat = np.asarray(grid["lon"])[cells[:, 1]], np.asarray(grid["lat"])[cells[:, 0]]
+    ties = 0
+    for k in range(3, 61):
+        idx, dist, _, st = ctx.knn(_lib.TMIN, lon, lat, k)
+        assert np.all(st == 0)
+        for i in range(len(cells)):
+            rc, want, _, _ = orc.select(odb, lat[i], lon[i], k)
+            assert rc == 0 and np.array_equal(idx[i], want), (k, i, idx[i], want)
+            ties += int(np.any(np.diff(dist[i]) == 0.0))
+    ctx.close()
+    assert ties >= 30, ties
+
+
 def test_krig_points_golden(env, golden):
     ctx, lib, grid = env["ctx"], env["lib"], env["grid"]
     pts = _pts(ctx, grid, golden["kr_cell"], "tmin")

@@ -378,17 +378,34 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
         m += __popcll(mask);
     }
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
+    // Equal distances are rare: the first pass counts only the strictly smaller ones (one compare + one add per pair).
+    // Candidates that tie then share a rank and leave the next one empty -- a hole among the ranks 0 .. ksel (one past
+    // the last rank kept, so that a tie across that boundary shows too) -- and only then the wave ranks again, ties in
+    // list order.
+    static_assert(TWX_MAX_NNGHS + 1 < TWX_KSEL_MAX, "the rank past the kept ones needs a slot (ksel <= TWX_MAX_NNGHS + 1, pick_ksel)");
     for (int p = lane; p < m; p += 64) {
         const double dj = sd[p];
-        int rank = 0, eq = 0;                                // two compares + two adds per pair; equal distances are rare
-        for (int i = 0; i < m; ++i) {
-            const double di = sd[i];
-            rank += di < dj;
-            eq += di == dj;
+        int rank = 0;
+        for (int i = 0; i < m; ++i) rank += sd[i] < dj;
+        if (rank <= ws.ksel && rank < TWX_KSEL_MAX) snp[rank] = p;
+    }
+    __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
+    {
+        bool hole = false;
+        for (int r = lane; r <= ws.ksel && r < m && r < TWX_KSEL_MAX; r += 64) hole = hole || snp[r] < 0;
+        if (__ballot(hole)) {                                // (wave-uniform)
+            for (int r = lane; r < TWX_KSEL_MAX; r += 64) snp[r] = -1;
+            __builtin_amdgcn_wave_barrier();
+            for (int p = lane; p < m; p += 64) {
+                const double dj = sd[p];
+                int rank = 0;
+                for (int i = 0; i < m; ++i) {
+                    const double di = sd[i];
+                    rank += (di < dj) || (di == dj && i < p);
+                }
+                if (rank < ws.ksel) snp[rank] = p;
+            }
         }
-        if (eq > 1)                                          // (its own entry is one): ties rank in list order
-            for (int i = 0; i < p; ++i) rank += sd[i] == dj;
-        if (rank < ws.ksel) snp[rank] = p;
     }
     __builtin_amdgcn_wave_barrier();                         // (each wave works on its own cell and LDS region: LDS operations of a wave execute in order)
     const int nnear = min(nv, ws.ksel);
