@@ -82,7 +82,8 @@ def parse():
     ap.add_argument("--nstns", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-daily", action="store_true", help="skip the daily (cell-days) record")
-    ap.add_argument("--daily-years", type=int, default=10, help="years of days of the daily record (1981-...)")
+    ap.add_argument("--daily-years", type=int, default=10, help="years of days of the daily record (from --daily-year0)")
+    ap.add_argument("--daily-year0", type=int, default=1981, help="first year of the daily record's axis (configs[3]'s own axis: 1948 with --daily-years 69)")
     ap.add_argument("--stream-tiles", type=int, default=4, help="tiles of the streamed (PCIe-inclusive) daily record; 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the all-core CPU sample window (0 = auto)")
     ap.add_argument("--int16-window", type=int, default=24, help="edge of the cell window whose packed int16 days are compared with the oracle")
@@ -873,8 +874,9 @@ def main():
     import datetime as dt
     # ---- daily record: the path that produces cell-DAYS (N = 1) --------------------------------------
     if world == 1 and not args.no_daily:
-        res["daily"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(1981, 1, 1),
-                                    dt.date(1980 + args.daily_years, 12, 31), "C2 tile, %d years" % args.daily_years,
+        res["daily"] = daily_record(env, args, base, grid, g, d_ninv, d_stat, dt.date(args.daily_year0, 1, 1),
+                                    dt.date(args.daily_year0 + args.daily_years - 1, 12, 31),
+                                    "C2 tile, %d years from %d" % (args.daily_years, args.daily_year0),
                                     args.steps, args.warmup, args.stream_tiles, args.int16_window,
                                     daily_traffic if args.daily_years == 10 else None, traffic_src)
 

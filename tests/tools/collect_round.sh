@@ -10,7 +10,7 @@ NEWEST=$(ls profiles/r*_c4_daily_traffic.json 2>/dev/null | sort | tail -1)
 [ -n "${TWX_ROUND_TAG:-}" ] && NEWEST=profiles/${TWX_ROUND_TAG}_c4_daily_traffic.json      # (see collect_profiles.sh)
 [ -n "$NEWEST" ] && cp gpurun_out/prof_c4/c4_daily_traffic.json $NEWEST
 bash tests/tools/collect_profiles.sh > gpurun_out/collect_profiles.log 2>&1
-python3 bench.py --steps 6 --warmup 2 --daily-years 69 --stream-tiles 4 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/prof_round/c4_stream_daily.json
+python3 bench.py --steps 6 --warmup 2 --daily-years 69 --daily-year0 1948 --stream-tiles 4 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > gpurun_out/prof_round/c4_stream_daily.json
 bash tests/tools/collect_sq.sh sq_krig > /dev/null 2>&1
 TWX_SQ_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-configs --stream-tiles 0" bash tests/tools/collect_sq.sh sq_daily > /dev/null 2>&1
 python3 -m topowx_amd.xval --db c5 --nstns 12000 --years 3 > gpurun_out/prof_round/xval_c5.json 2> gpurun_out/xval.err
