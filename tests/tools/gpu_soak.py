@@ -1,7 +1,9 @@
 """Soak: seeded random small cases through the whole grid path (normals + daily + fixer), GPU against the CPU oracle.
 Every case draws its own grid extent and shape (not multiples of the 8-cell tiles), mask, station count, nugget scale
 (down to values that route systems to the fp64 covariance build), close station pairs, Tmax offset (days with
-tmin >= tmax for the fixer), batch size and flags; some cases have too few stations or NaN predictors (failure statuses).  Not part of the test suite (minutes of oracle time): run on the GPU
+tmin >= tmax for the fixer), batch size and flags; some cases have too few stations or NaN predictors (failure statuses).
+A cell whose ninvalid differs because a day's tmax - tmin is within 2e-5 degC of 0 on the oracle's side (the fixer's test is
+discontinuous there) is reported as a near tie and set aside.  Not part of the test suite (minutes of oracle time): run on the GPU
 box after kernel changes.   python3 tests/tools/gpu_soak.py [n_cases] [first_seed]  ->  gpurun_out/soak.json"""
 import datetime as dt
 import json
@@ -105,6 +107,30 @@ for seed in range(seed0, seed0 + ncase):
     rec["failed_cells"] = int((got["status"] > 0).sum())
     rec["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"], want["ninvalid"]))
     rec["ninvalid_max"] = int(want["ninvalid"][want["status"] == 0].max()) if (want["status"] == 0).any() else 0
+    if not rec["ninvalid_equal"] and len(which) == 2:
+        # the fixer's test is tmin >= tmax on two interpolated fp64 series: how close to a tie is the nearest day of the cells
+        # that disagree?  (a tie broken the other way moves that day and its 15-day tails: a discontinuity of the algorithm,
+        # not an error of either side)
+        rr, cc = np.nonzero((got["ninvalid"] != want["ninvalid"]) & ok)
+        margins = []
+        odn, odx, prm = orc.Db(dbs[0]), orc.Db(dbs[1]), orc.params()
+        for r, c in list(zip(rr, cc))[:64]:
+            ptn = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_night"][:, r, c])
+            ptx = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_day"][:, r, c])
+            _, dn, _, _ = orc.interp(odn, prm, ptn)
+            _, dx, _, _ = orc.interp(odx, prm, ptx)
+            gap = dx - dn
+            margins.append({"cell": [int(r), int(c)], "ninvalid_gpu": int(got["ninvalid"][r, c]), "ninvalid_oracle": int(want["ninvalid"][r, c]),
+                            "oracle_days_tmin_ge_tmax": int((gap <= 0).sum()), "smallest_abs_gap_degC": float(np.abs(gap).min())})
+        rec["ninvalid_mismatch_cells"] = int(rr.size)
+        rec["ninvalid_mismatch_margins"] = margins
+        # near ties (a gap below 2e-5 degC, the size of the two sides' agreement on a daily value): those cells are set
+        # aside, everything else is compared as usual
+        if rr.size <= 64 and all(m["smallest_abs_gap_degC"] < 2e-5 for m in margins):
+            rec["near_tie_cells"] = int(rr.size)
+            ok = ok.copy()
+            ok[rr, cc] = False
+            rec["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"][ok], want["ninvalid"][ok]))
     rec["f64_solves"] = int(tim.get("uk_f64_solves", -1)) if isinstance(tim, dict) else int(getattr(tim, "uk_f64_solves", -1))
     for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
         d = np.abs(got[k].astype(np.float64) - want[k])[:, ok] if k in got else np.zeros(0)
