@@ -106,7 +106,7 @@ typedef struct {
  * inputs of interp.R:223-231,256 (nugget = min gamma, interp.R:304-359) and amplify the fp32 rounding of an entry
  * beyond the 1e-4 degC parity bar (measured: tests/test_gpu_closepairs.py). */
 #define TWX_FLAG_UK_FAST_ONLY 8
-/* kriging: EVERY system on the fp64 covariance build (2.1 x the kriging time): the normals then agree with an fp64
+/* kriging: EVERY system on the fp64 covariance build (2.2-2.3 x the kriging time): the normals then agree with an fp64
  * evaluation of the reference's formulas to ~1e-11 degC instead of ~1e-6 (one ulp of the f4 outputs), and the 2e-5 of
  * the packed int16 daily values that sit within that 1e-6 of a rounding boundary stop flipping by one count
  * (tests/test_gpu_closepairs.py).  For comparisons against other fp64 implementations; not needed for the 1e-4 degC bar. */

@@ -208,6 +208,12 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
     if (nb > TWX_VBINS) nb = TWX_VBINS;
     for (int b = t; b < TWX_VBINS; b += 256) { s_sh[b] = 0.0; s_sg[b] = 0.0; s_sn[b] = 0.0; }
     __syncthreads();
+    // Bins per WAVE when a quarter of the space holds them (cutoff <= 635 km: every neighbourhood of the path): the atomics of
+    // one wave are applied in program order and, within an instruction, in the LDS unit's fixed lane order, and the four
+    // partial sums are added in a fixed order afterwards -- the same bits run after run (shared bins took the waves' additions in
+    // whatever order they arrived: fits differed in the last bits between two runs), and a quarter of the collisions.
+    const int bo_step = nb <= TWX_VBINS / 4 ? TWX_VBINS / 4 : 0;
+    const int bo = bo_step * (t >> 6);
     const int npair = k * (k - 1) / 2;
     const double *gd = ws.gd64 + (int64_t)(src.ptile ? src.ptile[c] : c) * (int64_t)(ws.ksel * (ws.ksel - 1) / 2);
     // pair p = i (i - 1) / 2 + j, j < i: decoded once, then stepped (256 pairs ahead is at most a few rows down: k <= 152)
@@ -223,10 +229,18 @@ __global__ __launch_bounds__(256) void k_vario(StnDev st, CellSrc src, SelWs ws)
             if (b > 0 && h == b * width) --b;
             if (b >= nb) b = nb - 1;
             const double d = s_e[i] - s_e[j];
-            atomicAdd(&s_sh[b], h); atomicAdd(&s_sg[b], d * d); atomicAdd(&s_sn[b], 1.0);
+            atomicAdd(&s_sh[bo + b], h); atomicAdd(&s_sg[bo + b], d * d); atomicAdd(&s_sn[bo + b], 1.0);
         }
     }
     __syncthreads();
+    if (bo_step) {                                           // the four waves' bins, in a fixed order
+        for (int b = t; b < nb; b += 256) {
+            s_sh[b] = (s_sh[b] + s_sh[bo_step + b]) + (s_sh[2 * bo_step + b] + s_sh[3 * bo_step + b]);
+            s_sg[b] = (s_sg[b] + s_sg[bo_step + b]) + (s_sg[2 * bo_step + b] + s_sg[3 * bo_step + b]);
+            s_sn[b] = (s_sn[b] + s_sn[bo_step + b]) + (s_sn[2 * bo_step + b] + s_sn[3 * bo_step + b]);
+        }
+        __syncthreads();
+    }
 
     // ---- constrained fit by wave 0 (bins over lanes); Gauss-Newton with step halving ----------------------
     if (t < 64) {
