@@ -1,7 +1,9 @@
 """Every cell of the C2 tile (BASELINE.json configs[1]: 250 x 250 cells, 10 000 stations per variable), normals + SE of
 both variables, GPU against the CPU oracle -- the full-size check the suite samples (the oracle needs ~1 minute on the GPU
 box's host cores).  With --daily: three years of daily values of both variables with a lowered Tmax (fixer), every cell.
-python3 tests/tools/gpu_full_tile_parity.py [--daily] [--f64]  ->  gpurun_out/full_tile_parity[_daily].json"""
+--years N --year0 Y: the day axis of the daily run (default 3 years from 1981; 69 from 1948 = configs[3]'s 25 203 days:
+3.15e9 packed values per tile, ~15 GB of host memory, ~5 minutes of oracle time on 256 threads).
+python3 tests/tools/gpu_full_tile_parity.py [--daily [--years N --year0 Y]] [--f64]  ->  gpurun_out/full_tile_parity[_daily][_Ny].json"""
 import json
 import os
 import sys
@@ -20,7 +22,9 @@ if daily:
     import datetime as dt
     from topowx_amd import stationdb as sdb
     from topowx_amd.dates import get_days_metadata
-    days = get_days_metadata(dt.date(1981, 1, 1), dt.date(1983, 12, 31))
+    nyears = int(sys.argv[sys.argv.index("--years") + 1]) if "--years" in sys.argv else 3
+    year0 = int(sys.argv[sys.argv.index("--year0") + 1]) if "--year0" in sys.argv else 1981
+    days = get_days_metadata(dt.date(year0, 1, 1), dt.date(year0 + nyears - 1, 12, 31))
     grid, tmin, tmax = synth.make_case("C2", with_obs=True, days=days)
     stns = tmax.stns.copy()
     for m in range(1, 13):
@@ -39,19 +43,50 @@ ctx.close()
 want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, daily=daily, nthreads=min(256, os.cpu_count() or 8))
 t2 = time.perf_counter()
 ok = want["status"] == 0
+near = None
+if daily and not np.array_equal(got["ninvalid"], want["ninvalid"]):
+    # tmin_tmax_fixer tests tmin >= tmax on two interpolated fp64 series (interp_tair.py:1109-1157): a day whose gap is
+    # within the two sides' agreement (~1e-6 degC) can fall on either side, and then that day and its 15-day tails differ.
+    # Cells whose ninvalid differs are examined -- the oracle's unfixed series, the smallest |tmax - tmin| -- and those
+    # below 2e-5 degC are set aside as near ties (reported), everything else is compared as usual.
+    rr, cc = np.nonzero((got["ninvalid"] != want["ninvalid"]) & ok)
+    odn, odx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
+    gaps = []
+    for r, c in zip(rr, cc):
+        ptn = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_night"][:, r, c])
+        ptx = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_day"][:, r, c])
+        gaps.append(float(np.abs(orc.interp(odx, prm, ptx)[1] - orc.interp(odn, prm, ptn)[1]).min()))
+    gaps = np.array(gaps)
+    tie = gaps < 2e-5
+    near = {"cells_with_other_ninvalid": int(rr.size), "of_them_near_ties": int(tie.sum()),
+            "largest_smallest_gap_degC_among_near_ties": float(gaps[tie].max()) if tie.any() else None,
+            "smallest_gaps_of_the_others": [float(g) for g in gaps[~tie][:20]],
+            "ninvalid_difference_max": int(np.abs(got["ninvalid"][rr, cc] - want["ninvalid"][rr, cc]).max())}
+    ok = ok.copy()
+    ok[rr[tie], cc[tie]] = False
 res = {"flags": "TWX_FLAG_UK_F64_ALL" if f64 else "default", "cells": int(grid["mask"].size), "cells_ok": int(ok.sum()), "status_equal": bool(np.array_equal(got["status"], want["status"])),
        "gpu_s_incl_transfers": round(t1 - t0, 3), "oracle_s": round(t2 - t1, 1)}
 for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
     d = np.abs(got[k].astype(np.float64) - want[k])[:, ok]
     res[k] = {"max_abs_degC": float(d.max()), "p99.9": float(np.quantile(d, 0.999)), "bit_equal_f4_frac": float((d == 0).mean())}
 if daily:
-    res["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"], want["ninvalid"]))
+    res["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"][ok], want["ninvalid"][ok]))   # (near ties set aside)
+    if near:
+        res["fixer_near_ties"] = near
     res["cells_with_invalid_days"] = int((want["ninvalid"][ok] > 0).sum())
     res["ninvalid_max"] = int(want["ninvalid"][ok].max())
+    res["days"] = int(days.size)
+    res["day_axis"] = "%d-01-01 .. %d-12-31" % (year0, year0 + nyears - 1)
     for k in ("daily_tmin", "daily_tmax"):
-        neq = (got[k] != want[k])[:, ok]
-        d = np.abs(got[k].astype(np.int32) - want[k].astype(np.int32))[:, ok]
-        res[k] = {"values": int(neq.size), "differ": int(neq.sum()), "flip_rate": float(neq.mean()), "max_diff_LSB": int(d.max())}
+        nval = ndiff = mx = 0
+        for d0 in range(0, got[k].shape[0], 512):             # in blocks of days: the full axis is 3 GB per array
+            a, b = got[k][d0:d0 + 512][:, ok], want[k][d0:d0 + 512][:, ok]
+            neq = a != b
+            nval += int(neq.size); ndiff += int(neq.sum())
+            if neq.any():
+                mx = max(mx, int(np.abs(a[neq].astype(np.int32) - b[neq].astype(np.int32)).max()))
+        res[k] = {"values": nval, "differ": ndiff, "flip_rate": ndiff / max(nval, 1), "max_diff_LSB": mx}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", ("full_tile_parity_daily" if daily else "full_tile_parity") + ("_f64.json" if f64 else ".json")), "w"), indent=1)
+tag = ("full_tile_parity_daily" + ("_%dy" % nyears if nyears != 3 else "")) if daily else "full_tile_parity"
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", tag + ("_f64.json" if f64 else ".json")), "w"), indent=1)
 print(json.dumps(res))
