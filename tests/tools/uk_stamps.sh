@@ -4,6 +4,6 @@
 set -e
 mkdir -p gpurun_out
 ./build.sh -DTWX_UK_STAMP
-python3 bench.py --steps 1 --warmup 1 --no-daily --no-cpu-baseline > /dev/null
+python3 bench.py --steps 1 --warmup 1 --no-daily --no-cpu-baseline --no-configs > /dev/null
 python3 tests/tools/uk_stamps.py gpurun_out/uk_stamps.bin
 ./build.sh
