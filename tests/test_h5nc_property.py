@@ -42,7 +42,7 @@ def cases(draw):
     return shape, dtype, zlib, draw(st.booleans()), chunk, fill, writes
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(case=cases())
 def test_hyperslab_round_trips(tmp_path, case):
     shape, dtype, zlib, shuffle, chunk, fill, writes = case
@@ -87,7 +87,7 @@ def test_hyperslab_round_trips(tmp_path, case):
     ro.close()
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(words=st.lists(st.text(alphabet=st.characters(min_codepoint=32, max_codepoint=0x24F), max_size=12), min_size=1, max_size=9),
        width=st.integers(1, 16))
 def test_string_variables_round_trip(tmp_path, words, width):
