@@ -17,6 +17,7 @@ from oracle import pyoracle as orc  # noqa: E402
 from topowx_amd import _lib, synth  # noqa: E402
 
 orc.build()
+WIN = None                                                    # (rows, cols) window of the grid, or the whole grid
 daily = "--daily" in sys.argv
 if daily:
     import datetime as dt
@@ -25,7 +26,14 @@ if daily:
     nyears = int(sys.argv[sys.argv.index("--years") + 1]) if "--years" in sys.argv else 3
     year0 = int(sys.argv[sys.argv.index("--year0") + 1]) if "--year0" in sys.argv else 1981
     days = get_days_metadata(dt.date(year0, 1, 1), dt.date(year0 + nyears - 1, 12, 31))
-    grid, tmin, tmax = synth.make_case("C2", with_obs=True, days=days)
+    if "--c3" in sys.argv:                                      # a 250 x 250 tile of the FULL configs[2..3] grid, 12 000-station seed-2 tables
+        r0, c0 = int(sys.argv[sys.argv.index("--c3") + 1]), int(sys.argv[sys.argv.index("--c3") + 2])
+        grid = synth.make_grid("C3")
+        tmin = synth.make_stations(grid["bbox"], 12000, 2, "tmin", days, with_obs=True)
+        tmax = synth.make_stations(grid["bbox"], 12000, 2, "tmax", days, with_obs=True)
+        WIN = (slice(r0, r0 + 250), slice(c0, c0 + 250))
+    else:
+        grid, tmin, tmax = synth.make_case("C2", with_obs=True, days=days)
     stns = tmax.stns.copy()
     for m in range(1, 13):
         stns[sdb.get_norm_varname(m)] -= 7.5                     # a few per cent of the days with tmin >= tmax
@@ -37,10 +45,11 @@ ctx = _lib.Context(flags=_lib.FLAG_UK_F64_ALL if f64 else 0)
 ctx.set_stations(_lib.TMIN, tmin, with_obs=daily)
 ctx.set_stations(_lib.TMAX, tmax, with_obs=daily)
 t0 = time.perf_counter()
-got = ctx.interp_grid(grid, daily=daily)
+kw = {} if WIN is None else {"rows": WIN[0], "cols": WIN[1]}
+got = ctx.interp_grid(grid, daily=daily, **kw)
 t1 = time.perf_counter()
 ctx.close()
-want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, daily=daily, nthreads=min(256, os.cpu_count() or 8))
+want = orc.interp_grid(orc.Db(tmin), orc.Db(tmax), orc.params(), grid, daily=daily, nthreads=min(256, os.cpu_count() or 8), **kw)
 t2 = time.perf_counter()
 ok = want["status"] == 0
 near = None
@@ -52,7 +61,8 @@ if daily and not np.array_equal(got["ninvalid"], want["ninvalid"]):
     rr, cc = np.nonzero((got["ninvalid"] != want["ninvalid"]) & ok)
     odn, odx, prm = orc.Db(tmin), orc.Db(tmax), orc.params()
     gaps = []
-    for r, c in zip(rr, cc):
+    ro, co = (WIN[0].start, WIN[1].start) if WIN else (0, 0)
+    for r, c in zip(rr + ro, cc + co):
         ptn = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_night"][:, r, c])
         ptx = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_day"][:, r, c])
         gaps.append(float(np.abs(orc.interp(odx, prm, ptx)[1] - orc.interp(odn, prm, ptn)[1]).min()))
@@ -64,7 +74,8 @@ if daily and not np.array_equal(got["ninvalid"], want["ninvalid"]):
             "ninvalid_difference_max": int(np.abs(got["ninvalid"][rr, cc] - want["ninvalid"][rr, cc]).max())}
     ok = ok.copy()
     ok[rr[tie], cc[tie]] = False
-res = {"flags": "TWX_FLAG_UK_F64_ALL" if f64 else "default", "cells": int(grid["mask"].size), "cells_ok": int(ok.sum()), "status_equal": bool(np.array_equal(got["status"], want["status"])),
+res = {"flags": "TWX_FLAG_UK_F64_ALL" if f64 else "default", "grid": "C2 tile" if WIN is None else "C3 grid, tile at row %d col %d, 12 000 stations" % (WIN[0].start, WIN[1].start),
+       "cells": int(want["status"].size), "cells_ok": int(ok.sum()), "status_equal": bool(np.array_equal(got["status"], want["status"])),
        "gpu_s_incl_transfers": round(t1 - t0, 3), "oracle_s": round(t2 - t1, 1)}
 for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
     d = np.abs(got[k].astype(np.float64) - want[k])[:, ok]
@@ -88,5 +99,7 @@ if daily:
         res[k] = {"values": nval, "differ": ndiff, "flip_rate": ndiff / max(nval, 1), "max_diff_LSB": mx}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 tag = ("full_tile_parity_daily" + ("_%dy" % nyears if nyears != 3 else "")) if daily else "full_tile_parity"
+if WIN is not None:
+    tag += "_c3"
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", tag + ("_f64.json" if f64 else ".json")), "w"), indent=1)
 print(json.dumps(res))
