@@ -283,19 +283,6 @@ void launch_uk(const int32_t *cnt, const StnDev &st, const CellSrc &src, const S
 #endif
 }
 
-// k_ukz<NB, 2>: border as columns on two waves (k in the upper half of a block row: 105..112, 121..128) -- only in a
-// TWX_UKZ = 1 build (twx_select.h: measured slower, kept reproducible: ./build.sh -DTWX_UKZ=1 + tests/tools/ab_bench.sh)
-template <int NB, int PREC = 0>
-void launch_ukz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
-{
-#if TWX_UKZ
-    const int32_t *cells = ws.bucket_cells + (int64_t)bucket * ws.ncell * 12;
-    if (cnt && cnt[bucket] <= 0) return;
-    const unsigned grid = krig_grid(cnt, bucket, max_items);
-    hipLaunchKernelGGL((k_ukz<NB, 2, PREC>), dim3(grid), dim3(128), 0, s, st, src, ws, cells, ws.bucket_cnt + bucket);
-#endif
-}
-
 template <int NBR, int PREC = 0>
 void launch_ukwz(const int32_t *cnt, const StnDev &st, const CellSrc &src, const SelWs &ws, int bucket, int64_t max_items, hipStream_t s)
 {
@@ -381,10 +368,8 @@ int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int kse
         launch_ukw<5>(cnt, st, src, w.ws, 4, mi, stream);    // 64 < k <= 72
         launch_ukwz<5>(cnt, st, src, w.ws, 5, mi, stream);      // 72 < k <= 80
         launch_uk<7>(cnt, st, src, w.ws, 8, mi, stream);        // 96 < k <= 104
-        launch_ukz<7>(cnt, st, src, w.ws, 9, mi, stream);       // 104 < k <= 112  (border as columns)
-        launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);       // 112 < k <= 120  (104 < k without TWX_UKZ)
-        launch_ukz<8>(cnt, st, src, w.ws, 11, mi, stream);      // 120 < k <= 128  (border as columns)
-        launch_uk<9>(cnt, st, src, w.ws, 12, mi, stream);       // 128 < k <= 136  (120 < k without TWX_UKZ)
+        launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);       // 104 < k <= 120
+        launch_uk<9>(cnt, st, src, w.ws, 12, mi, stream);       // 120 < k <= 136
         launch_uk<10>(cnt, st, src, w.ws, 13, mi, stream);      // 136 < k <= 152
         constexpr int F = TWX_BUCKET_F64;
         if (w.ws.dist64) {       // ill-conditioned systems (uk_needs_f64): the fp64 covariance build of their own matrix size,
@@ -402,9 +387,7 @@ int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int kse
             launch_ukw<6, 1>(cnt, st, src, w.ws, F + 6, mi, stream);
             launch_ukwz<6, 1>(cnt, st, src, w.ws, F + 7, mi, stream);
             launch_uk<7, 1>(cnt, st, src, w.ws, F + 8, mi, stream);
-            launch_ukz<7, 1>(cnt, st, src, w.ws, F + 9, mi, stream);
             launch_uk<8, 1>(cnt, st, src, w.ws, F + 10, mi, stream);
-            launch_ukz<8, 1>(cnt, st, src, w.ws, F + 11, mi, stream);
             launch_uk<9, 1>(cnt, st, src, w.ws, F + 12, mi, stream);
             launch_uk<10, 1>(cnt, st, src, w.ws, F + 13, mi, stream);
         } else if (!cnt) {       // TWX_FLAG_NO_HOST_SYNC: no host decision possible, per-element distances, two worst-case sizes

@@ -724,21 +724,13 @@ __global__ __launch_bounds__(64 * WPB) void k_select(StnDev st, CellSrc src, Sel
 #define TWX_NBUCKET (2 * TWX_NFAST)
 #define TWX_BUCKET_F64 TWX_NFAST                              // fp64-build buckets: TWX_BUCKET_F64 + twx_krig_bucket(k)
 // 0..7: k <= 40, 48, .. 96 (one-wave kernels, twx_ukw.h); 8: <= 104 k_uk<7,2>; 10: <= 120 k_uk<8,4>; 12: <= 136 k_uk<9,2>;
-// 13: <= 152 k_uk<10,2>.  Buckets 9 (105..112) and 11 (121..128) exist only in a TWX_UKZ = 1 build: k_ukz<7 / 8, 2>, the
-// two-wave kernels with the border as columns (twx_uk.h) -- measured SLOWER than the bordered kernel one size up
-// (profiles/README.md, round 5), so the default build leaves those systems where they were.
-#ifndef TWX_UKZ
-#define TWX_UKZ 0
-#endif
+// 13: <= 152 k_uk<10,2>.  Buckets 9 (105..112) and 11 (121..128) stay empty: their two-wave kernels with the border as
+// columns were measured slower than the bordered kernel one size up (tests/tools/experiments/twx_ukz.h).
 __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
 {
     const int e = (k + 7) / 8;                               // eighths: 5 (k <= 40) .. 19 (k <= 152)
     const int b = (e < 5 ? 5 : (e > 19 ? 19 : e)) - 5;      // 0 .. 14
-#if TWX_UKZ
-    return b < 13 ? b : 13;
-#else
     return b < 9 ? b : (b < 11 ? 10 : (b < 13 ? 12 : 13));
-#endif
 }
 
 // Which systems need the fp64 covariance build.  The fast build forms every off-diagonal entry psill exp(-h / range)
