@@ -118,6 +118,20 @@ typedef struct {
  * call.  Both paths give the same fixed days and the same packed int16 values (the window means are summed in day order
  * in both); their recomputed f8 normals can differ in the last bits (tests/test_gpu_parity.py). */
 #define TWX_FLAG_FIX_FULL 32
+/* fixer: switch the TIE GUARD off (a test / diagnostic switch: tests/tools/gpu_full_tile_parity.py measures what it catches).
+ * Default (flag clear), grid entries with both variables and daily output: the fixer's test tmin >= tmax
+ * (interp_tair.py:170) is a discontinuity -- a day whose Tmax - Tmin lies within the fast covariance build's ~1e-6 degC of 0
+ * can fall on the other side of it than in an fp64 evaluation, and then the day moves by degrees, the cell's recomputed
+ * normals by ~0.05 degC and its ninvalid by 1.  So every cell that has a day with |Tmax - Tmin| < 2e-5 degC is kriged a
+ * second time on the fp64 covariance build and its whole series is recomputed from those normals: ninvalid and the fixed
+ * days of every cell are then those of a TWX_FLAG_UK_F64_ALL run.  Costs one subtraction per cell-day plus ~25 us per such
+ * cell (real data: about one cell in 1e5); twx_timing.tie_cells / tie_solves / tie_ms report it.  Not active under
+ * TWX_FLAG_UK_F64_ALL (nothing to guard) and TWX_FLAG_UK_FAST_ONLY (no fp64 build wanted). */
+#define TWX_FLAG_NO_TIE_GUARD 64
+
+/* twx_set_precision modes */
+#define TWX_PRECISION_FAST 0  /* default: fp32 pair distances + v_exp_f32, ill-conditioned systems and tie-guard cells on the fp64 build */
+#define TWX_PRECISION_EXACT 1 /* every kriging system on the fp64 covariance build (= TWX_FLAG_UK_F64_ALL) */
 
 /* Station table of ONE variable (replaces StationSerialDataDb.stns +
  * StationSelect's isnan(bad) mask: station_data.py:126-183,609,
@@ -179,6 +193,10 @@ typedef struct {
     int64_t uk_solves;    /* (cell, month, variable) kriging systems solved */
     int64_t uk_launches;  /* kernel launches of the kriging kernel */
     int64_t uk_f64_solves; /* of uk_solves: ill-conditioned systems that took the fp64 covariance build (TWX_FLAG_UK_FAST_ONLY) */
+    int64_t tie_cells;    /* tie guard (TWX_FLAG_NO_TIE_GUARD): cells with a day of |Tmax - Tmin| < 2e-5 degC, kriged a second time */
+    int64_t tie_solves;   /* ... and their kriging systems (both variables; not counted in uk_solves) */
+    float tie_ms;         /* ... and the device time of that second pass (kriging + epilogues; their fixer time is in fix_ms) */
+    float reserved;
 } twx_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -186,6 +204,13 @@ int twx_create(int device, const twx_params *params, twx_ctx **out);
 void twx_destroy(twx_ctx *ctx);
 const char *twx_last_error(const twx_ctx *ctx);
 const char *twx_version(void);
+
+/* Covariance build of the kriging systems of every later call on this context: TWX_PRECISION_FAST (the default routing, see
+ * TWX_FLAG_UK_FAST_ONLY / TWX_FLAG_NO_TIE_GUARD) or TWX_PRECISION_EXACT (all systems on the fp64 build: what the flag
+ * TWX_FLAG_UK_F64_ALL selects at twx_create).  A run that is bound by its copy-out (daily tiles streamed to the host: the GPU
+ * idles most of the wall) can afford EXACT for nothing -- topowx_amd/driver.py decides per run (precision="auto").
+ * No reference counterpart (the reference is fp64 throughout: interp.R:256). */
+int twx_set_precision(twx_ctx *ctx, int mode);
 
 /* day axis of the observation matrix: replaces StationSerialDataDb.days /
  * mth_idx (station_data.py:570-576) and PtInterpTair's normals masks
@@ -296,6 +321,9 @@ typedef struct twx_stream twx_stream;
 int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslots, twx_stream **out);
 int twx_stream_submit(twx_stream *st, int slot, const twx_grid *grid);
 int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device_ms);
+/* after twx_stream_wait(slot): device time of the tile's kernels and of its copy-out to the pinned block (HIP events on the
+ * stream's compute / copy streams; ms).  What precision="auto" of topowx_amd/driver.py compares. */
+int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms);
 void twx_stream_destroy(twx_stream *st);
 
 /* kernel times of the last grid call (synchronises on its events) */

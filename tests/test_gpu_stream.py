@@ -184,8 +184,23 @@ def test_driver_streamed_tiles_equal_synchronous(golden_case, tmp_path):
     def sink(k, arrays):
         np.savez(str(tmp_path / ("t%d.npz" % k)), **{n: v for n, v in arrays.items() if hasattr(v, "shape")})
         seen.append(k)
-    res, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, tiles, 25, 25, daily=True, sink=sink)
+    log = {}
+    res, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, tiles, 25, 25, daily=True, sink=sink, precision="fast", log=log)
+    assert log["precision"] == "fast" and log["tiles_fast"] == 7 and log["tiles_exact"] == 0 and log["copy_ms_mean"] > 0
+    # "exact": every tile equals a TWX_FLAG_UK_F64_ALL run; the context is handed back in the fast mode
+    exact, _, _ = driver.interp_tiles_streamed(ctx, grid, tiles[:3], 25, 25, daily=True, precision="exact")
+    again = driver.interp_tiles(grid, driver.gpu_compute(ctx, daily=True), tiles[:1], 25, 25)
     ctx.close()
+    ctx64 = _lib.Context(flags=_lib.FLAG_UK_F64_ALL)
+    ctx64.set_stations(_lib.TMIN, tmin)
+    ctx64.set_stations(_lib.TMAX, tmax)
+    want64 = driver.interp_tiles(grid, driver.gpu_compute(ctx64, daily=True), tiles[:3], 25, 25)
+    ctx64.close()
+    for k, _, _, _ in tiles[:3]:
+        for name in want64[k]:
+            assert np.array_equal(exact[k][name], want64[k][name]), (k, name)
+    for name in want[tiles[0][0]]:
+        assert np.array_equal(again[tiles[0][0]][name], want[tiles[0][0]][name]), name
     assert res is None and seen == [t[0] for t in tiles] and dev_ms > 0 and secs > 0
     for k, _, _, _ in tiles:
         got = np.load(str(tmp_path / ("t%d.npz" % k)))

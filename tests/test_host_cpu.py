@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(built.TwxPt) == 8 * 16 == built.PT_DTYPE.itemsize
     assert ctypes.sizeof(built.TwxGrid) == 8 + 8 * 8
     assert ctypes.sizeof(built.TwxGridOut) == 8 * 8
-    assert ctypes.sizeof(built.TwxTiming) == 4 * 7 + 4 + 8 * 4
+    assert ctypes.sizeof(built.TwxTiming) == 4 * 7 + 4 + 8 * 6 + 4 * 2
 
 
 def test_no_gpu_fails_loudly(built):

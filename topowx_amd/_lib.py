@@ -28,6 +28,8 @@ FLAG_DAILY_GATHER = 4
 FLAG_UK_FAST_ONLY = 8     # diagnostic: never use the fp64 covariance build (include/twx.h)
 FLAG_UK_F64_ALL = 16      # every kriging system on the fp64 covariance build (include/twx.h)
 FLAG_FIX_FULL = 32        # diagnostic: the fixer recomputes every flagged cell's whole series (include/twx.h)
+FLAG_NO_TIE_GUARD = 64    # diagnostic: do not re-krige the cells with a day of |Tmax - Tmin| < 2e-5 degC (include/twx.h)
+PRECISION_FAST, PRECISION_EXACT = 0, 1     # twx_set_precision
 
 CELL_STATUS = {0: "ok", 1: "too few stations (IndexError, station_select.py:164)",
                2: "Cannot determine the optimal # of neighbors to use!",
@@ -86,14 +88,16 @@ class TwxTiming(C.Structure):
     _fields_ = [("tile_cand_ms", C.c_float), ("select_ms", C.c_float), ("uk_ms", C.c_float),
                 ("gwr_ms", C.c_float), ("daily_ms", C.c_float), ("fix_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_int64), ("uk_solves", C.c_int64),
-                ("uk_launches", C.c_int64), ("uk_f64_solves", C.c_int64)]
+                ("uk_launches", C.c_int64), ("uk_f64_solves", C.c_int64), ("tie_cells", C.c_int64),
+                ("tie_solves", C.c_int64), ("tie_ms", C.c_float), ("reserved", C.c_float)]
 
 
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
            "twx_knn", "twx_krig_points", "twx_gwr_points", "twx_interp_points", "twx_fix_pair", "twx_pack_i16",
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
            "twx_fit_vario_points", "twx_krigall_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
-           "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy")
+           "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy", "twx_stream_times",
+           "twx_set_precision")
 
 _LIB = None
 
@@ -179,6 +183,12 @@ class Context(object):
     def _chk(self, rc, what):
         if rc != 0:
             raise TwxError("%s failed: %s" % (what, self.lib.twx_last_error(self.h).decode()))
+
+    def set_precision(self, mode):
+        """'fast' (default routing: fp32 pair distances, ill-conditioned systems and tie-guard cells on the fp64 covariance
+        build) or 'exact' (every kriging system on the fp64 build) for every later call (twx_set_precision)."""
+        m = {"fast": PRECISION_FAST, "exact": PRECISION_EXACT}.get(mode, mode)
+        self._chk(self.lib.twx_set_precision(self.h, C.c_int(int(m))), "twx_set_precision")
 
     # ---- model state ------------------------------------------------------------
     def set_days(self, days):
@@ -514,6 +524,12 @@ class TileStream(object):
                 out[name] = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
         out["device_ms"] = ms.value
         return out
+
+    def times(self, slot):
+        """(device_ms, copy_ms) of the tile last waited for in ``slot``: its kernels, and its copy-out to pinned memory."""
+        dev, cp = C.c_float(), C.c_float()
+        self.ctx._chk(self.ctx.lib.twx_stream_times(self.h, C.c_int(slot), C.byref(dev), C.byref(cp)), "twx_stream_times")
+        return dev.value, cp.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -35,6 +35,7 @@ struct GwrWs {
     double *z;        // [ncell][12][TWX_KZ]  hat row by neighbour rank (point mode, and the tile-months of grid mode that do
                       // not go through a table: see zd)
     double *zc;       // [ncell][12]          pt_norm - sum_j z_j norm_j
+    double *zn;       // [ncell][12]          sum_j z_j norm_j itself (grid mode: k_tie_rezc re-forms zc from a re-kriged normal)
     int32_t *gstat;   // [ncell]
     uint32_t *noff;   // [ncell][ksel] byte offset of each ranked neighbour's observation row (k_row_offsets)
     // EVERY daily sum runs in ONE order: ascending station index of the cell's neighbours -- the order of the reference
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(192) void k_gwr_z_cell(StnDev st, CellSrc src, SelW
     bad = (__ballot(bad) & rowmask) != 0;
     if (tr == 0 && ka > 0) {
         gw.zc[lc * 12 + m0] = ws.uk_mean[lc * 12 + m0] - zn;
+        gw.zn[lc * 12 + m0] = zn;
         if (bad) gw.gstat[lc] = TWX_CELL_NUMERIC;
     }
 }
@@ -672,12 +674,30 @@ __global__ __launch_bounds__(256) void k_tile_uidx(CellSrc src, SelWs ws, GwrWs 
 // Days with tmin >= tmax are recorded per cell as they are found (chronological day index, unordered; the count keeps
 // running past the capacity): a cell with at most TWX_INV_CAP of them is fixed from those days' windows alone
 // (k_fix_sparse), any other by recomputing its whole series (k_fix_cells).
+//
+// Near ties (the "tie guard"): the fixer's test tmin >= tmax (interp_tair.py:170) is a DISCONTINUITY of the product -- a day
+// whose Tmax - Tmin is within the fast covariance build's ~1e-6 degC of 0 can fall on the other side of it than in an fp64
+// evaluation of the reference's formulas, and then that day moves by the window's mean diurnal range, the cell's recomputed
+// normals by ~0.05 degC and its ninvalid by 1: far outside the parity bars, and the product would not know.  So the daily
+// kernels also record the cells that have ANY day with |Tmax - Tmin| < TWX_TIE_EPS (20 x the fast build's observed error of
+// a normal); exactly those cells are kriged again on the fp64 covariance build (run_tie_guard, twx_hip.hip), their constants
+// re-formed (k_tie_rezc) and their whole series recomputed by k_fix_cells -- every output of such a cell is then what a
+// TWX_FLAG_UK_F64_ALL run gives, bit for bit.  On real data this is a cell in ~1e5 (each costs ~25 us); the guard itself is
+// one subtraction and one compare per cell-day.
 #define TWX_INV_CAP 256
-__device__ __forceinline__ void note_invalid_day(int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, int64_t lc, int d)
+#ifndef TWX_TIE_EPS
+#define TWX_TIE_EPS 2e-5
+#endif
+// dtr = tmax - tmin of a day, called when dtr < TWX_TIE_EPS (rare): dtr <= 0 <=> tmin >= tmax exactly (IEEE subtraction of
+// finite values has the exact sign)
+__device__ __forceinline__ void note_day(int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, int32_t *tie, int64_t lc, int d, double dtr)
 {
-    flag[lc] = 1;
-    const int slot = atomicAdd(&inv_cnt[lc], 1);
-    if (slot < TWX_INV_CAP) inv_day[lc * TWX_INV_CAP + slot] = d;
+    if (dtr <= 0.0) {
+        flag[lc] = 1;
+        const int slot = atomicAdd(&inv_cnt[lc], 1);
+        if (slot < TWX_INV_CAP) inv_day[lc * TWX_INV_CAP + slot] = d;
+    }
+    if (tie && dtr > -TWX_TIE_EPS) tie[lc] = 1;
 }
 
 // lean argument block of k_daily_tile (the full workspaces would not fit the scalar registers: 97 spilled SGPRs)
@@ -696,6 +716,7 @@ struct DtArgs {
     int16_t *out_n, *out_x;   // [ndays][Y][X]
     int32_t *flag;
     int32_t *inv_cnt, *inv_day;   // per cell: number of days with tmin >= tmax, and the first TWX_INV_CAP of them (k_fix_sparse)
+    int32_t *tie;             // [ncell] set for cells with a day of |tmax - tmin| < TWX_TIE_EPS (null: guard off)
     int64_t cell0, ncell, tile0, ntile;
     int Y, X, ts, ntx, ndays, nblk_max, gather;
     int moff[13];
@@ -858,7 +879,8 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) __attribute__((amdgpu_waves_per_
         const int cl = wv * TWX_DT_CPW + i;
         const int64_t lc = lcs[i];
         const double vx = vxs[i];
-        if (lc >= 0 && day_ok && vn[i] >= vx) note_invalid_day(a.flag, a.inv_cnt, a.inv_day, lc, a.mm2chron[dm]);
+        const double dtr = vx - vn[i];
+        if (lc >= 0 && day_ok && dtr < TWX_TIE_EPS) note_day(a.flag, a.inv_cnt, a.inv_day, a.tie, lc, a.mm2chron[dm], dtr);
         const bool okd = lc >= 0 && day_ok;
         s_v[0][lane][cl] = okd ? pack_i16(vn[i]) : TWX_FILL_I2;
         s_v[1][lane][cl] = okd ? pack_i16(vx) : TWX_FILL_I2;
@@ -896,7 +918,7 @@ __global__ __launch_bounds__(64 * TWX_DT_WAVES) __attribute__((amdgpu_waves_per_
 // rows, or all of them with TWX_FLAG_DAILY_GATHER / TWX_FLAG_OBS_ADDR64
 __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                            GwrWs gn, GwrWs gx, DayAxis da, twx_grid_out out,
-                                                           int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, const int32_t *okc,
+                                                           int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, int32_t *tie, const int32_t *okc,
                                                            int nblk_max, int addr64, int gather)
 {
     __shared__ int16_t s_v[2][64][66];
@@ -930,7 +952,7 @@ __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev st
         if (lc >= 0 && day_ok) {
             if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
             else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, va, vb);
-            if (va >= vb) note_invalid_day(flag, inv_cnt, inv_day, lc, da.mm2chron[dm]);
+            if (vb - va < TWX_TIE_EPS) note_day(flag, inv_cnt, inv_day, tie, lc, da.mm2chron[dm], vb - va);
         }
         const bool okd = lc >= 0 && day_ok;
         s_v[0][lane][cl] = okd ? pack_i16(va) : TWX_FILL_I2;
@@ -957,7 +979,7 @@ __global__ __launch_bounds__(256) void k_daily_tile_gather(StnDev stn, StnDev st
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, CellSrc src, SelWs wn, SelWs wx,
                                                     GwrWs gn, GwrWs gx, int has_n, int has_x, DayAxis da,
-                                                    twx_grid_out out, int32_t *flag, int32_t *inv_cnt, int32_t *inv_day,
+                                                    twx_grid_out out, int32_t *flag, int32_t *inv_cnt, int32_t *inv_day, int32_t *tie,
                                                     int nblk_max, int addr64)
 {
     __shared__ int16_t s_v[2][64][66];
@@ -988,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_daily_grid(StnDev stn, StnDev stx, Cell
             if (has_n && has_x) {
                 if (off32) daily_value2<true>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
                 else daily_value2<false>(stn, wn, gn, stx, wx, gx, lc, m0, da.ndays, dm, vn, vx);
-                if (vn >= vx) note_invalid_day(flag, inv_cnt, inv_day, lc, da.mm2chron[dm]);
+                if (vx - vn < TWX_TIE_EPS) note_day(flag, inv_cnt, inv_day, tie, lc, da.mm2chron[dm], vx - vn);
             } else if (has_n) vn = daily_value(stn, wn, gn, lc, m0, wn.ka[lc * 12 + m0], da.ndays, dm);
             else vx = daily_value(stx, wx, gx, lc, m0, wx.ka[lc * 12 + m0], da.ndays, dm);
         }
@@ -1027,6 +1049,8 @@ struct FixArgs {
     const int32_t *ncells_dev; // grid mode: number of flagged cells (k_compact_flags), read on the device
     const int32_t *inv_cnt;  // grid mode: [ncell] days with tmin >= tmax found by the daily kernels
     const int32_t *inv_day;  // grid mode: [ncell][TWX_INV_CAP] the first of them (chronological day index, unordered)
+    const int32_t *tie;      // grid mode: [ncell] cells of the tie guard (note_day; re-kriged on the fp64 build): k_fix_cells recomputes and
+                             // REWRITES their whole series, k_fix_sparse leaves them alone (null: guard off)
     int sparse_ok;           // grid mode: k_fix_sparse can take the cells with <= TWX_INV_CAP invalid days (fix_sparse_usable, evaluated
                              // ONCE on the host: both kernels and the launch decision read this one flag)
     double *scratch;        // [gridDim][2][ndays]
@@ -1154,7 +1178,8 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
     const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
-        if (fa.sparse_ok && fa.inv_cnt[lc] <= TWX_INV_CAP) continue;   // fixed from its windows by k_fix_sparse
+        const bool tie = fa.tie && fa.tie[lc];                  // tie-guard cell: its normals have just been kriged again (fp64 build)
+        if (!tie && fa.sparse_ok && fa.inv_cnt[lc] <= TWX_INV_CAP) continue;   // fixed from its windows by k_fix_sparse
         const int64_t c = wn.cell0 + lc;
         const int rr = (int)(c / src.X), qq = (int)(c % src.X);
         const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
@@ -1180,12 +1205,15 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
             __syncthreads();
         }
         __syncthreads();
-        fix_series_block(tmin, tmax, list, da, &s_n, &s_err, s_norm);
-        const int ninv = s_n;
-        if (s_err) {
+        // (a tie-guard cell whose second kriging failed -- the fp64 build found a system singular that the fast build let
+        // pass: k_finalize_grid has entered its status -- is abandoned as a whole, like any kriging failure)
+        const int ukfail = tie ? (wn.uk_stat[lc] ? wn.uk_stat[lc] : wx.uk_stat[lc]) : 0;
+        if (!ukfail) fix_series_block(tmin, tmax, list, da, &s_n, &s_err, s_norm);
+        const int ninv = ukfail ? 0 : s_n;
+        if (ukfail || s_err) {
             // the reference raises (interp_tair.py:192) -> the worker leaves fill values
             if (threadIdx.x == 0) {
-                if (out.status) out.status[c] = TWX_CELL_FIXER;
+                if (out.status) out.status[c] = ukfail ? ukfail : TWX_CELL_FIXER;
                 if (out.ninvalid) out.ninvalid[c] = TWX_FILL_I4;
             }
             for (int m = threadIdx.x; m < 12; m += blockDim.x) {
@@ -1205,6 +1233,13 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
                     if (out.norm_tmin) out.norm_tmin[m * yx + c] = (float)s_norm[m];
                     if (out.norm_tmax) out.norm_tmax[m * yx + c] = (float)s_norm[12 + m];
                 }
+            }
+            if (tie) {          // every day: the series now stands on the re-kriged normals (ninv == 0: k_finalize_grid wrote those)
+                for (int d = threadIdx.x; d < da.ndays; d += blockDim.x) {
+                    if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(tmin[d]);
+                    if (out.daily_tmax) out.daily_tmax[(int64_t)d * yx + c] = pack_i16(tmax[d]);
+                }
+            } else {
                 for (int q = threadIdx.x; q < ninv; q += blockDim.x) {
                     int d = list[q];
                     if (out.daily_tmin) out.daily_tmin[(int64_t)d * yx + c] = pack_i16(tmin[d]);
@@ -1223,7 +1258,7 @@ __global__ __launch_bounds__(1024) void k_fix_cells(StnDev stn, StnDev stx, Cell
 // invalid days and reads the +-tail days around each (interp_tair.py:173-195), and the normals recompute (:583-590)
 // only needs per-(year, month) sums.  A tile whose cells are mostly flagged (one day in 69 years is enough) would spend
 // several times its whole interpolation in that recompute.  Here:
-//   * the invalid days come from the daily kernels themselves (note_invalid_day: the exact fp64 test vn >= vx at the
+//   * the invalid days come from the daily kernels themselves (note_day: the exact fp64 test vn >= vx at the
 //     moment the value is packed), sorted ascending;
 //   * only the days of their windows are recomputed (same lists, same fma chain, same bits as the daily kernels);
 //   * the sequential fix runs on those (earlier fixes feed later windows: one thread, day order);
@@ -1262,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_fix_sparse(StnDev stn, StnDev stx, Cell
     for (int it = blockIdx.x; it < ncells; it += gridDim.x) {
         const int64_t lc = fa.cells[it];
         const int ninv = fa.inv_cnt[lc];
-        if (ninv > TWX_INV_CAP || ninv <= 0) continue;       // (uniform) the full recompute takes this cell
+        if (ninv > TWX_INV_CAP || ninv <= 0 || (fa.tie && fa.tie[lc])) continue;   // (uniform) the full recompute takes this cell
         const int64_t c = wn.cell0 + lc;
         const int rr = (int)(c / src.X), qq = (int)(c % src.X);
         const int64_t tl = (int64_t)(rr / src.ts) * src.ntx + (qq / src.ts) - wn.tile0;
@@ -1409,6 +1444,25 @@ __global__ __launch_bounds__(256) void k_fix_series(DayAxis da, FixArgs fa)
         }
         __syncthreads();
     }
+}
+
+// Tie guard, after the second kriging of the listed cells (run_tie_guard): the daily constants zc = normal - sum_j z_j norm_j
+// from the NEW normals (the sum was kept by k_gwr_z_cell: the same subtraction, the same bits as a first pass on the fp64
+// build), and the cells enter the fixer's list (k_fix_cells rewrites their series whether or not a day is invalid).
+// One thread per (listed cell, variable, month).
+__global__ void k_tie_rezc(const int32_t *list, const int32_t *count, SelWs wn, SelWs wx, GwrWs gn, GwrWs gx, int32_t *flag,
+                           long long *stats)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) atomicAdd((unsigned long long *)&stats[4], (unsigned long long)*count);   // (twx_timing.tie_cells)
+    const int64_t it = idx / 24;
+    if (it >= *count) return;
+    const int64_t lc = list[it];
+    const int q = (int)(idx % 24), v = q / 12, m = q % 12;
+    const SelWs &w = v ? wx : wn;
+    const GwrWs &g = v ? gx : gn;
+    if (w.ka[lc * 12 + m] > 0) g.zc[lc * 12 + m] = w.uk_mean[lc * 12 + m] - g.zn[lc * 12 + m];
+    if (q == 0) flag[lc] = 1;
 }
 
 __global__ void k_pack(const double *x, int64_t n, int16_t *out)

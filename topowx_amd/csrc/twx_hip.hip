@@ -51,7 +51,7 @@ struct VarData {
 struct Work {
     DevBuf cand, ncand, small, dscratch, near_idx, near_dist, nnear, kk, ka, vario, cstat, cdup,
         bucket_cells, uk_mean, uk_var, uk_stat, z, zc, gstat, ctrig, uk_S, uk_beta, vfit, dist, h0, hminp, noff, near_pos, urow,
-        nurow, zd, perm, kp, uslot, cellf64, f64_cells, dist64, h064, gd64;
+        nurow, zd, perm, kp, uslot, cellf64, f64_cells, dist64, h064, gd64, zn;
     int cmax = TWX_CAND_SMALL;   // candidate slots per tile of the current batch
     SelWs ws{};
     GwrWs gw{};
@@ -59,12 +59,12 @@ struct Work {
     {
         for (DevBuf *b : {&cand, &ncand, &small, &dscratch, &near_idx, &near_dist, &nnear, &kk, &ka, &vario, &cstat,
                           &cdup, &bucket_cells, &uk_mean, &uk_var, &uk_stat, &z, &zc, &gstat, &ctrig, &uk_S, &uk_beta, &vfit, &dist, &h0, &hminp, &noff,
-                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot, &cellf64, &f64_cells, &dist64, &h064, &gd64})
+                          &near_pos, &urow, &nurow, &zd, &perm, &kp, &uslot, &cellf64, &f64_cells, &dist64, &h064, &gd64, &zn})
             b->release();
     }
 };
 
-enum { EV_TILE = 0, EV_SELECT, EV_UK, EV_GWR, EV_DAILY, EV_FIX, EV_NKIND };
+enum { EV_TILE = 0, EV_SELECT, EV_UK, EV_GWR, EV_DAILY, EV_FIX, EV_TIE, EV_NKIND };
 
 struct EvPair { hipEvent_t a, b; int kind; };
 
@@ -100,12 +100,12 @@ struct twx_ctx {
     AggAxis agg{};
     hipEvent_t ev_agg_a = nullptr, ev_agg_b = nullptr;
     // scratch for the point entries / fixer
-    DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list, inv_cnt, inv_day;
+    DevBuf pt_in, pt_aux, pt_out, fix_scratch, fix_lists, flags, flag_list, inv_cnt, inv_day, tie;
     DevBuf grid_in, grid_out;     // persistent device images of the host-buffer grid entry
     // every context-level device buffer (the per-variable ones live in var[] / work[]): twx_destroy releases these
     std::vector<DevBuf *> all_bufs()
     {
-        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list, &inv_cnt, &inv_day, &stats,
+        return {&day_dev, &agg_dev, &agg_in, &agg_out, &pt_in, &pt_aux, &pt_out, &fix_scratch, &fix_lists, &flags, &flag_list, &inv_cnt, &inv_day, &tie, &stats,
                 &grid_in, &grid_out};
     }
     std::string err;
@@ -113,7 +113,8 @@ struct twx_ctx {
     size_t ev_used = 0;
     twx_timing timing{};
     int64_t t_cells = 0;
-    DevBuf stats;                 // [3] int64: kriging systems solved, kriging launches with work, systems on the fp64 build (device-side counters)
+    DevBuf stats;                 // [5] int64: kriging systems solved, kriging launches with work, systems on the fp64 build, systems / cells of
+                                  // the tie guard's second pass (device-side counters: k_bucket_stats)
     int ncu = 256;                // compute units (sizes the fixed grids of the kriging launches)
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     bool have_total = false;
@@ -193,6 +194,7 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
         HIPCHK(w.z.ensure((size_t)ncell * 12 * TWX_KZ * 8));
         HIPCHK(w.noff.ensure((size_t)ncell * ksel * 4));
         HIPCHK(w.zc.ensure((size_t)ncell * 96));
+        HIPCHK(w.zn.ensure((size_t)ncell * 96));
         HIPCHK(w.gstat.ensure((size_t)ncell * 4));
         HIPCHK(w.perm.ensure((size_t)ncell * ksel * 4));     // ranks in ascending station-index order (k_perm)
         HIPCHK(w.kp.ensure((size_t)ncell * 4));
@@ -232,7 +234,8 @@ int prepare_work(twx_ctx *ctx, int v, int64_t cell0, int64_t ncell, int64_t tile
     s.fast_only = (ctx->p.flags & TWX_FLAG_UK_FAST_ONLY) ? 1 : 0;
     s.f64_all = (ctx->p.flags & TWX_FLAG_UK_F64_ALL) ? 1 : 0;
     s.cellf64 = w.cellf64.as<int32_t>(); s.f64_cells = w.f64_cells.as<int32_t>(); s.dist64 = nullptr; s.h064 = nullptr;
-    w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
+    s.rerun = nullptr;
+    w.gw.z = w.z.as<double>(); w.gw.zc = w.zc.as<double>(); w.gw.zn = w.zn.as<double>(); w.gw.gstat = w.gstat.as<int32_t>();
     w.gw.noff = w.noff.as<uint32_t>();
     w.gw.perm = w.perm.as<int32_t>(); w.gw.kp = w.kp.as<int32_t>();
     w.gw.uslot = tile_tab ? w.uslot.as<uint16_t>() : nullptr;
@@ -315,10 +318,19 @@ void launch_ukw(const int32_t *cnt, const StnDev &st, const CellSrc &src, const 
 // (cell, month) systems by matrix size, read the counts back (unless TWX_FLAG_NO_HOST_SYNC), fp64 slabs for routed cells,
 // one launch per bucket, the 7x7 epilogue.  Returns 1 when a grid batch must be re-run with longer candidate lists
 // (*cmax_wanted), 0 when done, -1 on error.  Also the second stage of twx_krigall_points (new variograms, same selection).
-int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int ksel, hipStream_t stream, bool may_retry, int *cmax_wanted)
+// rerun (the tie guard, run_tie_guard): [ncell] device flags -- only the flagged cells' systems are listed, all on the fp64 build; the
+// bucket counts are reset first, the time goes to EV_TIE and the systems to the guard's own counters.
+int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int ksel, hipStream_t stream, bool may_retry, int *cmax_wanted,
+                 const int32_t *rerun = nullptr)
 {
     Work &w = ctx->work[v];
     const StnDev &st = ctx->var[v].dev;
+    const int evk = rerun ? EV_TIE : EV_UK;
+    w.ws.rerun = rerun;
+    if (rerun) {
+        HIPCHK(hipMemsetAsync(w.small.as<int32_t>() + 1, 0, 4, stream));                              // routed cells
+        HIPCHK(hipMemsetAsync(w.small.as<int32_t>() + 16, 0, (size_t)TWX_NBUCKET * 4, stream));       // bucket counts
+    }
     HIPCHK(hipMemsetAsync(w.cellf64.p, 0, (size_t)ncell * 4, stream));
     hipLaunchKernelGGL(k_bucket_items, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     int32_t small_host[16 + TWX_NBUCKET];                    // [0] longest candidate list, [1] cells on the fp64 build, [16..] bucket counts
@@ -343,14 +355,15 @@ int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int kse
         HIPCHK(w.dist64.ensure((size_t)nf64 * TWX_DIST_BLOCKS * 256 * 8));
         HIPCHK(w.h064.ensure((size_t)nf64 * ksel * 8));
         w.ws.dist64 = w.dist64.as<double>(); w.ws.h064 = w.h064.as<double>();
-        EvScope ev(ctx, stream, EV_UK);
+        EvScope ev(ctx, stream, evk);
         hipLaunchKernelGGL(k_cell_dist64, dim3((unsigned)nf64), dim3(256), 0, stream, st, w.ws);
     }
     {
-        EvScope ev(ctx, stream, EV_UK);
+        EvScope ev(ctx, stream, evk);
         const int64_t mi = ncell * 12;
         // buckets of 8 neighbours (twx_krig_bucket): bordered one-wave kernels, one-wave kernels with the border as
         // columns (k in the upper half of a block row), two- / four-wave kernels from 97 neighbours on
+        if (!rerun) {
         launch_ukwz<6>(cnt, st, src, w.ws, 7, mi, stream);      // 88 < k <= 96
         launch_ukw<6>(cnt, st, src, w.ws, 6, mi, stream);    // 80 < k <= 88
 #if TWX_UKW2
@@ -371,6 +384,7 @@ int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int kse
         launch_uk<8>(cnt, st, src, w.ws, 10, mi, stream);       // 104 < k <= 120
         launch_uk<9>(cnt, st, src, w.ws, 12, mi, stream);       // 120 < k <= 136
         launch_uk<10>(cnt, st, src, w.ws, 13, mi, stream);      // 136 < k <= 152
+        }
         constexpr int F = TWX_BUCKET_F64;
         if (w.ws.dist64) {       // ill-conditioned systems (uk_needs_f64): the fp64 covariance build of their own matrix size,
                                  // distances from the cells' fp64 slabs
@@ -396,6 +410,7 @@ int run_uk_stage(twx_ctx *ctx, int v, const CellSrc &src, int64_t ncell, int kse
         }
         hipLaunchKernelGGL(k_uk_solve, dim3((unsigned)((ncell * 12 + 255) / 256)), dim3(256), 0, stream, w.ws);
     }
+    w.ws.rerun = nullptr;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -498,6 +513,36 @@ int run_gwr(twx_ctx *ctx, int v, const CellSrc &src, const double *pt_norm_dev, 
     return 0;
 }
 
+// The tie guard (twx_daily.h, note_day): the cells of this batch that have a day with |Tmax - Tmin| < TWX_TIE_EPS are kriged a second
+// time, both variables, every month on the fp64 covariance build; their normals / SE are written again, their daily constants
+// re-formed, and they enter the fixer's list flagged for a rewrite of their whole series (k_fix_cells).  Default mode: the number of
+// such cells is read back (one 4-byte copy; the host has been waiting on this stream's selection kernels anyway) and nothing is
+// launched when it is 0 -- the normal case.  TWX_FLAG_NO_HOST_SYNC: every launch covers the worst case.
+int run_tie_guard(twx_ctx *ctx, const CellSrc (&src)[2], int64_t ncell, const twx_grid_out &o, hipStream_t stream)
+{
+    int32_t *d_tie = ctx->tie.as<int32_t>(), *d_list = d_tie + ncell, *d_cnt = d_list + ncell;
+    hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_tie, ncell, d_list, d_cnt);
+    int64_t ntie = ncell;
+    if (!(ctx->p.flags & TWX_FLAG_NO_HOST_SYNC)) {
+        int32_t h = 0;
+        HIPCHK(hipMemcpyAsync(&h, d_cnt, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h == 0) return 0;
+        ntie = h;
+    }
+    for (int v = 0; v < 2; ++v) {
+        int dummy = 0;
+        if (run_uk_stage(ctx, v, src[v], ncell, ctx->work[v].ws.ksel, stream, false, &dummy, d_tie) < 0) return -1;
+    }
+    EvScope ev(ctx, stream, EV_TIE);
+    hipLaunchKernelGGL(k_tie_rezc, dim3((unsigned)((ntie * 24 + 255) / 256)), dim3(256), 0, stream, d_list, d_cnt, ctx->work[0].ws,
+                       ctx->work[1].ws, ctx->work[0].gw, ctx->work[1].gw, ctx->flags.as<int32_t>(), ctx->stats.as<long long>());
+    hipLaunchKernelGGL(k_finalize_grid, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, src[0], ctx->work[0].ws,
+                       ctx->work[1].ws, 1, 1, ctx->work[0].gw.gstat, ctx->work[1].gw.gstat, o, 1, d_tie);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int check_var(twx_ctx *ctx, int v, bool need_obs)
 {
     if (v < 0 || v > 1) return fail(ctx, "var must be TWX_TMIN or TWX_TMAX");
@@ -557,6 +602,16 @@ void twx_destroy(twx_ctx *ctx)
     if (ctx->ev_agg_a) (void)hipEventDestroy(ctx->ev_agg_a);
     if (ctx->ev_agg_b) (void)hipEventDestroy(ctx->ev_agg_b);
     delete ctx;
+}
+
+int twx_set_precision(twx_ctx *ctx, int mode)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    if (mode != TWX_PRECISION_FAST && mode != TWX_PRECISION_EXACT) return fail(ctx, "twx_set_precision: mode must be TWX_PRECISION_FAST or TWX_PRECISION_EXACT");
+    if (mode == TWX_PRECISION_EXACT) ctx->p.flags |= TWX_FLAG_UK_F64_ALL;
+    else ctx->p.flags &= ~TWX_FLAG_UK_F64_ALL;
+    return 0;
 }
 
 int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const int32_t *day_year)
@@ -1352,7 +1407,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
         hipLaunchKernelGGL(k_finalize_grid, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, s0,
                            ctx->work[0].ws, ctx->work[1].ws, (int)has_n, (int)has_x,
                            (daily && has_n) ? ctx->work[0].gw.gstat : nullptr,
-                           (daily && has_x) ? ctx->work[1].gw.gstat : nullptr, *o, 1);
+                           (daily && has_x) ? ctx->work[1].gw.gstat : nullptr, *o, 1, (const int32_t *)nullptr);
         ctx->t_cells += ncell;
         if (daily) {
             int maxd = 0;
@@ -1367,6 +1422,14 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
             int32_t *d_icnt = ctx->inv_cnt.as<int32_t>(), *d_iday = ctx->inv_day.as<int32_t>();
             int32_t *d_flag = ctx->flags.as<int32_t>();
             int32_t *d_count = d_flag + ncell;
+            // tie guard (see run_tie_guard): on whenever the fixer runs on fast-build normals
+            const bool guard = has_n && has_x && !(ctx->p.flags & (TWX_FLAG_UK_F64_ALL | TWX_FLAG_UK_FAST_ONLY | TWX_FLAG_NO_TIE_GUARD));
+            int32_t *d_tie = nullptr;
+            if (guard) {
+                HIPCHK(ctx->tie.ensure((size_t)ncell * 8 + 256));
+                HIPCHK(hipMemsetAsync(ctx->tie.p, 0, (size_t)ncell * 8 + 256, stream));
+                d_tie = ctx->tie.as<int32_t>();
+            }
             {
                 EvScope ev(ctx, stream, EV_DAILY);
                 for (int v = 0; v < 2; ++v)
@@ -1390,7 +1453,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                         dv.urow = wk.gw.urow; dv.nurow = wk.gw.nurow;
                     }
                     da.okc = d_okc; da.mm2chron = ctx->da.mm2chron; da.out_n = o->daily_tmin; da.out_x = o->daily_tmax;
-                    da.flag = d_flag; da.inv_cnt = d_icnt; da.inv_day = d_iday; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0; da.ntile = ntile;
+                    da.flag = d_flag; da.inv_cnt = d_icnt; da.inv_day = d_iday; da.tie = d_tie; da.cell0 = cell0; da.ncell = ncell; da.tile0 = tile0; da.ntile = ntile;
                     da.Y = Y; da.X = X; da.ts = ts; da.ntx = ntx; da.ndays = (int)ctx->ndays; da.nblk_max = nblk; da.gather = gather;
                     for (int m = 0; m < 13; ++m) da.moff[m] = ctx->da.moff[m];
                     if (!gather)
@@ -1398,13 +1461,14 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                         hipLaunchKernelGGL(k_daily_tile, dim3((unsigned)((((ntile + 7) / 8) * 12 + 7) / 8 * 8 * 8 * nblk)), dim3(64 * TWX_DT_WAVES), 0, stream, da);
                     hipLaunchKernelGGL(k_daily_tile_gather, dim3((unsigned)ntile, (unsigned)(12 * nblk)), dim3(256), 0, stream,
                                        ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws, ctx->work[0].gw,
-                                       ctx->work[1].gw, ctx->da, *o, d_flag, d_icnt, d_iday, d_okc, nblk, addr64, gather);
+                                       ctx->work[1].gw, ctx->da, *o, d_flag, d_icnt, d_iday, d_tie, d_okc, nblk, addr64, gather);
                 } else {
                     hipLaunchKernelGGL(k_daily_grid, dim3((unsigned)((ncell + 63) / 64), (unsigned)(12 * nblk)), dim3(256), 0,
                                        stream, ctx->var[0].dev, ctx->var[1].dev, s0, ctx->work[0].ws, ctx->work[1].ws,
-                                       ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, d_icnt, d_iday, nblk, addr64);
+                                       ctx->work[0].gw, ctx->work[1].gw, (int)has_n, (int)has_x, ctx->da, *o, d_flag, d_icnt, d_iday, d_tie, nblk, addr64);
                 }
             }
+            if (guard && run_tie_guard(ctx, src, ncell, *o, stream)) return -1;
             if (has_n && has_x) {
                 hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_flag,
                                    ncell, ctx->flag_list.as<int32_t>(), d_count);
@@ -1413,7 +1477,7 @@ int twx_interp_grid_dev(twx_ctx *ctx, const twx_grid *g, const twx_grid_out *o, 
                 HIPCHK(ctx->fix_scratch.ensure((size_t)nb * 2 * ctx->ndays * 8));
                 HIPCHK(ctx->fix_lists.ensure((size_t)nb * ctx->ndays * 4));
                 FixArgs fa{};
-                fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count; fa.inv_cnt = d_icnt; fa.inv_day = d_iday;
+                fa.cells = ctx->flag_list.as<int32_t>(); fa.ncells_dev = d_count; fa.inv_cnt = d_icnt; fa.inv_day = d_iday; fa.tie = d_tie;
                 fa.scratch = ctx->fix_scratch.as<double>(); fa.lists = ctx->fix_lists.as<int32_t>();
                 fa.sparse_ok = (!(ctx->p.flags & TWX_FLAG_FIX_FULL) &&
                                 fix_sparse_usable(ctx->var[0].dev.ymsum, ctx->var[1].dev.ymsum, ctx->da.norm_ny, ctx->da.tail)) ? 1 : 0;
@@ -1510,7 +1574,7 @@ struct twx_stream {
     DevBuf din[2], dout[2];                       // double-buffered device images
     std::vector<char *> hin, hout;                // pinned host staging per slot
     std::vector<GridDev> views;                   // per slot: where its outputs live in hout[slot]
-    std::vector<hipEvent_t> ev_start, ev_comp, ev_done;   // per slot
+    std::vector<hipEvent_t> ev_start, ev_comp, ev_copy0, ev_done;   // per slot
     hipEvent_t ev_free[2] = {nullptr, nullptr};   // device set d has been copied out
     bool used[2] = {false, false};
     int64_t nsub = 0;
@@ -1536,12 +1600,12 @@ int twx_stream_create(twx_ctx *ctx, int Y, int X, int vars, int daily, int nslot
         ok = st->din[d].ensure(st->in_bytes) == hipSuccess && st->dout[d].ensure(st->out_bytes) == hipSuccess &&
              hipEventCreateWithFlags(&st->ev_free[d], hipEventDisableTiming) == hipSuccess;
     st->hin.assign(nslots, nullptr); st->hout.assign(nslots, nullptr);
-    st->views.resize(nslots); st->ev_start.assign(nslots, nullptr); st->ev_comp.assign(nslots, nullptr); st->ev_done.assign(nslots, nullptr);
+    st->views.resize(nslots); st->ev_start.assign(nslots, nullptr); st->ev_comp.assign(nslots, nullptr); st->ev_copy0.assign(nslots, nullptr); st->ev_done.assign(nslots, nullptr);
     for (int i = 0; ok && i < nslots; ++i)
         ok = hipHostMalloc((void **)&st->hin[i], st->in_bytes, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void **)&st->hout[i], st->out_bytes, hipHostMallocDefault) == hipSuccess &&
              hipEventCreate(&st->ev_start[i]) == hipSuccess && hipEventCreate(&st->ev_comp[i]) == hipSuccess &&
-             hipEventCreate(&st->ev_done[i]) == hipSuccess;
+             hipEventCreate(&st->ev_copy0[i]) == hipSuccess && hipEventCreate(&st->ev_done[i]) == hipSuccess;
     ctx->streams.push_back(st);
     if (!ok) { twx_stream_destroy(st); return fail(ctx, "twx_stream_create: allocation failed (device images / pinned host staging)"); }
     *out = st;
@@ -1561,7 +1625,7 @@ void twx_stream_destroy(twx_stream *st)
     for (int d = 0; d < 2; ++d) { st->din[d].release(); st->dout[d].release(); if (st->ev_free[d]) (void)hipEventDestroy(st->ev_free[d]); }
     for (char *p : st->hin) if (p) (void)hipHostFree(p);
     for (char *p : st->hout) if (p) (void)hipHostFree(p);
-    for (auto *v : {&st->ev_start, &st->ev_comp, &st->ev_done})
+    for (auto *v : {&st->ev_start, &st->ev_comp, &st->ev_copy0, &st->ev_done})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (st->s_comp) (void)hipStreamDestroy(st->s_comp);
     if (st->s_copy) (void)hipStreamDestroy(st->s_copy);
@@ -1599,6 +1663,7 @@ int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
     HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_comp));
     // copy stream: device set d -> the slot's pinned block, overlapping the next tile's kernels
     HIPCHK(hipStreamWaitEvent(st->s_copy, st->ev_comp[slot], 0));
+    HIPCHK(hipEventRecord(st->ev_copy0[slot], st->s_copy));
     GridDev &view = st->views[slot];
     view = GridDev{};
     char *hout = st->hout[slot];
@@ -1639,11 +1704,25 @@ int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device
     return 0;
 }
 
+int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms)
+{
+    if (!st) return -1;
+    twx_ctx *ctx = st->ctx;
+    ctx->err.clear();
+    if (slot < 0 || slot >= st->nslots) return fail(ctx, "twx_stream_times: bad arguments");
+    if (!st->views[slot].o.status) return fail(ctx, "twx_stream_times: nothing submitted in this slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventSynchronize(st->ev_done[slot]));
+    if (device_ms) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
+    if (copy_ms) HIPCHK(hipEventElapsedTime(copy_ms, st->ev_copy0[slot], st->ev_done[slot]));
+    return 0;
+}
+
 int twx_get_timing(twx_ctx *ctx, twx_timing *t)
 {
     if (!ctx || !t) return -1;
     HIPCHK(hipSetDevice(ctx->device));
-    float acc[EV_NKIND] = {0, 0, 0, 0, 0, 0};
+    float acc[EV_NKIND] = {0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < ctx->ev_used; ++i) {
         HIPCHK(hipEventSynchronize(ctx->ev_pool[i].b));
         float ms = 0;
@@ -1657,9 +1736,10 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
         HIPCHK(hipEventSynchronize(ctx->ev_total_b));
         HIPCHK(hipEventElapsedTime(&r.total_ms, ctx->ev_total_a, ctx->ev_total_b));
     }
-    long long st[3] = {0, 0, 0};
+    long long st[5] = {0, 0, 0, 0, 0};
     if (ctx->stats.p) HIPCHK(hipMemcpy(st, ctx->stats.p, sizeof st, hipMemcpyDeviceToHost));
     r.cells = ctx->t_cells; r.uk_solves = st[0]; r.uk_launches = st[1]; r.uk_f64_solves = st[2];
+    r.tie_solves = st[3]; r.tie_cells = st[4]; r.tie_ms = acc[EV_TIE];
     *t = r;
     return 0;
 }

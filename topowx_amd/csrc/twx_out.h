@@ -8,12 +8,14 @@
 // gstat_n / gstat_x: GWR status of the batch (k_gwr_z; null when no daily output is asked for).  A cell
 // whose hat row cannot be formed (np.linalg.inv raises in _gwr_series, interp_tair.py:1139) is abandoned as a
 // whole by the worker: normals, SE and ninvalid stay at fill, exactly like a kriging failure.
+// only: null, or [ncell] flags -- the cells to (re)write (the tie guard's second pass, run_tie_guard).
 __global__ void k_finalize_grid(CellSrc src, SelWs wn, SelWs wx, int has_n, int has_x,
-                                const int32_t *gstat_n, const int32_t *gstat_x, twx_grid_out out, int write_ninvalid)
+                                const int32_t *gstat_n, const int32_t *gstat_x, twx_grid_out out, int write_ninvalid,
+                                const int32_t *only)
 {
     const int64_t lc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const SelWs &w0 = has_n ? wn : wx;
-    if (lc >= w0.ncell) return;
+    if (lc >= w0.ncell || (only && !only[lc])) return;
     const int64_t c = w0.cell0 + lc;
     const int64_t yx = (int64_t)src.Y * src.X;
     if (!cell_valid(src, c)) {

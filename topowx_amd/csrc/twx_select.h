@@ -73,6 +73,8 @@ struct SelWs {
     // TWX_FLAG_NO_HOST_SYNC: the fp64-build kernels then evaluate every element's distance themselves, per system)
     double *dist64;      // [nf64][TWX_DIST_BLOCKS][16 tc][16 tr]
     double *h064;        // [nf64][ksel]
+    const int32_t *rerun; // tie guard (twx_daily.h: note_day; run_tie_guard): [ncell] flags -- when set, k_bucket_items lists ONLY the
+                         // systems of the flagged cells, all of them on the fp64 build, and k_uk_solve finishes only those (null otherwise)
 #ifdef TWX_UK_STAMP      // diagnostic build only (tests/tools/uk_stamps.sh): s_memtime stamps of the panel loop
     unsigned long long *dbg;
 #endif
@@ -778,10 +780,10 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
     if (item < ws.ncell * 12) {
         const int64_t lc = item / 12;
         const int k = ws.kk[item];                           // (0 for masked cells and for months the reference's loop does not reach)
-        if (k > 0) {
+        if (k > 0 && (!ws.rerun || ws.rerun[lc])) {
             id = twx_krig_bucket(k);
             const double nug = ws.vario[item * 3], psill = ws.vario[item * 3 + 1], rng = ws.vario[item * 3 + 2];
-            if (ws.f64_all || (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
+            if (ws.f64_all || ws.rerun || (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
                                uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))) {
                 // its own matrix size's fp64-build kernel; without slabs the two-wave kernels of 112 / 160 rows take all of them
                 id = TWX_BUCKET_F64 + (ws.f64_sized ? id : (k > 104 ? 13 : 8));
@@ -802,12 +804,17 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
 }
 
 // launch statistics for twx_get_timing without a host read-back on the launch path: stats[0] += systems solved,
-// stats[1] += kriging launches that had work (+ 1 for k_cell_dist), stats[2] += systems that took the fp64 build
+// stats[1] += kriging launches that had work (+ 1 for k_cell_dist), stats[2] += systems that took the fp64 build;
+// a tie-guard pass (ws.rerun) counts apart: stats[3] += systems kriged a second time (stats[4], their cells: k_tie_rezc)
 __global__ void k_bucket_stats(SelWs ws, long long *stats)
 {
     const int b = threadIdx.x;
     const int c = b < TWX_NBUCKET ? ws.bucket_cnt[b] : 0;
     const int tot = wave_sum_i(c), nz = wave_sum_i(c > 0 ? 1 : 0), f64 = wave_sum_i(b >= TWX_BUCKET_F64 ? c : 0);
+    if (ws.rerun) {
+        if (b == 0) atomicAdd((unsigned long long *)&stats[3], (unsigned long long)tot);
+        return;
+    }
     if (b == 0) {
         atomicAdd((unsigned long long *)&stats[0], (unsigned long long)tot);
         atomicAdd((unsigned long long *)&stats[1], (unsigned long long)(nz + 1));

@@ -32,8 +32,10 @@
 // correction) -- relative error ~3e-7 on h, far inside the 1e-4 degC parity bar.
 #pragma once
 #include "twx_select.h"
+#include "twx_exptab.h"
 
 #include <type_traits>
+
 
 __device__ __forceinline__ constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
@@ -188,27 +190,41 @@ __device__ __forceinline__ double ellip_pair_f64(const double *a, const double *
     return ellip_far_f64(Sd, cc, sG2);
 }
 
-// exp(x) for x <= 0 in fp64 (relative error ~2e-16): x = n ln 2 + r, |r| <= ln 2 / 2, degree-12 Taylor polynomial, ldexp
-// (the library exp is a call of ~60 instructions; the fp64 build evaluates one per matrix element)
-__device__ __forceinline__ double exp_neg_f64(double x)
+// exp(x) for x <= 0 in fp64: exp(x) = 2^n T[j] e^r with k = rint(x 256 / ln 2) = 256 n + j, T[j] = 2^(j / 256) (twx_exptab.h: 2 KB,
+// staged in LDS by the kernels that evaluate one per matrix element; `tab` may also be the table in global memory), |r| <= ln 2 / 512
+// and e^r - 1 = r (1 + r / 2 + r^2 / 6 + r^3 / 24) (truncation r^5 / 120 < 4e-17).  The rounding to k rides on the fma that scales x
+// (adding 1.5 2^52 leaves k in the low mantissa bits: no rint, no convert).  13 VALU instructions + one table read; measured against
+// long-double exp on 4e7 arguments in [-700, 0]: <= 1.33 ulp (the degree-12 polynomial it replaces, ~20 instructions: 2.29 ulp).
+// x = -inf, x below -800 and NaN give 0.
+__device__ __forceinline__ double exp_neg_f64(double x, const double *tab)
 {
-    if (!(x > -700.0)) return 0.0;
-    const double n = rint(x * 1.4426950408889634);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;                   // 1 / 12!
-    p = fma(p, r, 2.50521083854417187751e-08); p = fma(p, r, 2.75573192239858906526e-07); p = fma(p, r, 2.75573192239858906526e-06);
-    p = fma(p, r, 2.48015873015873015873e-05); p = fma(p, r, 1.98412698412698412698e-04); p = fma(p, r, 1.38888888888888888889e-03);
-    p = fma(p, r, 8.33333333333333333333e-03); p = fma(p, r, 4.16666666666666666667e-02); p = fma(p, r, 1.66666666666666666667e-01);
-    p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+    x = __builtin_fmax(x, -800.0);
+    const double M = 6755399441055744.0;                     // 1.5 * 2^52
+    const double z = fma(x, TWX_EXP_INV_STEP, M);
+    const int k = __double2loint(z);
+    const double kf = z - M;
+    double r = fma(kf, -TWX_EXP_STEP_HI, x);
+    r = fma(kf, -TWX_EXP_STEP_LO, r);
+    double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;
+    const double T = tab[k & (TWX_EXP_TAB_N - 1)];
+    return ldexp(fma(T, p, T), k >> 8);
+}
+// stage the table in LDS (every thread of the work-group; the caller's next barrier publishes it)
+template <int NTH>
+__device__ __forceinline__ void exp_tab_stage(double *s_tab, int t)
+{
+#pragma unroll
+    for (int q = t; q < TWX_EXP_TAB_N; q += NTH) s_tab[q] = twx_exp2_tab[q];
 }
 
 // psill exp(-h / range) with ninv = -1 / range (0 with psill = 0 for a pure nugget); coincident points give psill,
 // as the fast build does (their systems are singular and flagged through SelWs.cdup)
 __device__ __attribute__((noinline)) double cov_pair_f64(const double *a, const double *b, double ninv, double psill)
 {
-    return psill * exp_neg_f64(ellip_pair_f64(a, b) * ninv);
+    return psill * exp_neg_f64(ellip_pair_f64(a, b) * ninv, twx_exp2_tab);
 }
 
 // waves per SIMD the register budget is sized for (min == max so that the compiler
@@ -545,6 +561,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     __shared__ __attribute__((aligned(16))) double s_raw[4 * NP];             // the same four columns before the panel is factorised, [column][row]
     __shared__ double s_B[7][NP];
     __shared__ double s_trig[PREC == 2 ? NP * 5 : 1];        // PREC = 2: {sin, cos(lat / 2), sin, cos(lon / 2), cos(lat)} by rank
+    __shared__ double s_et[PREC == 1 ? TWX_EXP_TAB_N : 1];   // PREC = 1: the table of exp_neg_f64
     __shared__ int s_err;
 
     const int t = threadIdx.x, tr = t & 15, lane = t & 63, tcl = lane >> 4;
@@ -595,6 +612,24 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     float hd[PREC ? 1 : NT];
     const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
     const int64_t fs = PREC == 1 ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC = 1) the cell's slot in the fp64 slabs
+    if constexpr (PREC == 1) exp_tab_stage<NTH>(s_et, t);    // (published by the barrier after the staging)
+    double A[NT];
+    // PREC = 1: the fp64 pair distances of this thread's elements (the cell's slab, k_cell_dist64) travel straight into the
+    // registers that will hold the matrix (A is not live before the build): every load is in flight before the staging
+    // begins, as the fast build's are, and the build turns each register into its covariance in place.  (Issued inside the
+    // build loop, one dependent load per exponential, they cost the fp64 build 8.5 of its 11.4 ms over the fast one on the C2
+    // tile.)  Plain loads, not streaming ones: the other months of the cell read the same slab from the L2.
+    if constexpr (PREC == 1) {
+        const double *d64 = ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + ((tc % 16) * 16 + tr);
+        sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, uk_nbc<NW>(a)>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                constexpr int j0 = CB * b;
+                A[uk_eidx<NW>(a, b)] = __hip_atomic_load(&d64[tri(a, j0 / 16) * 256 + (j0 % 16) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            });
+        });
+    }
     if constexpr (!PREC) {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
@@ -628,7 +663,7 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
             if constexpr (PREC) {
-                if constexpr (PREC == 1) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + q] * ninv);
+                if constexpr (PREC == 1) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + q] * ninv, twx_exp2_tab);
                 else {
                     const double sp = st.sph[j], cp = st.cph[j];
                     double *tq = &s_trig[q * 5];
@@ -654,7 +689,6 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
     // Straight-line: fma, v_exp_f32, convert per element.  A row outside the neighbourhood has c = -inf (its
     // elements come out 0); j <= i < k makes a column test unnecessary below the diagonal, and what lies above
     // the diagonal inside the diagonal blocks is never read by the elimination.
-    double A[NT];
     const bool rhs_row = tr >= 9;                             // of the last block row: rows NP-7..NP-1
     const double *rhs = &s_B[rhs_row ? tr - 9 : 0][tc];       // (s_B is 0 from column k on)
     sfor<0, NB>([&](auto a_) __attribute__((always_inline)) {
@@ -669,10 +703,8 @@ void k_uk(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int3
             // not multiplied by -inf)
             double v;
             if constexpr (PREC) {
-                constexpr int j0 = CB * b;
-                if constexpr (PREC == 1)   // the cell's fp64 pair distances (k_cell_dist64): one coalesced load + the exponential
-                    v = (i < k && j < i) ? psill_e * exp_neg_f64(ws.dist64[fs * (int64_t)(TWX_DIST_BLOCKS * 256) + tri(a, j0 / 16) * 256 +
-                                                                          ((j0 % 16) + (tc % 16)) * 16 + tr] * ninv) : 0.0;
+                if constexpr (PREC == 1)   // the cell's fp64 pair distance (loaded above) -> covariance
+                    v = (i < k && j < i) ? psill_e * exp_neg_f64(A[e] * ninv, s_et) : 0.0;
                 else v = (i < k && j < i) ? cov_pair_f64(&s_trig[i * 5], &s_trig[j * 5], ninv, psill_e) : 0.0;
             } else v = (double)(a == NB - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
             // rows / columns k .. NP-8 are padding: an identity block there makes every panel a full 4-column
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(256) void k_uk_solve(SelWs ws)
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (item >= ws.ncell * 12) return;
     const int64_t lc = item / 12;
-    if (ws.kk[item] <= 0) return;
+    if (ws.kk[item] <= 0 || (ws.rerun && !ws.rerun[lc])) return;
     const double *Sp = ws.uk_S + item * TWX_UK_SLEN;
     double S[7][7];
 #pragma unroll

@@ -42,6 +42,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     __shared__ __attribute__((aligned(16))) double s_pan[NP * PS];
     __shared__ __attribute__((aligned(16))) double s_raw[NP * 4];
     __shared__ double s_B[7][NP];
+    __shared__ double s_et[PREC ? TWX_EXP_TAB_N : 1];       // PREC: the table of exp_neg_f64 (twx_uk.h)
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
     // worst-case grid, device-side item count (see k_uk)
@@ -78,9 +79,25 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
         h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     float hd[PREC ? 1 : NT];
+    double A[NT];
+    if constexpr (PREC) exp_tab_stage<64>(s_et, lane);     // (one wave: its LDS operations execute in order; the barrier after the staging publishes it)
     const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
     const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) the cell's slot in the fp64 slabs
-    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr) : nullptr;
+    // PREC: the fp64 pair distances of this lane's elements travel straight into the registers that will hold the matrix
+    // (A is not live before the build): every load is in flight before the staging begins, as the fast build's are -- the
+    // build then turns each register into its covariance in place.  (Issued inside the build loop, one dependent load per
+    // exponential, they cost the fp64 build 8.5 of its 11.4 ms over the fast one on the C2 tile.)  Plain loads, not
+    // streaming ones: the other months of the cell read the same slab from the L2.
+    if constexpr (PREC) {
+        const double *d64 = ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                A[widx(a, b)] = __hip_atomic_load(&d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            });
+        });
+    }
     if constexpr (!PREC) {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
@@ -108,7 +125,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv, twx_exp2_tab);
             else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
@@ -125,7 +142,6 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
     //      Straight-line: fma, v_exp_f32, convert per element (cov_exp2).  A row outside the neighbourhood has
     //      c = -inf (its elements come out 0); j <= i < k makes a column test unnecessary below the diagonal, and
     //      what lies above the diagonal is never read by the elimination.
-    double A[NT];
     const bool rhs_row = tr >= R0 && tr < R0 + 7;             // of the last block row: rows RHS0..RHS0+6
     const double *rhs = &s_B[rhs_row ? tr - R0 : 0][tc];      // (s_B is 0 from column k on)
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
@@ -138,7 +154,7 @@ void k_ukw(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const int
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
             double v;
-            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16] * ninv) : 0.0;
+            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(A[widx(a, b)] * ninv, s_et) : 0.0;
             else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
             // rows / columns k .. RHS0-1 are padding: an identity block there makes every panel a full 4-column
             // panel (pivot 1, factors 0), so the panel step has no special cases
@@ -285,6 +301,7 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
     __shared__ __attribute__((aligned(16))) double s_pan[NPX * PS];
     __shared__ __attribute__((aligned(16))) double s_raw[NPX * 4];
     __shared__ double s_B[7][NP];
+    __shared__ double s_et[PREC ? TWX_EXP_TAB_N : 1];       // PREC: the table of exp_neg_f64 (twx_uk.h)
 
     const int lane = threadIdx.x, tr = lane & 15, tc = lane >> 4;
     const int it = xcd_contig(blockIdx.x, *nitems_dev);
@@ -316,9 +333,25 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
         h0q[u] = __hip_atomic_load(&ws.h0[lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     float hd[PREC ? 1 : NT];
+    double A[NT];
+    if constexpr (PREC) exp_tab_stage<64>(s_et, lane);     // (one wave: its LDS operations execute in order; the barrier after the staging publishes it)
     const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
     const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) the cell's slot in the fp64 slabs
-    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr) : nullptr;
+    // PREC: the fp64 pair distances of this lane's elements travel straight into the registers that will hold the matrix
+    // (A is not live before the build): every load is in flight before the staging begins, as the fast build's are -- the
+    // build then turns each register into its covariance in place.  (Issued inside the build loop, one dependent load per
+    // exponential, they cost the fp64 build 8.5 of its 11.4 ms over the fast one on the C2 tile.)  Plain loads, not
+    // streaming ones: the other months of the cell read the same slab from the L2.
+    if constexpr (PREC) {
+        const double *d64 = ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                A[widx(a, b)] = __hip_atomic_load(&d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            });
+        });
+    }
     if constexpr (!PREC) {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc * 16 + tr);
         sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
@@ -345,7 +378,7 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             yv = mr.y;
             const float h0 = h0q[u];                           // cell -> station distance (k_cell_dist)
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv, twx_exp2_tab);
             else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
@@ -359,7 +392,7 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
 
     // ---- build (negated: the registers hold N = -M): C with an identity block in rows / columns k .. NP-1, and the
     //      border transposed: Z[a][h] = -B[tc + 4h][16a + tr] (0 for the dummy column 7 and from row k on)
-    double A[NT], Z[NBR][2], Sacc[2] = {0.0, 0.0};
+    double Z[NBR][2], Sacc[2] = {0.0, 0.0};
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
         constexpr int a = decltype(a_)::value;
         const int i = 16 * a + tr;
@@ -370,7 +403,7 @@ void k_ukwz(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             // (the last block row may lie outside what k_cell_dist has written: stale memory is selected away there,
             // not multiplied by -inf)
             double v;
-            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4)) * 16] * ninv) : 0.0;
+            if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(A[widx(a, b)] * ninv, s_et) : 0.0;
             else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[widx(a, b)], chi, lgp) : 0.f) : cov_exp2(hd[widx(a, b)], ca, lgp));
             if (b >= 4 * a && i == j) v = i < k ? c00 : 1.0;
             A[widx(a, b)] = -v;
@@ -520,6 +553,7 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
     __shared__ __attribute__((aligned(16))) double s_pan[2][NP * PS + 2];
     __shared__ __attribute__((aligned(16))) double s_raw[2][NPS * 4];
     __shared__ double s_B[2][7][NP];
+    __shared__ double s_et[PREC ? TWX_EXP_TAB_N : 1];       // PREC: the table of exp_neg_f64 (twx_uk.h)
 
     const int lane = threadIdx.x, tr = lane & 15, tc2 = (lane >> 4) & 1, l32 = lane & 31, sys = lane >> 5;
     const int nitems = *nitems_dev;
@@ -561,9 +595,21 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
         h0q[u] = __hip_atomic_load(&ws.h0[(int64_t)lc * ws.ksel + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     float hd[PREC ? 1 : 2 * NT];
+    double A[2 * NT];
+    if constexpr (PREC) exp_tab_stage<64>(s_et, lane);     // (one wave: its LDS operations execute in order; the barrier after the staging publishes it)
     const double ninv = rng == 0.0 ? 0.0 : -1.0 / rng;       // (PREC)
     const int64_t fs = PREC ? (int64_t)ws.cellf64[lc] - 1 : 0;   // (PREC) this half's cell's slot in the fp64 slabs
-    const double *d64 = PREC ? ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr) : nullptr;
+    if constexpr (PREC) {   // (the fp64 pair distances go straight into the matrix registers: see k_ukw)
+        const double *d64 = ws.dist64 + fs * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr);
+        sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_)::value;
+            sfor<0, 4 * a + 4>([&](auto b_) __attribute__((always_inline)) {
+                constexpr int b = decltype(b_)::value;
+                A[2 * widx(a, b) + 0] = __hip_atomic_load(&d64[(tri(a, b / 4) * 16 + 4 * (b % 4) + 0) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                A[2 * widx(a, b) + 1] = __hip_atomic_load(&d64[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            });
+        });
+    }
     if constexpr (!PREC) {
         const float *dist = ws.dist + lc * (int64_t)(TWX_DIST_BLOCKS * 256) + (tc2 * 16 + tr);
         sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
@@ -592,7 +638,7 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
             yv = mr.y;
             const float h0 = h0q[u];
             const bool same = (lo == cv.lon && la == cv.lat) || h0 == 0.f;
-            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv);
+            if constexpr (PREC) c0v = same ? c00 : psill_e * exp_neg_f64(ws.h064[fs * ws.ksel + t] * ninv, twx_exp2_tab);
             else c0v = same ? c00 : (double)cov_exp2(h0, chi, lgp);
         }
         if (t < NP) {
@@ -605,7 +651,6 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
     __syncthreads();
 
     // ---- build (negated) ----------------------------------------------------------------------------------------
-    double A[2 * NT];
     const bool rhs_row = tr >= R0 && tr < R0 + 7;
     const double *rhs = &sB[rhs_row ? tr - R0 : 0][tc2];
     sfor<0, NBR>([&](auto a_) __attribute__((always_inline)) {
@@ -619,7 +664,7 @@ void k_ukw2(StnDev st, CellSrc src, SelWs ws, const int32_t *item_list, const in
                 constexpr int e = 2 * widx(a, b) + q;
                 const int j = 4 * b + 2 * q + tc2;
                 double v;
-                if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(d64[(tri(a, b / 4) * 16 + 4 * (b % 4) + 2 * q) * 16] * ninv) : 0.0;
+                if constexpr (PREC) v = (i < k && j < i) ? psill_e * exp_neg_f64(A[e] * ninv, s_et) : 0.0;
                 else v = (double)(a == NBR - 1 ? (i < k ? cov_exp2(hd[e], chi, lgp) : 0.f) : cov_exp2(hd[e], ca, lgp));
                 if (b >= 4 * a && i == j) v = i < k ? c00 : (i < RHS0 ? 1.0 : 0.0);
                 if (a == NBR - 1) v = rhs_row ? rhs[4 * b + 2 * q] : v;

@@ -193,18 +193,76 @@ def gather_mosaic_device(buf, assignment, shape, tile_y, tile_x, rank, world, ke
     return mosaic
 
 
+class PrecisionPolicy(object):
+    """Which covariance build a streamed run uses (``Context.set_precision``), decided once per run.
+
+      "fast"   the default routing: fp32 pair distances, only ill-conditioned systems and tie-guard cells on the fp64 build
+               (normals within ~2e-6 degC of an fp64 evaluation, ~2e-5 of the packed int16 days one count off);
+      "exact"  every system on the fp64 build: outputs equal an fp64 evaluation of the reference's formulas to the last
+               int16 / f4 bit (tests/tools/gpu_full_tile_parity.py --f64), ~1.3 x the kriging time;
+      "auto"   "exact" for as long as it is FREE: a streamed run is bound by the copy-out of its outputs whenever they are
+               large (daily tiles: the GPU idles ~70 % of the wall), and then the fp64 build costs no wall time.  The run
+               starts exact; each of the first tiles' device time is compared with its copy-out time (``TileStream.times``),
+               and if the kernels are NOT hidden behind the copy (device > 0.9 x copy: normals-only tiles) the rest of the
+               run is fast.
+
+    ``mode`` is the build the NEXT submitted tile gets; ``observe`` is fed every finished tile; ``summary()`` is what the tile
+    logs record.  ``close()`` leaves the context in the "fast" mode."""
+    PROBE = 2                                   # exact tiles looked at before "auto" stops looking
+
+    def __init__(self, ctx, requested="auto"):
+        if requested not in ("auto", "fast", "exact"):
+            raise ValueError("precision must be 'auto', 'fast' or 'exact'")
+        self.ctx, self.requested = ctx, requested
+        self.mode = "fast" if requested == "fast" else "exact"
+        self.decided = requested != "auto"
+        self.decision = "as requested" if self.decided else "exact throughout: every probed tile's kernels were hidden behind its copy-out"
+        self.seen = {"exact": [0, 0.0, 0.0], "fast": [0, 0.0, 0.0]}     # tiles, device ms, copy ms by the mode they ran in
+        self.tile_modes = {}
+        ctx.set_precision(self.mode)
+
+    def observe(self, tile_mode, device_ms, copy_ms, tile=None):
+        if tile is not None:
+            self.tile_modes[tile] = tile_mode
+        rec = self.seen[tile_mode]
+        rec[0] += 1; rec[1] += device_ms; rec[2] += copy_ms
+        if self.decided or tile_mode != "exact":
+            return
+        if device_ms > 0.9 * copy_ms:
+            self.mode, self.decided = "fast", True
+            self.decision = ("fast after %d tile(s): the kernels of an exact tile (%.2f ms) are not hidden behind its copy-out "
+                             "(%.2f ms)" % (self.seen["exact"][0] + self.seen["fast"][0], device_ms, copy_ms))
+            self.ctx.set_precision("fast")
+        elif rec[0] >= self.PROBE:
+            self.decided = True
+
+    def summary(self):
+        nt = self.seen["exact"][0] + self.seen["fast"][0]
+        return {"requested": self.requested, "precision": self.mode, "tiles_exact": self.seen["exact"][0],
+                "tiles_fast": self.seen["fast"][0], "device_ms_mean": (self.seen["exact"][1] + self.seen["fast"][1]) / max(nt, 1),
+                "copy_ms_mean": (self.seen["exact"][2] + self.seen["fast"][2]) / max(nt, 1), "decision": self.decision,
+                "tile_modes": dict(self.tile_modes)}
+
+    def close(self):
+        self.ctx.set_precision("fast")
+
 
 def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
-                          writer_threads=1, tile_ms=None):
+                          writer_threads=1, tile_ms=None, precision="auto", log=None):
     """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
     tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
     workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
     returns (they are views of a pinned slot that is reused two tiles later); default: collect copies.
     All tiles must have the shape tile_y x tile_x.  ``tile_ms``: a list that receives ``(tile_number, device_ms)`` per tile.
+
+    ``precision``: "auto" | "fast" | "exact", see ``PrecisionPolicy`` -- auto = the fp64 covariance build (outputs exact to the
+    last int16 / f4 bit) whenever the tiles' kernels hide behind their copy-out, i.e. for free.  ``log``: a dict that receives
+    the policy's summary (the mode the run ended in, tiles per mode, mean device / copy ms, the decision in words).
     Returns (results or None, seconds, device_ms)."""
     import queue
     import threading
     import time
+    policy = PrecisionPolicy(ctx, precision)
     collected = {}
     if sink is None:
         def sink(k, arrays):
@@ -233,32 +291,35 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     t0 = time.perf_counter()
     dev_ms = 0.0
     pending = None
+
+    def collect(pk, pslot, pmode):
+        nonlocal dev_ms
+        out = st.wait(pslot)                    # tile t is on the host; tile t + 1 is already running
+        ms = out.pop("device_ms")
+        dev_ms += ms
+        policy.observe(pmode, ms, st.times(pslot)[1], tile=pk)
+        if tile_ms is not None:
+            tile_ms.append((pk, ms))
+        q.put((pk, pslot, out))
+
     try:
         for n, (k, i, j, _) in enumerate(tiles):
             slot = n % nslots
             free[slot].acquire()                # the writer is done with this slot's previous tile
+            submitted_as = policy.mode
             st.submit(slot, grid, slice(i, i + tile_y), slice(j, j + tile_x))
             if pending is not None:
-                pk, pslot = pending
-                out = st.wait(pslot)            # tile t is on the host; tile t + 1 is already running
-                ms = out.pop("device_ms")
-                dev_ms += ms
-                if tile_ms is not None:
-                    tile_ms.append((pk, ms))
-                q.put((pk, pslot, out))
-            pending = (k, slot)
+                collect(*pending)
+            pending = (k, slot, submitted_as)
         if pending is not None:
-            pk, pslot = pending
-            out = st.wait(pslot)
-            ms = out.pop("device_ms")
-            dev_ms += ms
-            if tile_ms is not None:
-                tile_ms.append((pk, ms))
-            q.put((pk, pslot, out))
+            collect(*pending)
     finally:
         q.put(None)
         th.join()
         st.close()
+        policy.close()
+    if log is not None:
+        log.update(policy.summary())
     if err:
         raise err[0]
     return (collected if collected else None), time.perf_counter() - t0, dev_ms

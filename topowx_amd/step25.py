@@ -24,7 +24,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .driver import assign_tiles, tile_list
+from .driver import PrecisionPolicy, assign_tiles, tile_list
 from .interp import PtInterpTair, Tiler
 from .interp.interp_tair import chunk_to_grid
 
@@ -93,8 +93,15 @@ def _write_tile(out_dir, out_format, info, tile_id, store, days):
 
 
 def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, daily=True, out_dir=None,
-              rank=0, world=1, device=0, out_format="npz", check_tiles_done=True, keep=None, log=None):
+              rank=0, world=1, device=0, out_format="npz", check_tiles_done=True, keep=None, log=None, precision="fast"):
     """Interpolate the tiles of this rank chunk by chunk.
+
+    ``precision``: "fast" (default) | "exact" | "auto" (``driver.PrecisionPolicy``): exact = every kriging system on the fp64
+    covariance build -- outputs equal an fp64 evaluation to the last int16 / f4 bit; auto = exact for as long as the chunks'
+    kernels hide behind their copy-out to the host, else fast.  The mode a tile's last chunk ran in is part of its log record;
+    a run that was not asked for "fast" ends with one more record, the policy's summary (``{"requested": ..., "precision": ...}``).
+    (The default stays "fast" here, unlike ``driver.interp_tiles_streamed``: 50 x 50 chunks are too small to hide their kernels
+    behind their copy-out, and a resumed run should redo a tile in the mode it was first written in.)
 
     Returns ``{tile_id: TileStore}`` of the tiles kept in memory (``keep``; default: only when nothing is written
     to ``out_dir``).  ``log``: a callable or file object receiving one JSON line per tile (default: none); the
@@ -117,6 +124,7 @@ def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, dail
     pt_interp = PtInterpTair(stn_da_tmin, stn_da_tmax, norms_only=not daily, device=device)   # step25:53-55
     days = pt_interp.days
     stream = pt_interp.ctx.stream(chunk_size, chunk_size, daily=daily, nslots=2)
+    policy = PrecisionPolicy(pt_interp.ctx, precision)
     stores, open_tiles, pending = {}, {}, None
 
     def emit(rec):
@@ -126,8 +134,9 @@ def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, dail
             log(line) if callable(log) else log.write(line + "\n")
 
     def finish(p):
-        slot, tile_id, str_row, str_col = p
+        slot, tile_id, str_row, str_col, mode = p
         out = stream.wait(slot)                                                    # outputs of that chunk are on the host
+        policy.observe(mode, out["device_ms"], stream.times(slot)[1])
         st = open_tiles[tile_id]
         st["store"].write_tile_chunk(str_row, str_col, out)                        # step25:181-185
         st["device_ms"] += out["device_ms"]
@@ -140,7 +149,7 @@ def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, dail
                 _write_tile(out_dir, out_format, info, tile_id, store, days)
             emit({"tile": tile_id, "rank": rank, "cells": int((status != -1).sum()), "ok": int((status == 0).sum()),
                   "failures": {int(c): int(n) for c, n in zip(codes, counts)}, "device_ms": round(st["device_ms"], 3),
-                  "bytes": store.nbytes(), "seconds": round(time.perf_counter() - st["t0"], 3)})
+                  "bytes": store.nbytes(), "seconds": round(time.perf_counter() - st["t0"], 3), "precision": mode})
             if keep:
                 stores[tile_id] = store
             del open_tiles[tile_id]
@@ -153,15 +162,19 @@ def proc_work(grid, stn_da_tmin, stn_da_tmax, tile_size=250, chunk_size=50, dail
                                        "device_ms": 0.0, "t0": time.perf_counter()}
             str_row, str_col = int(wrk_chk[0, 0, 0]), int(wrk_chk[1, 0, 0])          # step25:110-111
             slot = n & 1
+            mode = policy.mode
             stream.submit(slot, chunk_to_grid(wrk_chk))                              # step25:126-172 in one call, asynchronous
             if pending is not None:
                 finish(pending)                                                      # overlaps the chunk just submitted
-            pending = (slot, tile_id, str_row, str_col)
+            pending = (slot, tile_id, str_row, str_col, mode)
         if pending is not None:
             finish(pending)
     finally:
         stream.close()
+        policy.close()
         pt_interp.close()
+    if precision != "fast":
+        emit(dict(policy.summary(), rank=rank))
     proc_work.last_log = records
     return stores
 
