@@ -96,6 +96,11 @@ def parse():
     ap.add_argument("--c4-rows", type=int, default=0, help="c4 record on a cut of the grid (tests; 0 = the full 3250x7000 grid)")
     ap.add_argument("--c4-cols", type=int, default=0)
     ap.add_argument("--c4-years", type=int, default=69, help="c4 record: years of days from 1948 (69 = 1948-2016, 25 203 days)")
+    ap.add_argument("--c4-precision", default="auto", choices=("auto", "fast", "exact"),
+                    help="c4 record: covariance build of the streamed run (driver.PrecisionPolicy; auto = exact while it is free)")
+    ap.add_argument("--c4-sink-tiles", type=int, default=8, help="c4 record: tiles written into NetCDF-4 tile files by ncio.TileSink (0 = skip)")
+    ap.add_argument("--c4-sink-dir", default=None, help="where (default: /dev/shm when it has 20 GB free, else $TMPDIR)")
+    ap.add_argument("--c4-sink-threads", type=int, default=0, help="TileSink workers (0 = min(64, cpu count))")
     ap.add_argument("--force-configs", action="store_true", help="time them also on a reduced --size (tests)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
                     help="auto: N = 1 headline (+ configs); N > 1 weak headline + a 'strong' record.  strong: the tile farm "
@@ -654,9 +659,10 @@ def c4_full_record(env, args):
                                                                             "se_tmin", "se_tmax", "ninvalid", "status")}
 
     driver.interp_tiles_streamed(ctx, grid, mine[:1], T, T, daily=True, sink=lambda k, a: None)     # warm-up: workspace, pinned slots
-    tile_ms = []
+    tile_ms, plog = [], {}
     t0 = time.perf_counter()
-    _, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, mine, T, T, daily=True, sink=sink, tile_ms=tile_ms)
+    _, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, mine, T, T, daily=True, sink=sink, tile_ms=tile_ms,
+                                                   precision=args.c4_precision, log=plog)
     wall = time.perf_counter() - t0
     ms = np.array([m for _, m in tile_ms])
     units = acc["ok"] * nd * 2
@@ -671,6 +677,7 @@ def c4_full_record(env, args):
            "device_only_cell_days_per_s": units / (dev_ms * 1e-3), "device_ms_total": dev_ms,
            "device_ms_per_tile": {"min": float(ms.min()), "median": float(np.median(ms)), "max": float(ms.max())},
            "d2h_bytes": acc["bytes"], "d2h_GBps": acc["bytes"] / wall / 1e9,
+           "precision": {k: v for k, v in plog.items() if k != "tile_modes"},
            "setup_s": setup_s}
     if not args.no_cpu_baseline and kept:
         from oracle import pyoracle as orc
@@ -695,7 +702,76 @@ def c4_full_record(env, args):
         rec["spot_check_vs_oracle"] = {"cells": len(kept), "tiles": len(picks), "tile_valid_cells": [mine[q][3] for q in pick_tiles],
                                        "normals_max_abs_degC": worst_n, "int16_max_abs_lsb": worst_lsb,
                                        "int16_values": nvals, "int16_differing": flips, "ninvalid_equal": ninv_eq, "status_equal": stat_eq}
+    if args.c4_sink_tiles > 0:
+        rec["sink"] = c4_sink_record(ctx, grid, mine[:args.c4_sink_tiles], T, days, args)
     ctx.close()
+    return rec
+
+
+def host_page_rates(path, threads, gb=4.0):
+    """What the host gives a writer of NEW file pages: ``threads`` workers fill disjoint parts of a fresh ``gb``-GB file under
+    ``path`` through one shared mmap (cold: every page is allocated by its first touch), then once more (warm).  GB/s each --
+    the ceiling of any sink into that file system, named beside the sink's own rate."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = int(gb * 1e9) // (threads * 4096) * (threads * 4096)
+    fp = os.path.join(path, "twx_page_rate.bin")
+    with open(fp, "wb") as f:
+        f.truncate(n)
+    mm = np.memmap(fp, dtype=np.uint8, mode="r+")
+    part = n // threads
+    out = {}
+    with ThreadPoolExecutor(threads) as pool:
+        for name, val in (("cold", 1), ("warm", 2)):
+            t0 = time.perf_counter()
+            list(pool.map(lambda i: mm[i * part:(i + 1) * part].fill(val), range(threads)))
+            out[name + "_GBps"] = n / (time.perf_counter() - t0) / 1e9
+    del mm
+    os.remove(fp)
+    return out
+
+
+def c4_sink_record(ctx, grid, tiles, T, days, args):
+    """the tiles of configs[3] into the reference's per-tile NetCDF-4 files (tiling.py:304-537: chunked
+    ``(ndays, 50, 50)`` int16, uncompressed as the reference's tiles are) through ``ncio.TileSink`` as the sink of
+    ``driver.interp_tiles_streamed``, against the same tiles into a discarding sink.  Every tile's files are deleted once written
+    (and, the first one, read back through libhdf5 and compared with the pinned block the GPU's outputs arrived in): a run of
+    8 tiles is 50 GB.  Also two tiles deflated (shuffle + zlib level 1, as the reference's MOSAICS are stored)."""
+    import shutil
+    from topowx_amd import driver, ncio
+    from topowx_amd.interp import Tiler
+    base = args.c4_sink_dir
+    if base is None:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 20e9 else os.environ.get("TMPDIR", "/tmp")
+    out_dir = os.path.join(base, "twx_c4_sink_%d" % os.getpid())
+    info = Tiler(grid, T, T, 50, 50, process_tiles=()).build_tile_grid_info()
+    threads = args.c4_sink_threads or min(64, os.cpu_count() or 8)
+    rec = {"dir": base, "tiles": len(tiles), "threads": threads, "host_cpus": os.cpu_count(),
+           "layout": "<tile_id>/<tile_id>_<var>.nc, NetCDF-4, daily int16 chunked (%d, 50, 50), normals / SE f4, inconsist_tair i4" % days.size}
+    try:
+        _, wall0, _ = driver.interp_tiles_streamed(ctx, grid, tiles, T, T, daily=True, sink=lambda k, a: None, precision=args.c4_precision)
+        rec["wall_discarding_sink_s"] = wall0
+        for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2])):
+            sink = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), **kw)
+
+            def write_and_drop(k, arrays, sink=sink):
+                sink(k, arrays)
+                shutil.rmtree(os.path.join(out_dir, info.get_tile_id(k)), ignore_errors=True)
+            _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write_and_drop, precision=args.c4_precision)
+            sink.close()
+            st = sink.stats
+            rec[name] = {"tiles": st["tiles"], "wall_s": wall, "int16_GB": st["int16_bytes"] / 1e9, "on_disk_GB": st["disk_bytes"] / 1e9,
+                         "int16_GBps_end_to_end": st["int16_bytes"] / wall / 1e9, "on_disk_GBps_end_to_end": st["disk_bytes"] / wall / 1e9,
+                         "sink_busy_s": st["total_s"], "of_it_file_creation_s": st["create_s"], "of_it_bulk_copy_s": st["copy_s"],
+                         "int16_GBps_while_sink_busy": st["int16_bytes"] / max(st["total_s"], 1e-9) / 1e9,
+                         "tiles_read_back_equal": st["verified"]}
+        rec["host_new_page_rate"] = host_page_rates(base, threads)
+        n4 = rec["netcdf4"]
+        rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files against %.1f GB/s into a discarding sink; the host "
+                                 "allocates new file pages at %.1f GB/s with %d threads (cold mmap fill) -- the bulk copy ran at %.1f GB/s"
+                                 % (n4["int16_GBps_end_to_end"], n4["int16_GB"] / wall0, rec["host_new_page_rate"]["cold_GBps"], threads,
+                                    n4["int16_GB"] / max(n4["of_it_bulk_copy_s"], 1e-9)))
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
     return rec
 
 

@@ -51,6 +51,11 @@ H5D_CHUNKED = 2
 H5_INDEX_NAME, H5_INDEX_CRT_ORDER, H5_ITER_INC = 0, 1, 0
 H5T_SGN_NONE = 0
 H5Z_FILTER_DEFLATE, H5Z_FILTER_SHUFFLE = 1, 2
+H5D_ALLOC_TIME_EARLY, H5D_FILL_TIME_NEVER = 1, 1
+HADDR_UNDEF = (1 << 64) - 1
+# netCDF's default fill values (netcdf.h NC_FILL_*; netCDF4.default_fillvals)
+DEFAULT_FILLS = {"i1": -127, "u1": 255, "i2": -32767, "u2": 65535, "i4": -2147483647, "u4": 4294967295,
+                 "i8": -9223372036854775806, "u8": 18446744073709551614, "f4": 9.969209968386869e36, "f8": 9.969209968386869e36}
 NOT_A_VAR = "This is a netCDF dimension but not a netCDF variable."
 NON_COORD = "_nc4_non_coord_"
 HIDDEN = {"CLASS", "NAME", "REFERENCE_LIST", "DIMENSION_LIST", "_Netcdf4Dimid", "_Netcdf4Coordinates",
@@ -106,6 +111,17 @@ def _load():
         if lib is None or hl is None:
             _LIB = False
             return _LIB
+        # the bindings below are those of HDF5 >= 1.10 (64-bit hid_t; the library globals are read as 8 bytes): an older
+        # library would hand back truncated ids and garbage type handles -- treat it as absent (classic netCDF fallback)
+        try:
+            lib.H5get_libversion.restype, lib.H5get_libversion.argtypes = herr_t, [C.POINTER(C.c_uint)] * 3
+            a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+            if lib.H5get_libversion(C.byref(a), C.byref(b), C.byref(c)) < 0 or (a.value, b.value) < (1, 10):
+                _LIB = False
+                return _LIB
+        except AttributeError:
+            _LIB = False
+            return _LIB
         _declare(lib, hl)
         if lib.H5open() < 0:
             _LIB = False
@@ -156,6 +172,8 @@ def _declare(lib, hl):
         "H5Pget_nfilters": (C.c_int, [hid_t]),
         "H5Pget_filter2": (C.c_int, [hid_t, C.c_uint, P(C.c_uint), P(C.c_size_t), P(C.c_uint), C.c_size_t, cp, P(C.c_uint)]),
         "H5Pset_chunk_cache": (herr_t, [hid_t, C.c_size_t, C.c_size_t, C.c_double]),
+        "H5Pset_alloc_time": (herr_t, [hid_t, C.c_int]), "H5Pset_fill_time": (herr_t, [hid_t, C.c_int]),
+        "H5Pset_alignment": (herr_t, [hid_t, hsize_t, hsize_t]),
         "H5Screate": (hid_t, [C.c_int]), "H5Screate_simple": (hid_t, [C.c_int, P(hsize_t), P(hsize_t)]),
         "H5Sclose": (herr_t, [hid_t]), "H5Sget_simple_extent_ndims": (C.c_int, [hid_t]),
         "H5Sget_simple_extent_dims": (C.c_int, [hid_t, P(hsize_t), P(hsize_t)]),
@@ -182,6 +200,15 @@ def _declare(lib, hl):
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
+    opt = {   # direct chunk access: H5Dwrite_chunk since 1.10.3, the chunk queries since 1.10.5 (Variable.write_chunk_raw / chunk_info)
+        "H5Dwrite_chunk": (herr_t, [hid_t, hid_t, C.c_uint32, P(hsize_t), C.c_size_t, vp]),
+        "H5Dget_num_chunks": (herr_t, [hid_t, hid_t, P(hsize_t)]),
+        "H5Dget_chunk_info": (herr_t, [hid_t, hid_t, hsize_t, P(hsize_t), P(C.c_uint), P(C.c_uint64), P(hsize_t)]),
+    }
+    for name, (res, args) in opt.items():
+        f = getattr(lib, name, None)
+        if f is not None:
+            f.restype, f.argtypes = res, args
     hsig = {
         "H5DSset_scale": (herr_t, [hid_t, cp]), "H5DSattach_scale": (herr_t, [hid_t, hid_t, C.c_uint]),
         "H5DSis_scale": (C.c_int, [hid_t]), "H5DSget_num_scales": (C.c_int, [hid_t, C.c_uint]),
@@ -414,6 +441,45 @@ class Variable(_Attrs):
                 lib.H5Pclose(p)
         return out
 
+    # ---- direct chunk access (no netCDF4-python counterpart; HDF5 >= 1.10.5) -----------------------------------------------
+    def chunk_info(self):
+        """{chunk offset (tuple of element indices): (file address, stored bytes, filter mask)} of the chunks that exist in
+        the file.  For a variable created with ``alloc_early`` these are ALL chunks, at their final addresses: once the file
+        has been flushed or closed their bytes may be written straight into it (the file has no user block)."""
+        lib, _ = _need()
+        if getattr(lib.H5Dget_chunk_info, "argtypes", None) is None:
+            raise H5Error("this libhdf5 (%s) has no H5Dget_chunk_info (needs >= 1.10.5)" % library_version())
+        out = OrderedDict()
+        with _LOCK:
+            fs = lib.H5Dget_space(self._loc())
+            try:
+                n = hsize_t()
+                _chk(lib.H5Dget_num_chunks(self._loc(), fs, C.byref(n)), "H5Dget_num_chunks(%s)" % self.name)
+                off = _dims(max(self.ndim, 1))
+                for i in range(int(n.value)):
+                    mask, addr, size = C.c_uint(), C.c_uint64(), hsize_t()
+                    _chk(lib.H5Dget_chunk_info(self._loc(), fs, hsize_t(i), off, C.byref(mask), C.byref(addr), C.byref(size)),
+                         "H5Dget_chunk_info(%s)" % self.name)
+                    if addr.value != HADDR_UNDEF:
+                        out[tuple(int(off[a]) for a in range(self.ndim))] = (int(addr.value), int(size.value), int(mask.value))
+            finally:
+                lib.H5Sclose(fs)
+        return out
+
+    def write_chunk_raw(self, offset, data, filter_mask=0):
+        """``H5Dwrite_chunk``: ``data`` (bytes-like) IS the stored form of the chunk at element offset ``offset`` -- for a
+        deflated variable the caller has shuffled and compressed it (``ncio.TileSink`` does that on a thread pool; the
+        library call is then a byte copy).  ``filter_mask``: bit i set = filter i of the pipeline was NOT applied."""
+        lib, _ = _need()
+        self._writable()
+        if getattr(lib.H5Dwrite_chunk, "argtypes", None) is None:
+            raise H5Error("this libhdf5 (%s) has no H5Dwrite_chunk (needs >= 1.10.3)" % library_version())
+        mv = memoryview(data).cast("B")
+        buf = (C.c_char * len(mv)).from_buffer_copy(mv) if mv.readonly else (C.c_char * len(mv)).from_buffer(mv)
+        with _LOCK:
+            _chk(lib.H5Dwrite_chunk(self._loc(), 0, C.c_uint32(filter_mask), _dims(self.ndim, offset), C.c_size_t(len(mv)), buf),
+                 "H5Dwrite_chunk(%s)" % self.name)
+
     # ---- hyperslab selection ------------------------------------------------------------------------------------
     def _select(self, key):
         if not isinstance(key, tuple):
@@ -530,11 +596,13 @@ class Variable(_Attrs):
 
 
 class Dataset(_Attrs):
-    """A NetCDF-4 file (root group only).  ``mode``: 'r', 'r+' / 'a' (must exist), 'w' (truncate)."""
+    """A NetCDF-4 file (root group only).  ``mode``: 'r', 'r+' / 'a' (must exist), 'w' (truncate).  ``alignment``
+    (mode 'w'): (threshold, alignment) in bytes -- file objects of at least ``threshold`` bytes start on a multiple of
+    ``alignment`` (``H5Pset_alignment``; ``ncio.TileSink`` puts the 126 MB chunks of a tile on page boundaries)."""
     _OWN = {"dimensions", "variables", "path", "mode"}
     data_model = "NETCDF4"
 
-    def __init__(self, path, mode="r", rdcc_nbytes=None):
+    def __init__(self, path, mode="r", rdcc_nbytes=None, alignment=None):
         lib, _ = _need()
         object.__setattr__(self, "_fid", None)
         self.path, self.mode = os.fspath(path), mode
@@ -548,8 +616,14 @@ class Dataset(_Attrs):
                 fcpl = lib.H5Pcreate(_g("H5P_CLS_FILE_CREATE_ID_g"))
                 lib.H5Pset_link_creation_order(fcpl, H5P_CRT_ORDER)
                 lib.H5Pset_attr_creation_order(fcpl, H5P_CRT_ORDER)
-                fid = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, fcpl, 0)
+                fapl = 0
+                if alignment is not None:
+                    fapl = lib.H5Pcreate(_g("H5P_CLS_FILE_ACCESS_ID_g"))
+                    _chk(lib.H5Pset_alignment(fapl, hsize_t(int(alignment[0])), hsize_t(int(alignment[1]))), "H5Pset_alignment")
+                fid = lib.H5Fcreate(self.path.encode(), H5F_ACC_TRUNC, fcpl, fapl)
                 lib.H5Pclose(fcpl)
+                if fapl:
+                    lib.H5Pclose(fapl)
                 _chk(fid, "H5Fcreate(%s)" % self.path)
                 object.__setattr__(self, "_fid", fid)
                 self.setncattr("_NCProperties", "version=2,hdf5=%s,writer=topowx_amd.h5nc" % library_version())
@@ -715,7 +789,12 @@ class Dataset(_Attrs):
         return name
 
     def createVariable(self, varname, datatype, dimensions=(), zlib=False, complevel=4, shuffle=True, chunksizes=None,
-                       fill_value=None, contiguous=False):
+                       fill_value=None, contiguous=False, alloc_early=False):
+        """netCDF4-python's ``createVariable``.  ``fill_value=None``: the type's netCDF default fill is the dataset's HDF5
+        fill value (never-written regions read back as it, as through netCDF-C) and no ``_FillValue`` attribute is written;
+        ``fill_value=False``: no fill value at all.  ``alloc_early`` (no netCDF4-python counterpart; chunked, unfiltered
+        variables): every chunk is allocated at creation and NOT pre-filled -- the caller writes all of them, possibly straight
+        into the file at the addresses of ``Variable.chunk_info()`` (``ncio.TileSink``)."""
         lib, hl = _need()
         self._writable()
         if isinstance(dimensions, str):
@@ -750,6 +829,9 @@ class Dataset(_Attrs):
             if fill_value is not None and fill_value is not False and kind == "num":
                 fill = np.array([fill_value]).astype(dtype)
                 _chk(lib.H5Pset_fill_value(dcpl, t, fill.ctypes.data_as(C.c_void_p)), "H5Pset_fill_value")
+            elif fill_value is None and kind == "num" and (dtype.kind + str(dtype.itemsize)) in DEFAULT_FILLS:
+                dfl = np.array([DEFAULT_FILLS[dtype.kind + str(dtype.itemsize)]]).astype(dtype)
+                _chk(lib.H5Pset_fill_value(dcpl, t, dfl.ctypes.data_as(C.c_void_p)), "H5Pset_fill_value")
             if shape and not contiguous and (chunksizes is not None or zlib):
                 if chunksizes is None:
                     chunksizes = _default_chunks(shape, dtype.itemsize if kind != "vstr" else 16)
@@ -760,6 +842,9 @@ class Dataset(_Attrs):
                     if shuffle and dtype.itemsize > 1:
                         lib.H5Pset_shuffle(dcpl)
                     _chk(lib.H5Pset_deflate(dcpl, int(complevel)), "H5Pset_deflate")
+                elif alloc_early and kind == "num":
+                    _chk(lib.H5Pset_alloc_time(dcpl, H5D_ALLOC_TIME_EARLY), "H5Pset_alloc_time")
+                    _chk(lib.H5Pset_fill_time(dcpl, H5D_FILL_TIME_NEVER), "H5Pset_fill_time")
             sp = lib.H5Screate_simple(len(shape), _dims(len(shape), shape), None) if shape else lib.H5Screate(H5S_SCALAR)
             if is_coord and varname in self._scale:
                 # a dimension-only placeholder of an earlier session is replaced by its coordinate variable

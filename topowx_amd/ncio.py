@@ -243,14 +243,14 @@ class _Classic(object):
             self.setncattr(name, value)
 
 
-def open_dataset(path, mode="r", format=None, rdcc_nbytes=None):
+def open_dataset(path, mode="r", format=None, rdcc_nbytes=None, alignment=None):
     """``netCDF4.Dataset(path, mode)`` on either container.  'w': ``format`` or ``default_format()``; otherwise the file's
-    own format (magic bytes)."""
+    own format (magic bytes).  ``alignment``: see ``h5nc.Dataset`` (NETCDF4 only)."""
     path = os.fspath(path)
     if mode == "w":
         fmt = format or default_format()
         if fmt == "NETCDF4":
-            return h5nc.Dataset(path, "w")
+            return h5nc.Dataset(path, "w", alignment=alignment)
         if fmt in ("NETCDF3_64BIT", "NETCDF3_CLASSIC"):
             return _Classic(path, "w", version=2 if fmt == "NETCDF3_64BIT" else 1)
         raise ValueError("format must be one of %r" % (FORMATS,))
@@ -358,21 +358,23 @@ class TileWriter(object):
     chunk shapes (``(ndays, chk_size_y, chk_size_x)`` for the daily variable, tiling.py:453-455); ``zlib`` is off as in
     the reference's tiles."""
 
-    def __init__(self, tile_grid_info, path_out, format=None, zlib=False):
+    def __init__(self, tile_grid_info, path_out, format=None, zlib=False, complevel=4):
         t = tile_grid_info
         self.tile_ids, self.tile_rc, self.ntiles = t.tile_ids, t.tile_rc, t.ntiles
         self.lons, self.lats = np.asarray(t.lons, np.float64), np.asarray(t.lats, np.float64)
         self.path_out = path_out
         self.tile_size_y, self.tile_size_x = t.tile_size_y, t.tile_size_x
         self.chk_size_y, self.chk_size_x = t.chk_size_y, t.chk_size_x
-        self.format, self.zlib = format, zlib
+        self.format, self.zlib, self.complevel = format, zlib, complevel
 
     def fpath(self, tile_id, varname):
         return os.path.join(self.path_out, tile_id, "%s_%s.nc" % (tile_id, varname))
 
-    def _create(self, fpath, tile_id, varname, days):
+    def _create(self, fpath, tile_id, varname, days, early=False):
+        """``early`` (NETCDF4, ``TileSink``): the daily variable's chunks are allocated at creation, on page boundaries, and
+        not pre-filled -- the caller writes every one of them."""
         os.makedirs(os.path.dirname(fpath), exist_ok=True)
-        ds = open_dataset(fpath, "w", self.format)
+        ds = open_dataset(fpath, "w", self.format, alignment=(1 << 20, 4096) if early else None)
         d0, d1 = _date(days, 0), _date(days, days.size - 1)
         ds.title = "Daily Interpolated Meteorological Data %d-%d" % (_ymd(d0), _ymd(d1))
         ds.institution = "University of Montana"
@@ -403,9 +405,9 @@ class TileWriter(object):
 
         long_name, vunits, std_name, cell_method = VAR_ATTRS[varname]
         cy, cx = min(self.chk_size_y, lats.size), min(self.chk_size_x, lons.size)
-        kw = dict(zlib=self.zlib)
+        kw = dict(zlib=self.zlib, complevel=self.complevel)
         mv = ds.createVariable(varname, "i2", ("time", "lat", "lon"), chunksizes=(int(days.size), cy, cx),
-                               fill_value=FILL_I2, **kw)
+                               fill_value=FILL_I2, **(dict(kw, alloc_early=True) if early and _is_nc4(ds) and not self.zlib else kw))
         mv.long_name, mv.units, mv.standard_name = long_name, vunits, std_name
         mv.scale_factor = SCALE_FACTOR
         mv.cell_methods = "area: mean time: " + cell_method
@@ -479,6 +481,138 @@ def read_tile_stores(path_in, tiles, variables=("tmin", "tmax")):
         if st is not None:
             stores[t] = st
     return stores
+
+
+class TileSink(object):
+    """``sink(tile_number, arrays)`` of ``driver.interp_tiles_streamed``: every finished tile goes into the reference's
+    per-tile NetCDF-4 files ``<path_out>/<tile_id>/<tile_id>_<var>.nc`` (``TileWriter``'s layout: tiling.py:304-537) at the
+    rate the host's memory system takes them, not at the rate of one ``H5Dwrite`` thread.
+
+    The reference's worker re-opens the tile's file for every 50 x 50 chunk and writes its ``(ndays, 50, 50)`` int16 block
+    through netCDF4-python (step25:177-185, tiling.py:488-537); a 250 x 250 tile of configs[3] is 25 such chunks of 126 MB
+    per variable, and one GPU produces a tile every ~0.12 s.  Here, per tile and variable:
+
+    * the file is created with the daily variable's chunks ALLOCATED AT CREATION on page boundaries and not pre-filled
+      (``h5nc``: ``alloc_early``), the small variables (normals, SE, inconsist_tair, coordinates) are written through the
+      library, the chunk addresses are read (``H5Dget_chunk_info``) and the file is closed;
+    * ``threads`` workers then copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
+      straight into the file's pages through one shared ``mmap`` -- each job one strided gather of a (days segment x chunk)
+      piece, numpy releases the GIL for it -- so the transposition into chunk order IS the write, and no HDF5 call touches
+      the 6.3 GB of a tile;
+    * ``zlib=True`` (the reference's tiles are not compressed; its mosaics are): the workers gather, byte-shuffle and
+      deflate each chunk (``zlib`` releases the GIL) and the sink's own thread appends the stored bytes with
+      ``H5Dwrite_chunk`` -- for the library a byte copy.
+
+    The files are complete NetCDF-4 files of the ``TileWriter`` layout (``read_tile`` / ``h5nc.Dataset`` / any HDF5 reader
+    open them; tests/test_ncio.py, tests/test_h5py_interop.py).  ``stats``: tiles, int16 bytes handed over, bytes on disk,
+    seconds in file creation / in the bulk copy / total.  ``verify``: tile numbers to read back through the library
+    and compare with what was handed over (``stats["verified"]``: number of tiles checked, raises on a difference)."""
+
+    def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None):
+        from concurrent.futures import ThreadPoolExecutor
+        if not h5nc.available():
+            raise IOError("TileSink needs libhdf5 (NetCDF-4 tiles); TileWriter writes classic netCDF without it")
+        self.info, self.path_out, self.days = tile_grid_info, path_out, days
+        self.writer = TileWriter(tile_grid_info, path_out, format="NETCDF4", zlib=zlib, complevel=complevel)
+        self.threads = int(threads or min(64, os.cpu_count() or 8))
+        self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
+        self.pool = ThreadPoolExecutor(self.threads)
+        cy, cx = tile_grid_info.chk_size_y, tile_grid_info.chk_size_x
+        nchunks = 2 * (tile_grid_info.tile_size_y // cy) * (tile_grid_info.tile_size_x // cx)
+        # enough jobs per tile to keep every worker busy: chunks are cut along the day axis
+        self.day_segments = int(day_segments or max(1, -(-2 * self.threads // max(nchunks, 1))))
+        self.stats = {"tiles": 0, "int16_bytes": 0, "disk_bytes": 0, "create_s": 0.0, "copy_s": 0.0, "total_s": 0.0,
+                      "verified": 0, "threads": self.threads, "zlib": self.zlib, "complevel": self.complevel if zlib else None}
+
+    @staticmethod
+    def _gather(mm, addr, src, d0, d1, r0, c0, cy, cx):
+        ny, nx = min(cy, src.shape[1] - r0), min(cx, src.shape[2] - c0)
+        dst = mm[addr + d0 * cy * cx * 2:addr + d1 * cy * cx * 2].view(np.int16).reshape(d1 - d0, cy, cx)
+        np.copyto(dst[:, :ny, :nx], src[d0:d1, r0:r0 + ny, c0:c0 + nx])
+
+    @staticmethod
+    def _deflate(src, r0, c0, cy, cx, level):
+        import zlib as _z
+        blk = np.ascontiguousarray(src[:, r0:r0 + cy, c0:c0 + cx])
+        if blk.shape[1:] != (cy, cx):                          # an edge chunk is stored whole: pad with the fill value
+            full = np.full((src.shape[0], cy, cx), FILL_I2, np.int16)
+            full[:, :blk.shape[1], :blk.shape[2]] = blk
+            blk = full
+        shuf = np.ascontiguousarray(blk.reshape(-1).view(np.uint8).reshape(-1, 2).T)      # HDF5's shuffle: byte planes
+        return _z.compress(shuf, level)
+
+    def __call__(self, k, arrays):
+        import time as _t
+        t_begin = _t.perf_counter()
+        tile_id = self.info.get_tile_id(k)
+        cy, cx = self.info.chk_size_y, self.info.chk_size_x
+        jobs, maps, open_ds = [], [], []
+        for var in ("tmin", "tmax"):
+            src = arrays.get("daily_" + var)
+            if src is None:
+                continue
+            t0 = _t.perf_counter()
+            fpath = self.writer.fpath(tile_id, var)
+            ds = self.writer._create(fpath, tile_id, var, self.days, early=True)
+            g = ds.variables
+            g[var + "_normal"][:] = np.asarray(arrays["norm_" + var], np.float32)
+            g[var + "_se"][:] = np.asarray(arrays["se_" + var], np.float32)
+            g["inconsist_tair"][:] = np.asarray(arrays["ninvalid"], np.int32)
+            nd = src.shape[0]
+            if self.zlib:
+                for r0 in range(0, src.shape[1], cy):
+                    for c0 in range(0, src.shape[2], cx):
+                        jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), g[var], (0, r0, c0)))
+                open_ds.append(ds)
+            else:
+                ds.sync()
+                info = g[var].chunk_info()
+                ds.close()
+                mm = np.memmap(fpath, dtype=np.uint8, mode="r+")
+                maps.append(mm)
+                seg = -(-nd // self.day_segments)
+                for (_, r0, c0), (addr, size, _) in info.items():
+                    if size != nd * cy * cx * 2:
+                        raise IOError("%s: unexpected chunk size %d" % (fpath, size))
+                    for d0 in range(0, nd, seg):
+                        jobs.append((self.pool.submit(self._gather, mm, addr, src, d0, min(nd, d0 + seg), r0, c0, cy, cx), None, None))
+            self.stats["create_s"] += _t.perf_counter() - t0
+            self.stats["int16_bytes"] += int(src.nbytes)
+        t1 = _t.perf_counter()
+        for fut, var_obj, off in jobs:
+            res = fut.result()                                  # (raises what a worker raised)
+            if var_obj is not None:
+                var_obj.write_chunk_raw(off, res)
+        for ds in open_ds:
+            ds.close()
+        for mm in maps:
+            mm.flush()
+        del maps
+        self.stats["copy_s"] += _t.perf_counter() - t1
+        for var in ("tmin", "tmax"):
+            if "daily_" + var in arrays:
+                self.stats["disk_bytes"] += os.path.getsize(self.writer.fpath(tile_id, var))
+        if k in self.verify:
+            for var in ("tmin", "tmax"):
+                if "daily_" + var not in arrays:
+                    continue
+                ds = open_dataset(self.writer.fpath(tile_id, var), "r")
+                try:
+                    v = ds.variables[var]
+                    for r0 in range(0, v.shape[1], cy):        # chunk-aligned slabs: every stored byte is read once
+                        if not np.array_equal(v[:, r0:r0 + cy, :], arrays["daily_" + var][:, r0:r0 + cy, :]):
+                            raise IOError("%s: read-back differs from what was written" % ds.path)
+                    for name, key in ((var + "_normal", "norm_" + var), (var + "_se", "se_" + var), ("inconsist_tair", "ninvalid")):
+                        if not np.array_equal(ds.variables[name][:], arrays[key]):
+                            raise IOError("%s: %s read-back differs" % (ds.path, name))
+                finally:
+                    ds.close()
+            self.stats["verified"] += 1
+        self.stats["tiles"] += 1
+        self.stats["total_s"] += _t.perf_counter() - t_begin
+
+    def close(self):
+        self.pool.shutdown(wait=True)
 
 
 # ---- mosaic / monthly product files (tiling.py:567-971,973-1078) --------------------------------------------------------
