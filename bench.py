@@ -180,7 +180,14 @@ class Env(object):
         self.shared = os.environ.get("TWX_BENCH_SHARE_GPU") == "1"
         if self.shared:
             self.local = 0
-        if self.world > 1:
+        # TWX_BENCH_FORCE_PG=1: a process group -- and every collective of the N > 1 path -- also at world 1 (a one-rank RCCL
+        # communicator on the 1-GPU box: tests/test_gpu_rccl_smoke.py)
+        self.pg = self.world > 1 or os.environ.get("TWX_BENCH_FORCE_PG") == "1"
+        if self.pg and self.world == 1:
+            os.environ.setdefault("MASTER_PORT", "29731")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if self.pg:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
@@ -190,19 +197,19 @@ class Env(object):
         self.dev = torch.device("cuda", self.local)
 
     def barrier(self):
-        if self.world > 1:
+        if self.pg:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if not self.pg:
             return float(x)
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def all_gather_scalar(self, x):
-        if self.world == 1:
+        if not self.pg:
             return [float(x)]
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         parts = [self.torch.empty_like(t) for _ in range(self.world)]
@@ -410,10 +417,10 @@ def strip_run(env, args, steps, warmup, spot_check, full=False, fitted=False):
         buf, stat, ms = driver.interp_tiles_device(ctx, dgrid, mine, T, T, nslots=nmax, stats=ukstats if fitted else None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        if env.world > 1:
+        if env.pg:
             env.dist.barrier()          # so that gather_ms is the collective, not the wait for the slowest rank
         t2 = time.perf_counter()
-        mosaic = driver.gather_mosaic_device(buf, assignment, shape, T, T, env.rank, env.world, backend=env.backend)
+        mosaic = driver.gather_mosaic_device(buf, assignment, shape, T, T, env.rank, env.world, backend=env.backend, collective=env.pg)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         state.update(buf=buf, stat=stat, mosaic=mosaic, ms=float(sum(ms)), tile_wall=t1 - t0, gather=(t3 - t2) * 1e3)
@@ -444,7 +451,10 @@ def strip_run(env, args, steps, warmup, spot_check, full=False, fitted=False):
         "gather_bytes_per_rank": int(nmax * 4 * 12 * T * T * 4),
         "gather": "one dist.gather of the [tiles, 4, 12, %d, %d] f4 device tensor per rank (%s)" % (
             T, T, "RCCL over xGMI" if env.backend == "nccl" and env.world > 1 else
-            ("gloo through host memory: control-flow run" if env.world > 1 else "single rank: device copies only")),
+            ("gloo through host memory: control-flow run" if env.world > 1 else
+             ("single rank through a ONE-RANK RCCL communicator (TWX_BENCH_FORCE_PG=1)" if env.pg and env.backend == "nccl" else
+              "single rank: device copies only"))),
+        "process_group": ("%s, world %d" % (env.backend, env.world)) if env.pg else None,
         "hbm": {"algorithmic_bytes_per_cell_month": ALG_BYTES_PER_CELL_MONTH_2V,
                 "achieved_GBps": ALG_BYTES_PER_CELL_MONTH_2V * units * steps / elapsed / 1e9,
                 "frac_of_peak": ALG_BYTES_PER_CELL_MONTH_2V * units * steps / elapsed / 1e9 / (HBM_PEAK_GBS * env.world)},
@@ -751,7 +761,7 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
         _, wall0, _ = driver.interp_tiles_streamed(ctx, grid, tiles, T, T, daily=True, sink=lambda k, a: None, precision=args.c4_precision)
         rec["wall_discarding_sink_s"] = wall0
         for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2])):
-            sink = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), **kw)
+            sink = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), order=[t[0] for t in sub], **kw)
 
             def write_and_drop(k, arrays, sink=sink):
                 sink(k, arrays)
@@ -761,14 +771,18 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
             st = sink.stats
             rec[name] = {"tiles": st["tiles"], "wall_s": wall, "int16_GB": st["int16_bytes"] / 1e9, "on_disk_GB": st["disk_bytes"] / 1e9,
                          "int16_GBps_end_to_end": st["int16_bytes"] / wall / 1e9, "on_disk_GBps_end_to_end": st["disk_bytes"] / wall / 1e9,
-                         "sink_busy_s": st["total_s"], "of_it_file_creation_s": st["create_s"], "of_it_bulk_copy_s": st["copy_s"],
+                         "sink_busy_s": st["total_s"], "of_it_waiting_for_prepared_files_s": st["prepare_s"], "of_it_bulk_copy_s": st["copy_s"],
+                         "posix_fallocate_s_off_thread": st["fallocate_s"], "look_ahead": st["look_ahead"],
                          "int16_GBps_while_sink_busy": st["int16_bytes"] / max(st["total_s"], 1e-9) / 1e9,
                          "tiles_read_back_equal": st["verified"]}
         rec["host_new_page_rate"] = host_page_rates(base, threads)
         n4 = rec["netcdf4"]
-        rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files against %.1f GB/s into a discarding sink; the host "
-                                 "allocates new file pages at %.1f GB/s with %d threads (cold mmap fill) -- the bulk copy ran at %.1f GB/s"
+        rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files against %.1f GB/s into a discarding sink.  New file "
+                                 "pages by first touch come at %.1f GB/s on this host (one file, %d threads: they serialise on the file's "
+                                 "page-cache lock), which is why the sink allocates a file's pages with ONE posix_fallocate (%.1f GB/s per "
+                                 "file here) off its own thread; the bulk copy into the allocated pages ran at %.1f GB/s"
                                  % (n4["int16_GBps_end_to_end"], n4["int16_GB"] / wall0, rec["host_new_page_rate"]["cold_GBps"], threads,
+                                    n4["on_disk_GB"] / max(n4["posix_fallocate_s_off_thread"], 1e-9),
                                     n4["int16_GB"] / max(n4["of_it_bulk_copy_s"], 1e-9)))
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
@@ -1071,7 +1085,7 @@ def main():
         res["strong"] = rec
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if env.pg:
         env.dist.destroy_process_group()
 
 

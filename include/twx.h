@@ -222,6 +222,16 @@ int twx_set_days(twx_ctx *ctx, int64_t ndays, const int32_t *day_month, const in
 int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *tbl);
 
 /* ---- per-point entries (host buffers) ----------------------------------- */
+/* stns_rm as an ARRAY of station ids (station_select.py:74-103 accepts any number and removes them with np.in1d): up to
+ * TWX_MAX_EXCL station indices per point for the NEXT point-entry call on this context (twx_knn, twx_krig_points,
+ * twx_krigall_points, twx_fit_vario_points, twx_gwr_points, twx_gwr_xval_points, twx_interp_points), whose npts must
+ * equal this call's.  lists [npts][nmax], entries < 0 = unused, 1 <= nmax <= TWX_MAX_EXCL.  The entry's own `excl` argument
+ * (one index per point -- what every caller on the reference's path passes) still applies: the union is removed.
+ * Consumed by that call, whether it succeeds or not; npts = 0 clears a pending list.  Library limit without reference
+ * counterpart: more than TWX_MAX_EXCL ids per point are refused here (call-level failure), never truncated. */
+#define TWX_MAX_EXCL 8
+int twx_set_exclusions(twx_ctx *ctx, int64_t npts, int32_t nmax, const int32_t *lists);
+
 /* StationSelect.set_ngh_stns (station_select.py:121-192).  excl: station index
  * to drop (stns_rm) or -1, per point, may be NULL.  Outputs [npts][k] in
  * ascending station-index (= id) order. */
@@ -325,6 +335,10 @@ int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device
  * stream's compute / copy streams; ms).  What precision="auto" of topowx_amd/driver.py compares. */
 int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms);
 void twx_stream_destroy(twx_stream *st);
+
+/* free / total device memory of the context's GPU in bytes (hipMemGetInfo): what a caller sizes its batches by
+ * (topowx_amd/xval.py: step21 pushes ~22 MB of workspace per cross-validated station through one call) */
+int twx_device_memory(twx_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 
 /* kernel times of the last grid call (synchronises on its events) */
 int twx_get_timing(twx_ctx *ctx, twx_timing *t);

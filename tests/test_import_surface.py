@@ -83,7 +83,8 @@ def test_twx_utils(tmp_path):
     chk = StatusCheck(10, 4, out=buf)
     for _ in range(9):
         chk.increment()
-    assert buf.getvalue().count("Total items processed") == 2 and "2 items to go" in buf.getvalue()
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("[progress] 4 done of 10 (40.0 %)") and "2 left" in lines[1] and "last 4 in" in lines[1]
     u = Unbuffered(buf)
     u.write("x")
     assert buf.getvalue().endswith("x")

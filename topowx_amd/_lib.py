@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libtwxhip.so")
 TMIN, TMAX = 0, 1
 VAR_TMIN_BIT, VAR_TMAX_BIT = 1, 2
 MAX_NNGHS = 152
+MAX_EXCL = 8              # station indices that can be excluded per point (twx_set_exclusions)
 FILL_I2 = np.int16(-32767)
 FILL_F4 = np.float32(9.969209968386869e36)
 FILL_I4 = np.int32(-2147483647)
@@ -97,7 +98,7 @@ EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_se
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
            "twx_fit_vario_points", "twx_krigall_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
            "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy", "twx_stream_times",
-           "twx_set_precision")
+           "twx_set_precision", "twx_set_exclusions", "twx_device_memory")
 
 _LIB = None
 
@@ -230,6 +231,26 @@ class Context(object):
             return None if default is None else np.full(n, default, np.int32)
         return np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.int32), (n,)))
 
+    def _excl(self, excl, n):
+        """The ``excl`` argument of a point entry: None, one station index per point ([n] or a scalar), or a LIST of indices
+        per point ([n, m], entries < 0 unused; m <= MAX_EXCL: StationSelect's ``stns_rm`` as an array,
+        station_select.py:74-103).  Column 0 travels as the entry's own argument, the others through
+        ``twx_set_exclusions`` for the call that follows."""
+        if excl is None:
+            return None
+        a = np.asarray(excl, np.int32)
+        if a.ndim < 2:
+            return np.ascontiguousarray(np.broadcast_to(a, (n,)))
+        if a.shape[0] != n:
+            a = np.broadcast_to(a, (n, a.shape[-1]))
+        if a.shape[1] > MAX_EXCL:
+            raise ValueError("at most %d stations can be excluded per point (got %d)" % (MAX_EXCL, a.shape[1]))
+        if a.shape[1] > 1:
+            more = np.ascontiguousarray(a[:, 1:])
+            self._chk(self.lib.twx_set_exclusions(self.h, C.c_int64(n), C.c_int32(more.shape[1]), _p(more, _ip)),
+                      "twx_set_exclusions")
+        return np.ascontiguousarray(a[:, 0])
+
     # ---- per-point entries ---------------------------------------------------------
     def knn(self, var, lon, lat, k, excl=None, rm_zero_dist=False):
         lon = np.ascontiguousarray(np.atleast_1d(lon), np.float64)
@@ -239,7 +260,7 @@ class Context(object):
         dist = np.empty((n, k))
         wgt = np.empty((n, k))
         st = np.empty(n, np.int32)
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         self._chk(self.lib.twx_knn(self.h, C.c_int(var), C.c_int64(n), _p(lon, _dp), _p(lat, _dp), C.c_int32(k),
                                    _p(ex, _ip), C.c_int(int(rm_zero_dist)), _p(idx, _ip), _p(dist, _dp),
                                    _p(wgt, _dp), _p(st, _ip)), "twx_knn")
@@ -250,7 +271,7 @@ class Context(object):
         n = pts.size
         mth = self._i32(mth, n)
         nn = self._i32(nnghs, n)
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         vp = None
         if vario is not None:
             vp = np.ascontiguousarray(np.broadcast_to(np.asarray(vario, np.float64), (n, 3)))
@@ -272,7 +293,7 @@ class Context(object):
         n = pts.size
         mth = self._i32(mth, n)
         nn = self._i32(nnghs, n)
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         mean = np.full(n, np.nan)
         var_ = np.full(n, np.nan)
         vario = np.full((n, 3), np.nan)
@@ -289,7 +310,7 @@ class Context(object):
         n = pts.size
         mth = self._i32(mth, n)
         nn = self._i32(nnghs, n)
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         vario = np.full((n, 3), np.nan)
         used = np.zeros(n, np.int32)
         st = np.zeros(n, np.int32)
@@ -303,7 +324,7 @@ class Context(object):
         n = pts.size
         mth = self._i32(mth, n)
         nn = self._i32(nnghs, n)
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         pn = np.ascontiguousarray(np.broadcast_to(np.asarray(pt_norm, np.float64), (n,)))
         ld = max(self.mth_days)
         out = np.full((n, ld), np.nan)
@@ -319,7 +340,7 @@ class Context(object):
         station ``obs_idx`` (XvalTairAnom.run_xval's statistics, computed on the device)."""
         pts = np.ascontiguousarray(pts, PT_DTYPE)
         n = pts.size
-        mth, nn, ex, oi = self._i32(mth, n), self._i32(nnghs, n), self._i32(excl, n), self._i32(obs_idx, n)
+        mth, nn, ex, oi = self._i32(mth, n), self._i32(nnghs, n), self._excl(excl, n), self._i32(obs_idx, n)
         pn = np.ascontiguousarray(np.broadcast_to(np.asarray(pt_norm, np.float64), (n,)))
         bias, mae, r2 = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
         used = np.zeros(n, np.int32)
@@ -333,7 +354,7 @@ class Context(object):
     def interp_points(self, var, pts, excl=None, rm_zero_dist=False, daily=True):
         pts = np.ascontiguousarray(pts, PT_DTYPE)
         n = pts.size
-        ex = self._i32(excl, n)
+        ex = self._excl(excl, n)
         d = np.full((n, self.ndays), np.nan) if daily else None
         norms = np.full((n, 12), np.nan)
         se = np.full((n, 12), np.nan)
@@ -477,6 +498,12 @@ class Context(object):
         if n < 0:
             self._chk(-1, "twx_last_bandwidths")
         return buf[:min(n, max_cells)]
+
+    def device_memory(self):
+        """(free, total) bytes of the context's GPU."""
+        f, t = C.c_int64(), C.c_int64()
+        self._chk(self.lib.twx_device_memory(self.h, C.byref(f), C.byref(t)), "twx_device_memory")
+        return f.value, t.value
 
     def timing(self):
         t = TwxTiming()

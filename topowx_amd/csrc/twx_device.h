@@ -48,6 +48,8 @@ struct CellSrc {
     const float *lst;    // [12][Y][X] plane of the variable being interpolated
     const twx_pt *pts;
     const int32_t *excl; // per point station index to drop or null
+    const int32_t *excl_more;  // [npts][nexcl] further station indices to drop per point (< 0: unused), or null (twx_set_exclusions)
+    int nexcl;
     const int32_t *mth;  // per point month 1..12 (0 / null = all twelve)
     const int32_t *nnghs_in;   // per point explicit bandwidth (<= 0 smooth) or null
     const double *vario_in;    // per point [3] explicit variogram (NaN nugget = smooth) or null

@@ -119,6 +119,9 @@ struct twx_ctx {
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     bool have_total = false;
     std::vector<struct twx_stream *> streams;   // open twx_stream objects: twx_destroy closes them before the context goes away
+    std::vector<int32_t> excl_lists;            // twx_set_exclusions: [excl_npts][excl_nmax] for the next point-entry call
+    int64_t excl_npts = 0;
+    int excl_nmax = 0;
 };
 
 namespace {
@@ -818,7 +821,8 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *t)
 namespace {
 struct PtDev {
     twx_pt *pts = nullptr;
-    int32_t *mth = nullptr, *nnghs = nullptr, *excl = nullptr, *ptile = nullptr, *ptfirst = nullptr;
+    int32_t *mth = nullptr, *nnghs = nullptr, *excl = nullptr, *ptile = nullptr, *ptfirst = nullptr, *excl_more = nullptr;
+    int nexcl = 0;
     double *vario = nullptr, *pt_norm = nullptr;
     int64_t nlists = 0;       // candidate lists: runs of consecutive points with the same location and excluded station
 };
@@ -831,7 +835,14 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
     ctx->have_total = false;
     HIPCHK(ctx->stats.ensure(64));                           // ... but they do count their systems (twx_get_timing: uk_solves, uk_f64_solves
     HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 64, nullptr));    // of the LAST entry call, grid or points)
-    size_t bytes = (size_t)npts * (sizeof(twx_pt) + 5 * 4 + 4 * 8) + 8192;
+    // a pending exclusion list (twx_set_exclusions) belongs to THIS call: taken over and cleared, whatever happens next
+    std::vector<int32_t> more;
+    more.swap(ctx->excl_lists);
+    const int64_t more_npts = ctx->excl_npts;
+    const int nmore = ctx->excl_nmax;
+    ctx->excl_npts = 0; ctx->excl_nmax = 0;
+    if (!more.empty() && more_npts != npts) return fail(ctx, "the pending twx_set_exclusions list was given for another number of points");
+    size_t bytes = (size_t)npts * (sizeof(twx_pt) + 5 * 4 + 4 * 8 + (size_t)nmore * 4) + 8192;
     HIPCHK(ctx->pt_in.ensure(bytes));
     char *cur = ctx->pt_in.as<char>();
     pd.pts = carve<twx_pt>(cur, npts);
@@ -846,6 +857,10 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
     if (mth) { pd.mth = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.mth, mth, npts * 4, hipMemcpyHostToDevice)); }
     if (nnghs) { pd.nnghs = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.nnghs, nnghs, npts * 4, hipMemcpyHostToDevice)); }
     if (excl) { pd.excl = carve<int32_t>(cur, npts); HIPCHK(hipMemcpy(pd.excl, excl, npts * 4, hipMemcpyHostToDevice)); }
+    if (!more.empty()) {
+        pd.excl_more = carve<int32_t>(cur, npts * nmore); pd.nexcl = nmore;
+        HIPCHK(hipMemcpy(pd.excl_more, more.data(), more.size() * 4, hipMemcpyHostToDevice));
+    }
     if (vario) { pd.vario = carve<double>(cur, npts * 3); HIPCHK(hipMemcpy(pd.vario, vario, npts * 24, hipMemcpyHostToDevice)); }
     if (pt_norm) { pd.pt_norm = carve<double>(cur, npts); HIPCHK(hipMemcpy(pd.pt_norm, pt_norm, npts * 8, hipMemcpyHostToDevice)); }
     // one candidate list per run of points that share location and excluded station (cross-validation asks for a
@@ -853,7 +868,8 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
     std::vector<int32_t> ptile(npts), ptfirst;
     for (int64_t i = 0; i < npts; ++i) {
         const bool same = i > 0 && pts[i].lon == pts[i - 1].lon && pts[i].lat == pts[i - 1].lat &&
-                          (excl ? excl[i] == excl[i - 1] : true);
+                          (excl ? excl[i] == excl[i - 1] : true) &&
+                          (more.empty() || std::equal(more.begin() + i * nmore, more.begin() + (i + 1) * nmore, more.begin() + (i - 1) * nmore));
         if (!same) ptfirst.push_back((int32_t)i);
         ptile[i] = (int32_t)ptfirst.size() - 1;
     }
@@ -866,7 +882,7 @@ int upload_points(twx_ctx *ctx, int64_t npts, const twx_pt *pts, const double *l
 CellSrc point_src(const PtDev &pd, int rm_zero, int do_krig, int do_anom)
 {
     CellSrc s{};
-    s.mode = 1; s.pts = pd.pts; s.excl = pd.excl; s.mth = pd.mth; s.nnghs_in = pd.nnghs; s.vario_in = pd.vario;
+    s.mode = 1; s.pts = pd.pts; s.excl = pd.excl; s.excl_more = pd.excl_more; s.nexcl = pd.nexcl; s.mth = pd.mth; s.nnghs_in = pd.nnghs; s.vario_in = pd.vario;
     s.ptile = pd.ptile; s.ptfirst = pd.ptfirst;
     s.rm_zero = rm_zero; s.do_krig = do_krig; s.do_anom = do_anom; s.do_vario = 1;
     return s;
@@ -879,6 +895,19 @@ int max_k(const int32_t *nnghs, int64_t n)
     return m;
 }
 }  // namespace
+
+int twx_set_exclusions(twx_ctx *ctx, int64_t npts, int32_t nmax, const int32_t *lists)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    ctx->excl_lists.clear(); ctx->excl_npts = 0; ctx->excl_nmax = 0;
+    if (npts == 0) return 0;
+    if (npts < 0 || nmax < 1 || nmax > TWX_MAX_EXCL || !lists)
+        return fail(ctx, "twx_set_exclusions: 1 <= nmax <= TWX_MAX_EXCL station indices per point (more are refused, never truncated)");
+    ctx->excl_lists.assign(lists, lists + npts * nmax);
+    ctx->excl_npts = npts; ctx->excl_nmax = nmax;
+    return 0;
+}
 
 int twx_knn(twx_ctx *ctx, int var, int64_t npts, const double *lon, const double *lat, int32_t k,
             const int32_t *excl, int rm_zero_dist, int32_t *idx, double *dist, double *wgt, int32_t *status)
@@ -1715,6 +1744,18 @@ int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms)
     HIPCHK(hipEventSynchronize(st->ev_done[slot]));
     if (device_ms) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
     if (copy_ms) HIPCHK(hipEventElapsedTime(copy_ms, st->ev_copy0[slot], st->ev_done[slot]));
+    return 0;
+}
+
+int twx_device_memory(twx_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!ctx) return -1;
+    ctx->err.clear();
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
     return 0;
 }
 

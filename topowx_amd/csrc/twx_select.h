@@ -107,11 +107,13 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
         const int64_t tile = ws.tile0 + tl;
         double clon, clat, hd = 0.0;
         int excl = -1;
+        const int32_t *more = nullptr;                       // further exclusions of the list's points (twx_set_exclusions)
         int any = 1;
         if (src.mode == 1) {
             const int64_t p = src.ptfirst ? src.ptfirst[tile] : tile;     // the list's first point stands for all of them
             clon = src.pts[p].lon; clat = src.pts[p].lat;
             excl = src.excl ? src.excl[p] : -1;
+            if (src.excl_more) more = src.excl_more + p * src.nexcl;
         } else {
             int ty = (int)(tile / src.ntx), tx = (int)(tile % src.ntx);
             int r0 = ty * src.ts, r1 = min(r0 + src.ts, src.Y) - 1;
@@ -146,7 +148,10 @@ __global__ __launch_bounds__(1024) void k_tile_cand(StnDev st, CellSrc src, SelW
             // test of rm_zero_dist_stns (station_select.py:111-119) is the coordinate comparison
             const double slon = st.lon[j], slat = st.lat[j];
             float f = hav_km_f32(clon, clat, ccos, slon, slat, (float)st.coslat[j]);
-            if (j == excl || (src.rm_zero && slon == clon && slat == clat)) f = -1.f; // dropped (point mode)
+            bool drop = j == excl || (src.rm_zero && slon == clon && slat == clat);   // dropped (point mode)
+            if (more)                                        // (uniform)
+                for (int q = 0; q < src.nexcl; ++q) drop = drop || more[q] == j;
+            if (drop) f = -1.f;
             else { dmax = fmaxf(dmax, f); ++nvalid; }
             dsc[j] = f;
         }
@@ -314,6 +319,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
     const int32_t *cand = nullptr;
     CellVals cv = {0, 0, 0, 0};
     int excl = -1;
+    const int32_t *more = nullptr;
     bool too_many = false;
     if (valid) {
         int64_t tl = cell_tile(src, c) - ws.tile0;
@@ -323,6 +329,7 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
         cand = ws.cand + tl * ws.cmax;
         cv = cell_load(src, c);
         if (src.mode == 1 && src.excl) excl = src.excl[c];
+        if (src.mode == 1 && src.excl_more) more = src.excl_more + c * src.nexcl;
     }
     // non-finite predictors of the point, as scalar bits (wave-uniform): 0 elev, 1 tdi, 2 + m lst of month m
     unsigned nan_pred = 0;
@@ -339,7 +346,10 @@ __device__ __forceinline__ void select_cell(const StnDev &st, const CellSrc &src
     for (int j = lane; j < ncand; j += 64) {
         int s = cand[j];
         double d = hav_km(cv.lon, cv.lat, st.lon[s], st.lat[s]);
-        if (s == excl || (src.rm_zero && d == 0.0)) d = INFINITY; else ++nv;
+        bool drop = s == excl || (src.rm_zero && d == 0.0);
+        if (more)                                            // (wave-uniform)
+            for (int q = 0; q < src.nexcl; ++q) drop = drop || more[q] == s;
+        if (drop) d = INFINITY; else ++nv;
         sd[j] = d;
     }
     for (int r = lane; r < TWX_KSEL_MAX; r += 64) snp[r] = -1;

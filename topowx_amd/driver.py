@@ -134,46 +134,53 @@ def interp_tiles_device(ctx, dgrid, tiles, tile_y, tile_x, variables=("tmin", "t
     strm = tstream.cuda_stream
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(tiles) + 1)]
     marks[0].record(tstream)
-    for s, (k, i, j, _) in enumerate(tiles):
-        y, x = min(tile_y, Yg - i), min(tile_x, Xg - j)
-        if per_tile:
-            t = dgrid["tiles"][k]
-        else:
-            t = {n: dgrid[n][i:i + y, j:j + x].contiguous() for n in ("mask", "elev", "tdi", "climdiv")}
-            t["lat"] = dgrid["lat"][i:i + y].contiguous()
-            t["lon"] = dgrid["lon"][j:j + x].contiguous()
-            for n in ("lst_night", "lst_day"):
-                t[n] = dgrid[n][:, i:i + y, j:j + x].contiguous()
-        full = y == tile_y and x == tile_x
-        # an edge tile is smaller than its slot: computed into a scratch image and placed afterwards
-        o = buf[s] if full else torch.full((4, 12, y, x), float(FILL_F4), dtype=torch.float32, device=dev)
-        so = stat[s] if full else torch.full((y, x), -1, dtype=torch.int32, device=dev)
-        g = _lib.TwxGrid(y, x, *[t[n].data_ptr() for n in ("mask", "lat", "lon", "elev", "tdi", "climdiv", "lst_night", "lst_day")])
-        ptr = [o[q].data_ptr() if v in variables else None for q, v in enumerate(("tmin", "tmin", "tmax", "tmax"))]
-        go = _lib.TwxGridOut(ptr[0], ptr[1], ptr[2], ptr[3], None, None, ninv.data_ptr(), so.data_ptr())
-        ctx.interp_grid_dev(g, go, vars_mask, strm)     # (stream-ordered: the tile's input images may be freed by torch afterwards)
-        if stats is not None:
-            t_ = ctx.timing()
-            for key in ("uk_solves", "uk_f64_solves"):
-                stats[key] = stats.get(key, 0) + int(t_[key])
-        if not full:
-            buf[s, :, :, :y, :x] = o
-            stat[s, :y, :x] = so
-        marks[s + 1].record(tstream)
+    # everything of a tile -- the gathers of its input planes, the edge tile's scratch images, the library call, the placement of
+    # an edge tile -- runs on ONE stream (the caller's `stream` when given): torch's copies are ordered with the kernels that read /
+    # write the same tensors, and the caching allocator recycles t / o / so only behind work queued on that stream
+    tstream.wait_stream(torch.cuda.current_stream())        # (buf / stat / the uploaded planes were filled on the current stream)
+    with torch.cuda.stream(tstream):
+        for s, (k, i, j, _) in enumerate(tiles):
+            y, x = min(tile_y, Yg - i), min(tile_x, Xg - j)
+            if per_tile:
+                t = dgrid["tiles"][k]
+            else:
+                t = {n: dgrid[n][i:i + y, j:j + x].contiguous() for n in ("mask", "elev", "tdi", "climdiv")}
+                t["lat"] = dgrid["lat"][i:i + y].contiguous()
+                t["lon"] = dgrid["lon"][j:j + x].contiguous()
+                for n in ("lst_night", "lst_day"):
+                    t[n] = dgrid[n][:, i:i + y, j:j + x].contiguous()
+            full = y == tile_y and x == tile_x
+            # an edge tile is smaller than its slot: computed into a scratch image and placed afterwards
+            o = buf[s] if full else torch.full((4, 12, y, x), float(FILL_F4), dtype=torch.float32, device=dev)
+            so = stat[s] if full else torch.full((y, x), -1, dtype=torch.int32, device=dev)
+            g = _lib.TwxGrid(y, x, *[t[n].data_ptr() for n in ("mask", "lat", "lon", "elev", "tdi", "climdiv", "lst_night", "lst_day")])
+            ptr = [o[q].data_ptr() if v in variables else None for q, v in enumerate(("tmin", "tmin", "tmax", "tmax"))]
+            go = _lib.TwxGridOut(ptr[0], ptr[1], ptr[2], ptr[3], None, None, ninv.data_ptr(), so.data_ptr())
+            ctx.interp_grid_dev(g, go, vars_mask, strm)     # (stream-ordered: the tile's input images may be freed by torch afterwards)
+            if stats is not None:
+                t_ = ctx.timing()
+                for key in ("uk_solves", "uk_f64_solves"):
+                    stats[key] = stats.get(key, 0) + int(t_[key])
+            if not full:
+                buf[s, :, :, :y, :x] = o
+                stat[s, :y, :x] = so
+            marks[s + 1].record(tstream)
     marks[-1].synchronize()
     ms = [marks[s].elapsed_time(marks[s + 1]) for s in range(len(tiles))]
     return buf, stat, ms
 
 
-def gather_mosaic_device(buf, assignment, shape, tile_y, tile_x, rank, world, keys=NORMAL_KEYS, backend="nccl"):
+def gather_mosaic_device(buf, assignment, shape, tile_y, tile_x, rank, world, keys=NORMAL_KEYS, backend="nccl", collective=None):
     """``gather_mosaic`` on device tensors: ``buf[nmax, len(keys), 12, tile_y, tile_x]`` of every rank (the tensor
     ``interp_tiles_device`` has filled, same nmax everywhere) goes to rank 0 with ONE ``dist.gather`` -- over RCCL
     world - 1 concurrent xGMI transfers into rank 0's HBM -- and is placed into ``[12, Y, X]`` mosaics by device
     copies; no host staging (with the gloo backend of the CPU / shared-GPU control-flow runs the collective itself
-    travels through host memory).  Returns {key: device tensor} on rank 0, None elsewhere."""
+    travels through host memory).  ``collective``: run the ``dist.gather`` (default: whenever world > 1; True at world 1 sends
+    rank 0's buffer through a one-rank RCCL communicator -- tests/test_gpu_rccl_smoke.py).
+    Returns {key: device tensor} on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if world > 1:
+    if (world > 1) if collective is None else collective:
         send = buf if backend == "nccl" else buf.cpu()
         parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
         dist.gather(send, parts, dst=0)
@@ -202,13 +209,14 @@ class PrecisionPolicy(object):
                int16 / f4 bit (tests/tools/gpu_full_tile_parity.py --f64), ~1.3 x the kriging time;
       "auto"   "exact" for as long as it is FREE: a streamed run is bound by the copy-out of its outputs whenever they are
                large (daily tiles: the GPU idles ~70 % of the wall), and then the fp64 build costs no wall time.  The run
-               starts exact; each of the first tiles' device time is compared with its copy-out time (``TileStream.times``),
-               and if the kernels are NOT hidden behind the copy (device > 0.9 x copy: normals-only tiles) the rest of the
-               run is fast.
+               starts exact; the device times of the first PROBE exact tiles are compared with their copy-out times
+               (``TileStream.times``), and if their MEDIAN is not hidden behind the copy (device > 0.9 x copy: normals-only
+               tiles) the rest of the run is fast.  (The median, not any one tile: the first tile of a new size grows the
+               library's workspace -- a hipFree + hipMalloc of gigabytes shows as half a second of "device time" once.)
 
     ``mode`` is the build the NEXT submitted tile gets; ``observe`` is fed every finished tile; ``summary()`` is what the tile
     logs record.  ``close()`` leaves the context in the "fast" mode."""
-    PROBE = 2                                   # exact tiles looked at before "auto" stops looking
+    PROBE = 3                                   # exact tiles looked at before "auto" decides
 
     def __init__(self, ctx, requested="auto"):
         if requested not in ("auto", "fast", "exact"):
@@ -219,6 +227,7 @@ class PrecisionPolicy(object):
         self.decision = "as requested" if self.decided else "exact throughout: every probed tile's kernels were hidden behind its copy-out"
         self.seen = {"exact": [0, 0.0, 0.0], "fast": [0, 0.0, 0.0]}     # tiles, device ms, copy ms by the mode they ran in
         self.tile_modes = {}
+        self._probe = []                        # (device ms, copy ms) of the exact tiles seen so far
         ctx.set_precision(self.mode)
 
     def observe(self, tile_mode, device_ms, copy_ms, tile=None):
@@ -228,13 +237,19 @@ class PrecisionPolicy(object):
         rec[0] += 1; rec[1] += device_ms; rec[2] += copy_ms
         if self.decided or tile_mode != "exact":
             return
-        if device_ms > 0.9 * copy_ms:
-            self.mode, self.decided = "fast", True
-            self.decision = ("fast after %d tile(s): the kernels of an exact tile (%.2f ms) are not hidden behind its copy-out "
-                             "(%.2f ms)" % (self.seen["exact"][0] + self.seen["fast"][0], device_ms, copy_ms))
+        self._probe.append((device_ms, copy_ms))
+        if len(self._probe) < self.PROBE:
+            return
+        self.decided = True
+        dev, cp = sorted(p[0] for p in self._probe)[self.PROBE // 2], sorted(p[1] for p in self._probe)[self.PROBE // 2]
+        if dev > 0.9 * cp:
+            self.mode = "fast"
+            self.decision = ("fast after %d tiles: the kernels of an exact tile (median %.2f ms) are not hidden behind its copy-out "
+                             "(median %.2f ms)" % (self.seen["exact"][0] + self.seen["fast"][0], dev, cp))
             self.ctx.set_precision("fast")
-        elif rec[0] >= self.PROBE:
-            self.decided = True
+        else:
+            self.decision = ("exact throughout: the kernels of an exact tile (median %.2f ms) hide behind its copy-out (median %.2f ms)"
+                             % (dev, cp))
 
     def summary(self):
         nt = self.seen["exact"][0] + self.seen["fast"][0]

@@ -43,21 +43,31 @@ class StationSelect(object):
         self.ngh_stns = self.ngh_obs = self.ngh_dists = self.ngh_wgt = None
 
     def excl_index(self, stns_rm):
-        """Station index of ``stns_rm`` (a single id, as every reference caller passes)."""
+        """``stns_rm`` (station_select.py:74-103: a str, or a numpy array of ids removed with ``np.in1d``) as what the point
+        entries take: -1 (nothing), ONE station index (a single id, what every caller on the reference's path passes), or
+        a ``[1, m]`` array of indices (several ids; ids that are not in the table remove nothing, as ``np.in1d`` has it).
+        More than ``_lib.MAX_EXCL`` ids in the table: ValueError (a library limit, never a silent truncation)."""
         if stns_rm is None:
             return -1
-        if isinstance(stns_rm, np.ndarray):
-            if stns_rm.size != 1:
-                raise NotImplementedError("only a single station id can be removed per point")
-            stns_rm = stns_rm.ravel()[0]
-        return self._id_to_idx.get(str(stns_rm), -1)
+        if isinstance(stns_rm, (str, bytes)):
+            ids = [stns_rm]
+        elif isinstance(stns_rm, np.ndarray):
+            ids = list(stns_rm.ravel())
+        else:
+            raise Exception("stns_rm must be str, unicode, or numpy array of str/unicode")       # station_select.py:77
+        idx = sorted({self._id_to_idx[str(i)] for i in ids if str(i) in self._id_to_idx})
+        if len(idx) <= 1:
+            return idx[0] if idx else -1
+        if len(idx) > _lib.MAX_EXCL:
+            raise ValueError("stns_rm names %d stations of the table; the library excludes at most %d per point" % (len(idx), _lib.MAX_EXCL))
+        return np.array([idx], np.int32)
 
     def set_ngh_stns(self, lat, lon, nnghs, load_obs=True, obs_mth=None, stns_rm=None):
         if nnghs >= self.stns.size:
             raise IndexError("index %d is out of bounds: only %d stations" % (nnghs, self.stns.size))  # :164
         if nnghs > _lib.MAX_NNGHS + 7:
             raise ValueError("nnghs above the supported maximum (%d)" % _lib.MAX_NNGHS)
-        idx, dist, wgt, st = self.ctx.knn(self.var, [lon], [lat], int(nnghs), excl=[self.excl_index(stns_rm)],
+        idx, dist, wgt, st = self.ctx.knn(self.var, [lon], [lat], int(nnghs), excl=self.excl_index(stns_rm),
                                           rm_zero_dist=self.rm_zero_dist_stns)
         raise_for_status(st[0])
         self.ngh_stns = self.stns[idx[0]]

@@ -412,6 +412,8 @@ class TileWriter(object):
         mv.scale_factor = SCALE_FACTOR
         mv.cell_methods = "area: mean time: " + cell_method
         _gridded(mv)
+        if early and _is_nc4(ds) and not self.zlib:
+            kw = dict(kw, alloc_early=True)                   # (TileSink: the file has its final size once it is created)
         nv = ds.createVariable(varname + "_normal", "f4", ("time_normals", "lat", "lon"), chunksizes=(12, cy, cx),
                                fill_value=FILL_F4, **kw)
         nv.long_name, nv.units, nv.standard_name = "normal " + long_name, vunits, std_name
@@ -492,37 +494,75 @@ class TileSink(object):
     through netCDF4-python (step25:177-185, tiling.py:488-537); a 250 x 250 tile of configs[3] is 25 such chunks of 126 MB
     per variable, and one GPU produces a tile every ~0.12 s.  Here, per tile and variable:
 
-    * the file is created with the daily variable's chunks ALLOCATED AT CREATION on page boundaries and not pre-filled
-      (``h5nc``: ``alloc_early``), the small variables (normals, SE, inconsist_tair, coordinates) are written through the
-      library, the chunk addresses are read (``H5Dget_chunk_info``) and the file is closed;
-    * ``threads`` workers then copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
+    * PREPARE (needs no data; with ``order`` -- the tile numbers in the order they will arrive -- the NEXT tile's files are
+      prepared by a background thread while this tile's bytes are copied): the file is created with EVERY variable's chunks
+      allocated at creation, the daily variable's on page boundaries (``h5nc``: ``alloc_early`` + ``alignment``), coordinates
+      and attributes are written, the chunk addresses are read (``H5Dget_chunk_info``), the file is closed -- and its pages
+      are allocated with ONE ``posix_fallocate``: new file pages by first touch cost a page fault each and serialise on the
+      file's page-cache lock (tests/tools/host_page_rates.py: ~1.5-2 GB/s per file however many threads), ``fallocate``
+      allocates them in one in-kernel loop (~10 GB/s);
+    * WRITE: ``threads`` workers copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
       straight into the file's pages through one shared ``mmap`` -- each job one strided gather of a (days segment x chunk)
       piece, numpy releases the GIL for it -- so the transposition into chunk order IS the write, and no HDF5 call touches
-      the 6.3 GB of a tile;
+      the 6.3 GB of a tile; the small variables (normals, SE, inconsist_tair) go through the library into their allocated chunks;
     * ``zlib=True`` (the reference's tiles are not compressed; its mosaics are): the workers gather, byte-shuffle and
       deflate each chunk (``zlib`` releases the GIL) and the sink's own thread appends the stored bytes with
       ``H5Dwrite_chunk`` -- for the library a byte copy.
 
     The files are complete NetCDF-4 files of the ``TileWriter`` layout (``read_tile`` / ``h5nc.Dataset`` / any HDF5 reader
     open them; tests/test_ncio.py, tests/test_h5py_interop.py).  ``stats``: tiles, int16 bytes handed over, bytes on disk,
-    seconds in file creation / in the bulk copy / total.  ``verify``: tile numbers to read back through the library
-    and compare with what was handed over (``stats["verified"]``: number of tiles checked, raises on a difference)."""
+    seconds in preparation (on the caller's thread only: look-ahead preparation is off it) / in the bulk copy / total.
+    ``verify``: tile numbers to read back through the library and compare with what was handed over (``stats["verified"]``:
+    number of tiles checked, raises on a difference)."""
 
-    def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None):
+    def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None,
+                 variables=("tmin", "tmax"), order=None):
         from concurrent.futures import ThreadPoolExecutor
         if not h5nc.available():
             raise IOError("TileSink needs libhdf5 (NetCDF-4 tiles); TileWriter writes classic netCDF without it")
-        self.info, self.path_out, self.days = tile_grid_info, path_out, days
+        self.info, self.path_out, self.days, self.variables = tile_grid_info, path_out, days, tuple(variables)
         self.writer = TileWriter(tile_grid_info, path_out, format="NETCDF4", zlib=zlib, complevel=complevel)
         self.threads = int(threads or min(64, os.cpu_count() or 8))
         self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
         self.pool = ThreadPoolExecutor(self.threads)
+        self.prep_pool = ThreadPoolExecutor(max(2, len(self.variables)))
+        self.order = list(order) if order is not None else None
+        self._ahead = {}                                        # tile number -> {var: future of _prepare_var}
         cy, cx = tile_grid_info.chk_size_y, tile_grid_info.chk_size_x
-        nchunks = 2 * (tile_grid_info.tile_size_y // cy) * (tile_grid_info.tile_size_x // cx)
+        nchunks = len(self.variables) * (tile_grid_info.tile_size_y // cy) * (tile_grid_info.tile_size_x // cx)
         # enough jobs per tile to keep every worker busy: chunks are cut along the day axis
         self.day_segments = int(day_segments or max(1, -(-2 * self.threads // max(nchunks, 1))))
-        self.stats = {"tiles": 0, "int16_bytes": 0, "disk_bytes": 0, "create_s": 0.0, "copy_s": 0.0, "total_s": 0.0,
-                      "verified": 0, "threads": self.threads, "zlib": self.zlib, "complevel": self.complevel if zlib else None}
+        self.stats = {"tiles": 0, "int16_bytes": 0, "disk_bytes": 0, "prepare_s": 0.0, "copy_s": 0.0, "total_s": 0.0, "fallocate_s": 0.0,
+                      "verified": 0, "threads": self.threads, "zlib": self.zlib, "complevel": self.complevel if zlib else None,
+                      "look_ahead": self.order is not None}
+
+    # ---- prepare: no data needed ----------------------------------------------------------------------------------------------
+    def _prepare_var(self, k, var):
+        import time as _t
+        tile_id = self.info.get_tile_id(k)
+        fpath = self.writer.fpath(tile_id, var)
+        ds = self.writer._create(fpath, tile_id, var, self.days, early=True)
+        ds.sync()
+        info = ds.variables[var].chunk_info()
+        ds.close()
+        t0 = _t.perf_counter()
+        fd = os.open(fpath, os.O_RDWR)
+        try:
+            os.posix_fallocate(fd, 0, os.fstat(fd).st_size)   # every page of the file, in one in-kernel loop (releases the GIL)
+        finally:
+            os.close(fd)
+        dt = _t.perf_counter() - t0
+        return fpath, np.memmap(fpath, dtype=np.uint8, mode="r+"), info, dt
+
+    def _prepared(self, k):
+        futs = self._ahead.pop(k, None)
+        if futs is None:
+            futs = {v: self.prep_pool.submit(self._prepare_var, k, v) for v in self.variables}
+        if self.order is not None and k in self.order:          # the next tile's files, while this one is written
+            i = self.order.index(k) + 1
+            if i < len(self.order) and self.order[i] not in self._ahead:
+                self._ahead[self.order[i]] = {v: self.prep_pool.submit(self._prepare_var, self.order[i], v) for v in self.variables}
+        return {v: f.result() for v, f in futs.items()}
 
     @staticmethod
     def _gather(mm, addr, src, d0, d1, r0, c0, cy, cx):
@@ -541,61 +581,66 @@ class TileSink(object):
         shuf = np.ascontiguousarray(blk.reshape(-1).view(np.uint8).reshape(-1, 2).T)      # HDF5's shuffle: byte planes
         return _z.compress(shuf, level)
 
+    def _small(self, ds, var, arrays):
+        g = ds.variables
+        g[var + "_normal"][:] = np.asarray(arrays["norm_" + var], np.float32)
+        g[var + "_se"][:] = np.asarray(arrays["se_" + var], np.float32)
+        g["inconsist_tair"][:] = np.asarray(arrays["ninvalid"], np.int32)
+
     def __call__(self, k, arrays):
         import time as _t
         t_begin = _t.perf_counter()
         tile_id = self.info.get_tile_id(k)
         cy, cx = self.info.chk_size_y, self.info.chk_size_x
+        present = [v for v in self.variables if arrays.get("daily_" + v) is not None]
         jobs, maps, open_ds = [], [], []
-        for var in ("tmin", "tmax"):
-            src = arrays.get("daily_" + var)
-            if src is None:
-                continue
-            t0 = _t.perf_counter()
-            fpath = self.writer.fpath(tile_id, var)
-            ds = self.writer._create(fpath, tile_id, var, self.days, early=True)
-            g = ds.variables
-            g[var + "_normal"][:] = np.asarray(arrays["norm_" + var], np.float32)
-            g[var + "_se"][:] = np.asarray(arrays["se_" + var], np.float32)
-            g["inconsist_tair"][:] = np.asarray(arrays["ninvalid"], np.int32)
-            nd = src.shape[0]
-            if self.zlib:
+        if self.zlib:
+            for var in present:
+                src = arrays["daily_" + var]
+                ds = self.writer._create(self.writer.fpath(tile_id, var), tile_id, var, self.days, early=True)
+                self._small(ds, var, arrays)
                 for r0 in range(0, src.shape[1], cy):
                     for c0 in range(0, src.shape[2], cx):
-                        jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), g[var], (0, r0, c0)))
+                        jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), ds.variables[var], (0, r0, c0)))
                 open_ds.append(ds)
-            else:
-                ds.sync()
-                info = g[var].chunk_info()
-                ds.close()
-                mm = np.memmap(fpath, dtype=np.uint8, mode="r+")
+        else:
+            prepared = self._prepared(k)
+            for var in present:
+                src = arrays["daily_" + var]
+                fpath, mm, info, dt_f = prepared[var]
+                self.stats["fallocate_s"] += dt_f
                 maps.append(mm)
+                nd = src.shape[0]
                 seg = -(-nd // self.day_segments)
                 for (_, r0, c0), (addr, size, _) in info.items():
                     if size != nd * cy * cx * 2:
                         raise IOError("%s: unexpected chunk size %d" % (fpath, size))
                     for d0 in range(0, nd, seg):
                         jobs.append((self.pool.submit(self._gather, mm, addr, src, d0, min(nd, d0 + seg), r0, c0, cy, cx), None, None))
-            self.stats["create_s"] += _t.perf_counter() - t0
-            self.stats["int16_bytes"] += int(src.nbytes)
+        self.stats["prepare_s"] += _t.perf_counter() - t_begin
         t1 = _t.perf_counter()
+        if not self.zlib:                                       # the small variables, through the library, while the workers copy
+            for var in present:
+                ds = open_dataset(self.writer.fpath(tile_id, var), "a")
+                try:
+                    self._small(ds, var, arrays)
+                finally:
+                    ds.close()
         for fut, var_obj, off in jobs:
             res = fut.result()                                  # (raises what a worker raised)
             if var_obj is not None:
                 var_obj.write_chunk_raw(off, res)
         for ds in open_ds:
             ds.close()
-        for mm in maps:
-            mm.flush()
         del maps
         self.stats["copy_s"] += _t.perf_counter() - t1
-        for var in ("tmin", "tmax"):
-            if "daily_" + var in arrays:
-                self.stats["disk_bytes"] += os.path.getsize(self.writer.fpath(tile_id, var))
+        for var in present:
+            self.stats["int16_bytes"] += int(arrays["daily_" + var].nbytes)
+            self.stats["disk_bytes"] += os.path.getsize(self.writer.fpath(tile_id, var))
+        self.stats["tiles"] += 1
+        self.stats["total_s"] += _t.perf_counter() - t_begin
         if k in self.verify:
-            for var in ("tmin", "tmax"):
-                if "daily_" + var not in arrays:
-                    continue
+            for var in present:
                 ds = open_dataset(self.writer.fpath(tile_id, var), "r")
                 try:
                     v = ds.variables[var]
@@ -608,10 +653,16 @@ class TileSink(object):
                 finally:
                     ds.close()
             self.stats["verified"] += 1
-        self.stats["tiles"] += 1
-        self.stats["total_s"] += _t.perf_counter() - t_begin
 
     def close(self):
+        for futs in self._ahead.values():                       # (files prepared for tiles that never came are left complete but empty)
+            for f in futs.values():
+                try:
+                    f.result()
+                except Exception:                               # noqa: BLE001
+                    pass
+        self._ahead.clear()
+        self.prep_pool.shutdown(wait=True)
         self.pool.shutdown(wait=True)
 
 

@@ -11,47 +11,57 @@ __all__ = ["StatusCheck", "Unbuffered", "TwxConfig", "mkdir_p"]
 
 
 class StatusCheck(object):
-    """Progress printer (twx/utils/status_check.py:22-57): ``increment()`` reports every ``check_cnt`` items."""
+    """Progress reporter with the constructor and ``increment`` of the reference's helper (``StatusCheck(total_cnt, check_cnt)``
+    in scripts/step21..24): one line every ``check_cnt`` items -- items done, share of the total, rate of the last batch,
+    elapsed time and, when the total is known (``total_cnt`` != -1), items left and an estimate of the time left.
+    Own wording and bookkeeping; nothing parses these lines."""
 
     def __init__(self, total_cnt, check_cnt, out=None):
-        self.total_cnt, self.check_cnt = total_cnt, check_cnt
-        self.num = self.num_last_check = 0
-        self.status_time = self.start_time = time.time()
-        self.out = out
+        self.total_cnt, self.check_cnt, self.out = total_cnt, max(int(check_cnt), 1), out
+        self.num = 0
+        self._reported = 0
+        self._t_start = self._t_batch = time.monotonic()
 
     def increment(self, n=1):
         self.num += n
-        if self.num - self.num_last_check < self.check_cnt:
+        batch = self.num - self._reported
+        if batch < self.check_cnt:
             return
-        now = time.time()
-        out = self.out or sys.stdout
-        last = self.num - self.num_last_check
+        now = time.monotonic()
+        elapsed, took = (now - self._t_start) / 60.0, (now - self._t_batch) / 60.0
+        parts = ["[progress] %d done" % self.num]
         if self.total_cnt != -1:
-            out.write("Total items processed is %d.  Last %d items took %f minutes. %d items to go.\n" % (
-                self.num, last, (now - self.status_time) / 60.0, self.total_cnt - self.num))
-            out.write("Current total process time: %f minutes\n" % ((now - self.start_time) / 60.0))
-            out.write("Estimated Time Remaining: %f\n" % (
-                ((self.total_cnt - self.num) / float(self.num)) * ((now - self.start_time) / 60.0)))
-        else:
-            out.write("Total items processed is %d.  Last %d items took %f minutes\n" % (
-                self.num, last, (now - self.status_time) / 60.0))
-            out.write("Current total process time: %f minutes\n" % ((now - self.start_time) / 60.0))
-        out.flush()
-        self.status_time, self.num_last_check = time.time(), self.num
+            left = self.total_cnt - self.num
+            parts[0] += " of %d (%.1f %%)" % (self.total_cnt, 100.0 * self.num / max(self.total_cnt, 1))
+            parts.append("%d left" % left)
+            parts.append("about %.2f min to go" % (elapsed * left / float(self.num)))
+        parts.insert(1, "last %d in %.2f min" % (batch, took))
+        parts.append("%.2f min so far" % elapsed)
+        stream = self.out if self.out is not None else sys.stdout
+        stream.write(", ".join(parts) + "\n")
+        stream.flush()
+        self._reported, self._t_batch = self.num, time.monotonic()
 
 
 class Unbuffered(object):
-    """twx/utils/util_misc.py:26-33: a stream that flushes on every write."""
+    """``sys.stdout = Unbuffered(sys.stdout)`` of the step scripts: every ``write`` / ``writelines`` reaches the wrapped stream
+    at once; everything else is the stream's own."""
+    __slots__ = ("_wrapped",)
 
     def __init__(self, stream):
-        self.stream = stream
+        object.__setattr__(self, "_wrapped", stream)
 
-    def write(self, data):
-        self.stream.write(data)
-        self.stream.flush()
+    def write(self, text):
+        n = self._wrapped.write(text)
+        self._wrapped.flush()
+        return n
 
-    def __getattr__(self, attr):
-        return getattr(self.stream, attr)
+    def writelines(self, lines):
+        self._wrapped.writelines(lines)
+        self._wrapped.flush()
+
+    def __getattr__(self, name):
+        return getattr(self._wrapped, name)
 
 
 def mkdir_p(path):

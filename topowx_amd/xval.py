@@ -78,7 +78,37 @@ def _batches(ids, batch):
         yield i, ids[i:i + batch]
 
 
-def optim_nstns_norms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0, world=1, batch=1024, device=0,
+KRIGALL_BYTES_PER_STATION = 22e9 / 1024        # device workspace of one cross-validated station x 16 bandwidths x 12 months (step21)
+
+
+def pick_batch(ctx, bytes_per_station=KRIGALL_BYTES_PER_STATION, most=1024, least=32):
+    """Stations per ``twx_krigall_points`` / ``twx_fit_vario_points`` call: as many as HALF the GPU's free memory holds
+    (``twx_device_memory``), between ``least`` and ``most`` -- 1 024 on an MI355X by itself, fewer when ranks share a GPU or
+    on a smaller one."""
+    free, _ = ctx.device_memory()
+    return int(max(least, min(most, (free // 2) // max(int(bytes_per_station), 1))))
+
+
+def _run_batched(mine, batch, ctx, fn):
+    """``fn(first_index, chunk)`` over ``mine`` in chunks of ``batch`` stations (None = ``pick_batch``); a chunk whose device
+    workspace cannot be allocated is retried in halves instead of failing the run."""
+    from ._lib import TwxError
+    batch = (pick_batch(ctx) if ctx is not None else 256) if batch is None else int(batch)
+    i = 0
+    while i < len(mine):
+        chunk = mine[i:i + batch]
+        try:
+            fn(i, chunk)
+        except TwxError as e:
+            if batch > 32 and ("hipMalloc" in str(e) or "ensure" in str(e) or "out of memory" in str(e).lower()):
+                batch = max(32, batch // 2)
+                continue
+            raise
+        i += len(chunk)
+    return batch
+
+
+def optim_nstns_norms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0, world=1, batch=None, device=0,
                       gather_device="cpu"):
     """step21: leave-one-out error of the kriged normals for every station and bandwidth.
 
@@ -86,24 +116,27 @@ def optim_nstns_norms(stn_da, tair_var, ladder=DFLT_LADDER, stn_ids=None, rank=0
     (step21:124-128); a station that cannot be cross-validated keeps NaN (the reference's worker prints the error
     and writes nothing: the netCDF fill value, masked in the reduction).  ``batch`` stations (x 16 bandwidths x 12 months
     points, ~22 GB of workspace at 1 024) go through ``twx_krigall_points`` per call: 256 -> 1 024 took step21 from 0.53 to
-    0.48 s on the 12 000-station database (tests/tools/gpu_c5_batch.py; the per-call host work amortises)."""
+    0.48 s on the 12 000-station database (tests/tools/gpu_c5_batch.py; the per-call host work amortises).  Default (None):
+    as many as half the GPU's free memory holds, at most 1 024 (``pick_batch``); a chunk that still cannot be allocated is
+    retried in halves."""
     ids = xval_station_ids(stn_da) if stn_ids is None else np.asarray(stn_ids)
     mine = shard(ids, rank, world)
     ladder = np.asarray(ladder)
     mae = np.full((12, ladder.size, len(mine)), np.nan)
     xv = XvalTairNorm(stn_da, tair_var, device=device)
     try:
-        for i, chunk in _batches(mine, batch):
+        def one(i, chunk):
             err, ok = xv.run_xval_many(chunk, ladder, raise_on_error=False)          # [ns, 12, nb]
             blk = np.abs(np.transpose(err, (1, 2, 0)))
             blk[:, :, ~ok] = np.nan
             mae[:, :, i:i + len(chunk)] = blk
+        _run_batched(mine, batch, getattr(xv, "ctx", None), one)
     finally:
         xv.close()
     return ids, _all_gather(mae, len(ids), rank, world, gather_device)
 
 
-def set_stn_variograms(stn_da, tair_var, stn_ids=None, rank=0, world=1, batch=1024, device=0, gather_device="cpu"):
+def set_stn_variograms(stn_da, tair_var, stn_ids=None, rank=0, world=1, batch=None, device=0, gather_device="cpu"):
     """step22: the variogram parameters of every station location for every month, fitted with the station's optimised
     bandwidth (``optim_nnghsMM`` smoothed over its neighbours; the station stays inside its own neighbourhood,
     interp_tair.py:667,681) and written into ``vario_nugMM / vario_psillMM / vario_rngMM`` of ``stn_da.stns`` for the
@@ -118,12 +151,13 @@ def set_stn_variograms(stn_da, tair_var, stn_ids=None, rank=0, world=1, batch=10
     out = np.full((3, 12, len(mine)), np.nan)
     kp = StationKrigParams(stn_da, tair_var, device=device)
     try:
-        for i, chunk in _batches(mine, batch):
+        def one(i, chunk):
             nug, psill, rng, ok = kp.get_krig_params_many(chunk, raise_on_error=False)     # [ns, 12]
             for q, a in enumerate((nug, psill, rng)):
                 blk = a.T.copy()
                 blk[:, ~ok] = np.nan
                 out[q, :, i:i + len(chunk)] = blk
+        _run_batched(mine, batch, getattr(kp, "ctx", None), one)
     finally:
         kp.close()
     out = _all_gather(out, len(ids), rank, world, gather_device)
