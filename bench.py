@@ -745,8 +745,11 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
     ``(ndays, 50, 50)`` int16, uncompressed as the reference's tiles are) through ``ncio.TileSink`` as the sink of
     ``driver.interp_tiles_streamed``, against the same tiles into a discarding sink.  Every tile's files are deleted once written
     (and, the first one, read back through libhdf5 and compared with the pinned block the GPU's outputs arrived in): a run of
-    8 tiles is 50 GB.  Also two tiles deflated (shuffle + zlib level 1, as the reference's MOSAICS are stored)."""
+    8 tiles is 50 GB.  Also two tiles deflated (shuffle + zlib level 1, as the reference's MOSAICS are stored).  The timed runs
+    only write (files are deleted after the run when the file system has room for all of them, else by a second thread); one
+    more tile per mode is written, read back through libhdf5 and compared, outside the timing."""
     import shutil
+    from concurrent.futures import ThreadPoolExecutor
     from topowx_amd import driver, ncio
     from topowx_amd.interp import Tiler
     base = args.c4_sink_dir
@@ -760,21 +763,32 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
     try:
         _, wall0, _ = driver.interp_tiles_streamed(ctx, grid, tiles, T, T, daily=True, sink=lambda k, a: None, precision=args.c4_precision)
         rec["wall_discarding_sink_s"] = wall0
+        per_tile = 2 * days.size * T * T * 2 * 1.01
         for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2])):
-            sink = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), order=[t[0] for t in sub], **kw)
+            keep_all = shutil.disk_usage(base).free > 2.5 * per_tile * len(sub) + 40e9      # room for every tile of the run: delete afterwards
+            sink = ncio.TileSink(info, out_dir, days, threads=threads, order=[t[0] for t in sub], **kw)
+            dropper = ThreadPoolExecutor(1)
 
-            def write_and_drop(k, arrays, sink=sink):
+            def write(k, arrays, sink=sink, keep_all=keep_all, dropper=dropper):
                 sink(k, arrays)
-                shutil.rmtree(os.path.join(out_dir, info.get_tile_id(k)), ignore_errors=True)
-            _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write_and_drop, precision=args.c4_precision)
+                if not keep_all:                                 # (off the sink's thread: freeing 6 GB of pages takes about a second)
+                    dropper.submit(shutil.rmtree, os.path.join(out_dir, info.get_tile_id(k)), True)
+            _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write, precision=args.c4_precision)
             sink.close()
-            st = sink.stats
+            dropper.shutdown(wait=True)
+            st = dict(sink.stats)
+            shutil.rmtree(out_dir, ignore_errors=True)
+            # one more tile, outside the timing: written, read back through libhdf5, compared with the pinned block it came from
+            chk = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), **kw)
+            driver.interp_tiles_streamed(ctx, grid, sub[:1], T, T, daily=True, sink=chk, precision=args.c4_precision)
+            chk.close()
+            shutil.rmtree(out_dir, ignore_errors=True)
             rec[name] = {"tiles": st["tiles"], "wall_s": wall, "int16_GB": st["int16_bytes"] / 1e9, "on_disk_GB": st["disk_bytes"] / 1e9,
                          "int16_GBps_end_to_end": st["int16_bytes"] / wall / 1e9, "on_disk_GBps_end_to_end": st["disk_bytes"] / wall / 1e9,
                          "sink_busy_s": st["total_s"], "of_it_waiting_for_prepared_files_s": st["prepare_s"], "of_it_bulk_copy_s": st["copy_s"],
                          "posix_fallocate_s_off_thread": st["fallocate_s"], "look_ahead": st["look_ahead"],
                          "int16_GBps_while_sink_busy": st["int16_bytes"] / max(st["total_s"], 1e-9) / 1e9,
-                         "tiles_read_back_equal": st["verified"]}
+                         "files_kept_until_the_end_of_the_run": keep_all, "tiles_read_back_equal": chk.stats["verified"]}
         rec["host_new_page_rate"] = host_page_rates(base, threads)
         n4 = rec["netcdf4"]
         rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files against %.1f GB/s into a discarding sink.  New file "

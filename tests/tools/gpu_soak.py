@@ -2,8 +2,9 @@
 Every case draws its own grid extent and shape (not multiples of the 8-cell tiles), mask, station count, nugget scale
 (down to values that route systems to the fp64 covariance build), close station pairs, Tmax offset (days with
 tmin >= tmax for the fixer), batch size and flags; some cases have too few stations or NaN predictors (failure statuses).
-A cell whose ninvalid differs because a day's tmax - tmin is within 2e-5 degC of 0 on the oracle's side (the fixer's test is
-discontinuous there) is reported as a near tie and set aside.  Not part of the test suite (minutes of oracle time): run on the GPU
+No cell is set aside: the fixer's test tmin >= tmax is discontinuous, but since round 6 the library re-kriges every cell with
+a day of |tmax - tmin| < 2e-5 degC on the fp64 covariance build (the tie guard, include/twx.h), so ninvalid must be the oracle's in
+every cell; a case whose ninvalid differs FAILS, and the margins of the differing cells are reported.  Not part of the test suite (minutes of oracle time): run on the GPU
 box after kernel changes.   python3 tests/tools/gpu_soak.py [n_cases] [first_seed]  ->  gpurun_out/soak.json"""
 import datetime as dt
 import json
@@ -124,14 +125,9 @@ for seed in range(seed0, seed0 + ncase):
                             "oracle_days_tmin_ge_tmax": int((gap <= 0).sum()), "smallest_abs_gap_degC": float(np.abs(gap).min())})
         rec["ninvalid_mismatch_cells"] = int(rr.size)
         rec["ninvalid_mismatch_margins"] = margins
-        # near ties (a gap below 2e-5 degC, the size of the two sides' agreement on a daily value): those cells are set
-        # aside, everything else is compared as usual
-        if rr.size <= 64 and all(m["smallest_abs_gap_degC"] < 2e-5 for m in margins):
-            rec["near_tie_cells"] = int(rr.size)
-            ok = ok.copy()
-            ok[rr, cc] = False
-            rec["ninvalid_equal"] = bool(np.array_equal(got["ninvalid"][ok], want["ninvalid"][ok]))
+        rec["near_tie_cells"] = int(sum(1 for m in margins if m["smallest_abs_gap_degC"] < 2e-5))      # (diagnostic only)
     rec["f64_solves"] = int(tim.get("uk_f64_solves", -1)) if isinstance(tim, dict) else int(getattr(tim, "uk_f64_solves", -1))
+    rec["tie_cells"] = int(tim.get("tie_cells", -1)) if isinstance(tim, dict) else -1
     for k in ("norm_tmin", "norm_tmax", "se_tmin", "se_tmax"):
         d = np.abs(got[k].astype(np.float64) - want[k])[:, ok] if k in got else np.zeros(0)
         rec[k] = float(d.max()) if d.size else 0.0

@@ -494,13 +494,14 @@ class TileSink(object):
     through netCDF4-python (step25:177-185, tiling.py:488-537); a 250 x 250 tile of configs[3] is 25 such chunks of 126 MB
     per variable, and one GPU produces a tile every ~0.12 s.  Here, per tile and variable:
 
-    * PREPARE (needs no data; with ``order`` -- the tile numbers in the order they will arrive -- the NEXT tile's files are
-      prepared by a background thread while this tile's bytes are copied): the file is created with EVERY variable's chunks
+    * PREPARE (needs no data; with ``order`` -- the tile numbers in the order they will arrive -- the files of the next ``ahead``
+      tiles are prepared by background threads while this tile's bytes are copied): the file is created with EVERY variable's chunks
       allocated at creation, the daily variable's on page boundaries (``h5nc``: ``alloc_early`` + ``alignment``), coordinates
       and attributes are written, the chunk addresses are read (``H5Dget_chunk_info``), the file is closed -- and its pages
-      are allocated with ONE ``posix_fallocate``: new file pages by first touch cost a page fault each and serialise on the
-      file's page-cache lock (tests/tools/host_page_rates.py: ~1.5-2 GB/s per file however many threads), ``fallocate``
-      allocates them in one in-kernel loop (~10 GB/s);
+      are allocated with ONE ``posix_fallocate`` and mapped with ``MAP_POPULATE``: new file pages by first touch cost a page
+      fault each and serialise on the file's page-cache lock (tests/tools/host_page_rates.py on the GPU box: 1.3-4 GB/s per
+      file however many threads), ``fallocate`` allocates them in one in-kernel loop (13-18 GB/s per file), and the populated
+      map leaves the copy without a single fault;
     * WRITE: ``threads`` workers copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
       straight into the file's pages through one shared ``mmap`` -- each job one strided gather of a (days segment x chunk)
       piece, numpy releases the GIL for it -- so the transposition into chunk order IS the write, and no HDF5 call touches
@@ -516,7 +517,7 @@ class TileSink(object):
     number of tiles checked, raises on a difference)."""
 
     def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None,
-                 variables=("tmin", "tmax"), order=None):
+                 variables=("tmin", "tmax"), order=None, ahead=4):
         from concurrent.futures import ThreadPoolExecutor
         if not h5nc.available():
             raise IOError("TileSink needs libhdf5 (NetCDF-4 tiles); TileWriter writes classic netCDF without it")
@@ -525,8 +526,10 @@ class TileSink(object):
         self.threads = int(threads or min(64, os.cpu_count() or 8))
         self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
         self.pool = ThreadPoolExecutor(self.threads)
-        self.prep_pool = ThreadPoolExecutor(max(2, len(self.variables)))
+        self.ahead = max(1, int(ahead))                         # tiles prepared ahead of the one being written (6.3 GB of pages each)
+        self.prep_pool = ThreadPoolExecutor(max(2, len(self.variables) * (self.ahead if order is not None else 1)))
         self.order = list(order) if order is not None else None
+        self._pos = {k: i for i, k in enumerate(self.order)} if self.order is not None else {}
         self._ahead = {}                                        # tile number -> {var: future of _prepare_var}
         cy, cx = tile_grid_info.chk_size_y, tile_grid_info.chk_size_x
         nchunks = len(self.variables) * (tile_grid_info.tile_size_y // cy) * (tile_grid_info.tile_size_x // cx)
@@ -538,6 +541,7 @@ class TileSink(object):
 
     # ---- prepare: no data needed ----------------------------------------------------------------------------------------------
     def _prepare_var(self, k, var):
+        import mmap as _mmap
         import time as _t
         tile_id = self.info.get_tile_id(k)
         fpath = self.writer.fpath(tile_id, var)
@@ -549,19 +553,26 @@ class TileSink(object):
         fd = os.open(fpath, os.O_RDWR)
         try:
             os.posix_fallocate(fd, 0, os.fstat(fd).st_size)   # every page of the file, in one in-kernel loop (releases the GIL)
+            # ... and map them all at once (MAP_POPULATE): the copy then meets no page fault at all
+            size = os.fstat(fd).st_size
+            try:
+                mm = _mmap.mmap(fd, size, flags=_mmap.MAP_SHARED | getattr(_mmap, "MAP_POPULATE", 0x8000), prot=_mmap.PROT_READ | _mmap.PROT_WRITE)
+            except (OSError, ValueError):
+                mm = _mmap.mmap(fd, size)
         finally:
             os.close(fd)
         dt = _t.perf_counter() - t0
-        return fpath, np.memmap(fpath, dtype=np.uint8, mode="r+"), info, dt
+        return fpath, np.frombuffer(mm, np.uint8), info, dt
 
     def _prepared(self, k):
         futs = self._ahead.pop(k, None)
         if futs is None:
             futs = {v: self.prep_pool.submit(self._prepare_var, k, v) for v in self.variables}
-        if self.order is not None and k in self.order:          # the next tile's files, while this one is written
-            i = self.order.index(k) + 1
-            if i < len(self.order) and self.order[i] not in self._ahead:
-                self._ahead[self.order[i]] = {v: self.prep_pool.submit(self._prepare_var, self.order[i], v) for v in self.variables}
+        if k in self._pos:                                      # the next tiles' files, while this one is written: preparing a file
+            for i in range(self._pos[k] + 1, min(self._pos[k] + 1 + self.ahead, len(self.order))):   # (fallocate + populate)
+                nk = self.order[i]                              # takes longer than copying into it, and scales with the number of FILES
+                if nk not in self._ahead:
+                    self._ahead[nk] = {v: self.prep_pool.submit(self._prepare_var, nk, v) for v in self.variables}
         return {v: f.result() for v, f in futs.items()}
 
     @staticmethod
