@@ -227,7 +227,8 @@ int twx_set_stations(twx_ctx *ctx, int var, const twx_station_table *tbl);
  * twx_krigall_points, twx_fit_vario_points, twx_gwr_points, twx_gwr_xval_points, twx_interp_points), whose npts must
  * equal this call's.  lists [npts][nmax], entries < 0 = unused, 1 <= nmax <= TWX_MAX_EXCL.  The entry's own `excl` argument
  * (one index per point -- what every caller on the reference's path passes) still applies: the union is removed.
- * Consumed by that call, whether it succeeds or not; npts = 0 clears a pending list.  Library limit without reference
+ * Consumed by the next point-entry call that passes its argument checks, whether it then succeeds or not; npts = 0 clears a
+ * pending list.  Library limit without reference
  * counterpart: more than TWX_MAX_EXCL ids per point are refused here (call-level failure), never truncated. */
 #define TWX_MAX_EXCL 8
 int twx_set_exclusions(twx_ctx *ctx, int64_t npts, int32_t nmax, const int32_t *lists);

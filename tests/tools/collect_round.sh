@@ -21,3 +21,7 @@ python3 tests/tools/gpu_closepair_scan.py > gpurun_out/prof_round/closepair_scan
 python3 tests/tools/gpu_closepair_scan.py --fast-only > gpurun_out/prof_round/closepair_scan_fast.log 2>&1
 python3 tests/tools/gpu_f64_cost.py > gpurun_out/prof_round/f64_cost.log 2>&1
 cp gpurun_out/closepair_scan.json gpurun_out/closepair_scan_fast.json gpurun_out/f64_cost.json gpurun_out/prof_round/
+# round 6: the cycle floor of the kriging kernels' design and what the host gives a writer of new file pages
+python3 tests/tools/cycle_floor.py gpurun_out/sq_krig gpurun_out/prof_round/kernel_stats.csv > gpurun_out/prof_round/cycle_floor.md 2> gpurun_out/prof_round/cycle_floor.err
+python3 tests/tools/host_page_rates.py /dev/shm 8 > gpurun_out/prof_round/host_page_rates.log 2>&1
+cp gpurun_out/host_page_rates.json gpurun_out/prof_round/

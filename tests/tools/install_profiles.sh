@@ -25,3 +25,5 @@ cp topowx_amd/libtwxhip.resources.txt profiles/${R}_isa_resources.txt
 cp gpurun_out/prof_c4/c4_daily_traffic.json profiles/${R}_c4_daily_traffic.json
 cp gpurun_out/prof_c4/pmc_daily_FETCH_SIZE.csv profiles/${R}_c4_daily_pmc_FETCH_SIZE.csv
 cp gpurun_out/prof_c4/pmc_daily_WRITE_SIZE.csv profiles/${R}_c4_daily_pmc_WRITE_SIZE.csv
+[ -f $P/cycle_floor.md ] && cp $P/cycle_floor.md profiles/${R}_cycle_floor.md
+[ -f $P/host_page_rates.json ] && cp $P/host_page_rates.json profiles/${R}_host_page_rates.json

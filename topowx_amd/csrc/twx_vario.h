@@ -84,6 +84,10 @@ __device__ __forceinline__ double block_max(double v, double *s_tmp)
 // ksel (ksel - 1) / 2.  Evaluated per (point, pass) the distance formula was ~70 of the ~110 instructions of k_vario's pair
 // loop, 64 x redundantly in step21 (profiles/README.md, round 5).  One work-group per list; pair (i, j) at i (i - 1) / 2 + j.
 // ---------------------------------------------------------------------------------
+// INVARIANT the sharing rests on: every point of a list has the SAME ranked neighbour list.  The host forms the lists
+// (upload_points, twx_hip.hip) from everything select_cell's ranking depends on per point -- location, the excluded station,
+// the further exclusion list of twx_set_exclusions --; rm_zero_dist and the station table are per call.  A new per-point
+// selection input must join that key, or k_vario would pair the first point's distances with another point's residuals.
 __global__ __launch_bounds__(256) void k_group_dist64(StnDev st, CellSrc src, SelWs ws)
 {
     __shared__ double s_trig[5][TWX_KSEL_MAX];

@@ -498,10 +498,11 @@ class TileSink(object):
       tiles are prepared by background threads while this tile's bytes are copied): the file is created with EVERY variable's chunks
       allocated at creation, the daily variable's on page boundaries (``h5nc``: ``alloc_early`` + ``alignment``), coordinates
       and attributes are written, the chunk addresses are read (``H5Dget_chunk_info``), the file is closed -- and its pages
-      are allocated with ONE ``posix_fallocate`` and mapped with ``MAP_POPULATE``: new file pages by first touch cost a page
-      fault each and serialise on the file's page-cache lock (tests/tools/host_page_rates.py on the GPU box: 1.3-4 GB/s per
-      file however many threads), ``fallocate`` allocates them in one in-kernel loop (13-18 GB/s per file), and the populated
-      map leaves the copy without a single fault;
+      are allocated with ONE ``posix_fallocate``: new file pages by first touch cost a page fault each and serialise on the
+      file's page-cache lock (tests/tools/host_page_rates.py on the GPU box: 1.3-4 GB/s per file however many threads),
+      ``fallocate`` allocates them in one in-kernel loop (13-18 GB/s per file).  (``populate=True`` also maps them ahead,
+      ``MAP_POPULATE``: the copy itself then runs at 43 GB/s instead of 12, but building and tearing down 1.5 M page-table
+      entries per file queues on the process's address-space lock -- 4.5 GB/s end to end against 9.5 without it, measured.)
     * WRITE: ``threads`` workers copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
       straight into the file's pages through one shared ``mmap`` -- each job one strided gather of a (days segment x chunk)
       piece, numpy releases the GIL for it -- so the transposition into chunk order IS the write, and no HDF5 call touches
@@ -517,7 +518,7 @@ class TileSink(object):
     number of tiles checked, raises on a difference)."""
 
     def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None,
-                 variables=("tmin", "tmax"), order=None, ahead=4):
+                 variables=("tmin", "tmax"), order=None, ahead=2, populate=False, prep_threads=2):
         from concurrent.futures import ThreadPoolExecutor
         if not h5nc.available():
             raise IOError("TileSink needs libhdf5 (NetCDF-4 tiles); TileWriter writes classic netCDF without it")
@@ -527,7 +528,11 @@ class TileSink(object):
         self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
         self.pool = ThreadPoolExecutor(self.threads)
         self.ahead = max(1, int(ahead))                         # tiles prepared ahead of the one being written (6.3 GB of pages each)
-        self.prep_pool = ThreadPoolExecutor(max(2, len(self.variables) * (self.ahead if order is not None else 1)))
+        self.populate = bool(populate)
+        # few preparing threads: one fallocate runs at 13-18 GB/s by itself, and everything that changes the process's address
+        # space (mmap + populate, munmap) queues on ONE lock -- eight concurrent preparations were slower than two
+        self.prep_pool = ThreadPoolExecutor(max(1, int(prep_threads)))
+        self.unmap_pool = ThreadPoolExecutor(1)                 # dropping a 3 GB mapping takes ~0.3 s: off the sink's thread
         self.order = list(order) if order is not None else None
         self._pos = {k: i for i, k in enumerate(self.order)} if self.order is not None else {}
         self._ahead = {}                                        # tile number -> {var: future of _prepare_var}
@@ -556,7 +561,8 @@ class TileSink(object):
             # ... and map them all at once (MAP_POPULATE): the copy then meets no page fault at all
             size = os.fstat(fd).st_size
             try:
-                mm = _mmap.mmap(fd, size, flags=_mmap.MAP_SHARED | getattr(_mmap, "MAP_POPULATE", 0x8000), prot=_mmap.PROT_READ | _mmap.PROT_WRITE)
+                mm = _mmap.mmap(fd, size, flags=_mmap.MAP_SHARED | (getattr(_mmap, "MAP_POPULATE", 0x8000) if self.populate else 0),
+                                prot=_mmap.PROT_READ | _mmap.PROT_WRITE)
             except (OSError, ValueError):
                 mm = _mmap.mmap(fd, size)
         finally:
@@ -643,7 +649,11 @@ class TileSink(object):
                 var_obj.write_chunk_raw(off, res)
         for ds in open_ds:
             ds.close()
-        del maps
+        if not self.zlib:                                       # the mappings die on the unmapping thread, not here
+            holder = [maps, prepared]
+            maps = prepared = mm = None
+            self.unmap_pool.submit(holder.clear)
+            del holder
         self.stats["copy_s"] += _t.perf_counter() - t1
         for var in present:
             self.stats["int16_bytes"] += int(arrays["daily_" + var].nbytes)
@@ -673,6 +683,7 @@ class TileSink(object):
                 except Exception:                               # noqa: BLE001
                     pass
         self._ahead.clear()
+        self.unmap_pool.shutdown(wait=True)
         self.prep_pool.shutdown(wait=True)
         self.pool.shutdown(wait=True)
 
