@@ -119,6 +119,12 @@ def test_bench_c2_fitted_and_c4_reduced():
     assert c["tiles"] >= 4 and c["cells_ok"] + sum(c["failures_by_status"].values()) == c["cells_valid"]
     assert c["cell_days"] == c["cells_ok"] * 731 * 2 and c["value"] > 0 and c["d2h_bytes"] > 0
     assert c["device_ms_per_tile"]["min"] <= c["device_ms_per_tile"]["median"] <= c["device_ms_per_tile"]["max"]
+    pr = c["precision"]                                 # driver.PrecisionPolicy: requested "auto", the decision in words
+    assert pr["requested"] == "auto" and pr["precision"] in ("exact", "fast") and pr["tiles_exact"] + pr["tiles_fast"] == c["tiles"]
+    k = c["sink"]                                       # ncio.TileSink: tiles into NetCDF-4 tile files, read back through libhdf5
+    assert k["netcdf4"]["tiles"] >= 4 and k["netcdf4"]["tiles_read_back_equal"] == 1 and k["netcdf4"]["int16_GBps_end_to_end"] > 0
+    assert k["netcdf4_deflate1"]["tiles_read_back_equal"] == 1 and k["netcdf4_deflate1"]["on_disk_GB"] < k["netcdf4_deflate1"]["int16_GB"]
+    assert k["host_new_page_rate"]["cold_GBps"] > 0 and "posix_fallocate" in k["limiting_stage"]
     s = c["spot_check_vs_oracle"]
     assert s["cells"] >= 12 and s["tiles"] >= 3 and s["status_equal"] and s["ninvalid_equal"]
     assert s["normals_max_abs_degC"] < 1e-4 and s["int16_max_abs_lsb"] <= 1

@@ -251,3 +251,36 @@ def test_non_finite_observations_are_rejected(golden_case):
         ctx.set_stations(_lib.TMIN, sdb.StationDataWrkChk(tmin.stns.copy(), "tmin", tmin.days, obs))
     ctx.set_stations(_lib.TMIN, tmin)             # the context is still usable
     ctx.close()
+
+
+def test_streamed_tiles_into_netcdf4_tile_files(golden_case, tmp_path):
+    """driver.interp_tiles_streamed with ncio.TileSink as its sink (the reference's workers write every chunk into the tile's
+    netCDF, step25:177-185, tiling.py:488-537): the files hold what the synchronous path computes, chunked (ndays, cy, cx) as the
+    reference's TileWriter lays them out, in both forms -- chunks copied straight into the file's pages / deflated by the sink."""
+    from topowx_amd import _lib, driver, h5nc, ncio
+    from topowx_amd.interp import Tiler
+    if not h5nc.available():
+        pytest.skip("libhdf5 not loadable")
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    tiles = driver.tile_list(grid["mask"], 50, 50)
+    want = driver.interp_tiles(grid, driver.gpu_compute(ctx, daily=True), tiles, 50, 50)
+    info = Tiler(grid, 50, 50, 10, 10, process_tiles=()).build_tile_grid_info()
+    for zl in (False, True):
+        out = str(tmp_path / ("tiles%d" % zl))
+        sink = ncio.TileSink(info, out, tmin.days, threads=6, zlib=zl, order=[t[0] for t in tiles], verify=(tiles[1][0],))
+        driver.interp_tiles_streamed(ctx, grid, tiles, 50, 50, daily=True, sink=sink, precision="fast")
+        sink.close()
+        assert sink.stats["tiles"] == 4 and sink.stats["verified"] == 1
+        for k, i, j, _ in tiles:
+            for var in ("tmin", "tmax"):
+                t = ncio.read_tile(sink.writer.fpath(info.get_tile_id(k), var), var)
+                assert np.array_equal(t["daily"], want[k]["daily_" + var]) and np.array_equal(t["norm"], want[k]["norm_" + var])
+                assert np.array_equal(t["se"], want[k]["se_" + var]) and np.array_equal(t["ninvalid"], want[k]["ninvalid"])
+                np.testing.assert_array_equal(t["lat"], grid["lat"][i:i + 50])
+        ds = ncio.open_dataset(sink.writer.fpath(info.get_tile_id(0), "tmax"))
+        assert ds.variables["tmax"].chunking() == [tmin.days.size, 10, 10] and ds.variables["tmax"].filters()["zlib"] == zl
+        ds.close()
+    ctx.close()

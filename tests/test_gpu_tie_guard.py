@@ -138,3 +138,26 @@ def test_guard_off_is_the_round5_behaviour_and_no_host_sync_guards_too(planted):
     assert not np.any(d & ~planted_mask)
     nosync, t2 = _run(lib, grid, tmin, tmax, lib.FLAG_NO_HOST_SYNC)
     assert np.array_equal(nosync["ninvalid"], want["ninvalid"]) and t2["tie_cells"] >= len(CELLS)
+
+
+@pytest.mark.gpu
+def test_point_mode_guards_the_same_ties(planted):
+    """PtInterpTair.interp_pt (the reference's per-point contract, interp_tair.py:526-592) on the planted cells: the facade
+    sees the near tie in the two series and interpolates the point once more in the exact precision."""
+    from topowx_amd import stationdb as sdb
+    from topowx_amd.interp import PtInterpTair
+    grid, tmin, tmax, want = planted
+    p = PtInterpTair(tmin, tmax)
+    try:
+        for (r, c), t in zip(CELLS, TARGETS):
+            pt = p.a_pt
+            pt[sdb.LON], pt[sdb.LAT], pt[sdb.ELEV], pt[sdb.TDI] = grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c]
+            for m in range(1, 13):
+                pt["tmin%02d" % m], pt["tmax%02d" % m] = grid["lst_night"][m - 1, r, c], grid["lst_day"][m - 1, r, c]
+            tmin_d, tmax_d, nmin, nmax, smin, smax, ninv = p.interp_pt()
+            i, j = r - ROWS.start, c - COLS.start
+            assert ninv == want["ninvalid"][i, j], (r, c, t)
+            assert np.abs(nmin - want["norm_tmin"][:, i, j]).max() < 1e-4 and np.abs(nmax - want["norm_tmax"][:, i, j]).max() < 1e-4
+            assert np.all(tmin_d < tmax_d)
+    finally:
+        p.close()

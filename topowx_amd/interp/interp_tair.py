@@ -215,7 +215,9 @@ class PtInterpTair(object):
             raise Exception('Point is outside interpolation region')
         return self.interp_pt(fixInvalid, stns_rm)
 
-    def interp_pt(self, fix_invalid=True, stns_rm=None):
+    TIE_EPS = 2e-5      # degC: the grid entries' tie guard (include/twx.h, TWX_FLAG_NO_TIE_GUARD), here on the host
+
+    def _both(self, stns_rm):
         pt = self.a_pt
         out = []
         for v, itp in (("tmin", self.interp_tmin), ("tmax", self.interp_tmax)):
@@ -227,6 +229,19 @@ class PtInterpTair(object):
                                                           daily=not self.norms_only)
             raise_for_status(st[0])
             out.append((daily[0] if daily is not None else None, norms[0], se[0]))
+        return out
+
+    def interp_pt(self, fix_invalid=True, stns_rm=None):
+        out = self._both(stns_rm)
+        if fix_invalid and not self.norms_only and np.any(np.abs(out[1][0] - out[0][0]) < self.TIE_EPS):
+            # a day whose Tmax - Tmin lies within the fast covariance build's ~1e-6 degC of 0 could fall on the other side of
+            # the fixer's test (interp_tair.py:170) than in the reference's fp64 arithmetic: this point once more, every
+            # kriging system on the fp64 build, so that the fixed days and ninvalid do not depend on it
+            self.ctx.set_precision("exact")
+            try:
+                out = self._both(stns_rm)
+            finally:
+                self.ctx.set_precision("fast")
         (tmin_dly, tmin_norms, tmin_se), (tmax_dly, tmax_norms, tmax_se) = out
         ninvalid = 0
         if fix_invalid and not self.norms_only:
