@@ -745,13 +745,13 @@ __host__ __device__ __forceinline__ int twx_krig_bucket(int k)
     return b < 9 ? b : (b < 11 ? 10 : (b < 13 ? 12 : 13));
 }
 
-// fp64-build bucket of a SPARSELY routed system (amplification > TWX_F64_AMP, tie-guard cells): one of FOUR sizes -- 64 rows
-// (k_ukwz<4, 1>), 96 (k_ukwz<6, 1>), 128 (k_uk<8, 4, 1>), 160 (k_uk<10, 2, 1>) -- instead of its own of fourteen: a batch with
-// a handful of routed systems pays four small launches per variable instead of up to fourteen.  Measured (EXPERIMENTS.md, round
-// 6): the tie guard's second pass 1.04 -> 0.54 ms for 32 cells; no effect either way on a full configs[2] pass that routes
-// 0.7 % of its systems.  A system in a larger kernel eliminates identity rows (pivot 1, factors 0): same result.  With every
-// system routed (TWX_FLAG_UK_F64_ALL / precision "exact") a system keeps the kernel of its own size: there the padding would
-// cost more than the launches.
+// fp64-build bucket of a system of the TIE GUARD's second pass (SelWs.rerun: a few dozen cells of a batch): one of FOUR sizes
+// -- 64 rows (k_ukwz<4, 1>), 96 (k_ukwz<6, 1>), 128 (k_uk<8, 4, 1>), 160 (k_uk<10, 2, 1>) -- instead of its own of fourteen:
+// 8 small launches for both variables instead of up to 28 (1.04 -> 0.54 ms for 32 guarded cells).  A system in a larger
+// kernel eliminates identity rows (pivot 1, factors 0): same result.  Systems routed by their amplification keep the
+// kernel of their own size whatever their number: a table may route MOST of its systems (then the padding of a larger
+// kernel costs 13 %: 15.7 -> 17.8 ms on the all-routed C2 step), and a run that routes 0.7 % of them gained nothing from
+// fewer launches (EXPERIMENTS.md, round 6).
 __host__ __device__ __forceinline__ int twx_f64_coarse_bucket(int b) { return b <= 3 ? 3 : (b <= 7 ? 7 : (b <= 10 ? 10 : 13)); }
 
 // Which systems need the fp64 covariance build.  The fast build forms every off-diagonal entry psill exp(-h / range)
@@ -804,9 +804,9 @@ __global__ __launch_bounds__(256) void k_bucket_items(SelWs ws)
             const double nug = ws.vario[item * 3], psill = ws.vario[item * 3 + 1], rng = ws.vario[item * 3 + 2];
             if (ws.f64_all || ws.rerun || (!ws.fast_only && uk_may_need_f64(nug, psill, rng) &&
                                uk_needs_f64(nug, psill, rng, ws.hminp[lc * ws.ksel + min(k, ws.ksel) - 1]))) {
-                // all routed: its own matrix size's fp64-build kernel; sparsely routed: one of four sizes (twx_f64_coarse_bucket);
+                // its own matrix size's fp64-build kernel (the tie guard's pass: one of four sizes, twx_f64_coarse_bucket);
                 // without slabs the two-wave kernels of 112 / 160 rows take all of them
-                id = TWX_BUCKET_F64 + (ws.f64_sized ? (ws.f64_all ? id : twx_f64_coarse_bucket(id)) : (k > 104 ? 13 : 8));
+                id = TWX_BUCKET_F64 + (ws.f64_sized ? (ws.rerun ? twx_f64_coarse_bucket(id) : id) : (k > 104 ? 13 : 8));
                 // the first routed month of a cell claims the cell a slot in the fp64 slabs (read by later kernels only)
                 if (atomicCAS(&ws.cellf64[lc], 0, -1) == 0) {
                     const int slot = atomicAdd(ws.nf64, 1);
