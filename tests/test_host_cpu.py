@@ -99,3 +99,44 @@ def test_xcd_contiguous_order_is_a_bijection():
         for x in range(8):
             mine = [g for w, g in enumerate(got) if w % 8 == x and g >= 0]
             assert mine == list(range(x * per, min(n, (x + 1) * per)))
+
+
+def test_precision_policy_decides_once_on_the_median_of_three_tiles():
+    """driver.PrecisionPolicy (host logic, no GPU): "auto" starts exact and keeps it when the MEDIAN device time of the first three
+    exact tiles hides behind the median copy-out time -- one slow tile (workspace growth) does not flip the run --, falls back to fast
+    otherwise, and never looks again; "fast" / "exact" are taken as they are; the context is handed back in the fast mode."""
+    from topowx_amd import driver
+
+    class Ctx(object):
+        def __init__(self):
+            self.calls = []
+
+        def set_precision(self, mode):
+            self.calls.append(mode)
+
+    c = Ctx()
+    p = driver.PrecisionPolicy(c, "auto")
+    assert p.mode == "exact" and c.calls == ["exact"]
+    for k, (dev, cp) in enumerate(((546.0, 114.0), (52.0, 112.0), (51.0, 111.0))):     # the first tile grew the fp64 slabs
+        assert p.mode == "exact"
+        p.observe("exact", dev, cp, tile=k)
+    assert p.decided and p.mode == "exact" and p.decision.startswith("exact throughout")
+    p.observe("exact", 900.0, 1.0, tile=3)                       # decided: later tiles change nothing
+    assert p.mode == "exact" and p.summary()["tiles_exact"] == 4 and p.summary()["tile_modes"] == {0: "exact", 1: "exact", 2: "exact", 3: "exact"}
+    p.close()
+    assert c.calls[-1] == "fast"
+    c = Ctx()
+    p = driver.PrecisionPolicy(c, "auto")                        # normals-only tiles: kernels 2.5 ms, copy-out 0.1 ms
+    for k in range(3):
+        p.observe("exact", 2.5, 0.1, tile=k)
+    assert p.mode == "fast" and c.calls == ["exact", "fast"] and p.decision.startswith("fast after 3 tiles")
+    p.observe("fast", 2.0, 0.1, tile=3)
+    s = p.summary()
+    assert s["precision"] == "fast" and s["tiles_exact"] == 3 and s["tiles_fast"] == 1 and s["requested"] == "auto"
+    for req in ("fast", "exact"):
+        c = Ctx()
+        p = driver.PrecisionPolicy(c, req)
+        p.observe(req, 100.0, 1.0)
+        assert p.mode == req and p.decided and c.calls == [req] and p.decision == "as requested"
+    with pytest.raises(ValueError):
+        driver.PrecisionPolicy(Ctx(), "double")

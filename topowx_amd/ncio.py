@@ -676,11 +676,13 @@ class TileSink(object):
             self.stats["verified"] += 1
 
     def close(self):
-        for futs in self._ahead.values():                       # (files prepared for tiles that never came are left complete but empty)
+        for futs in self._ahead.values():                       # files prepared for tiles that never came hold no data: remove them
             for f in futs.values():
                 try:
-                    f.result()
-                except Exception:                               # noqa: BLE001
+                    fpath = f.result()[0]
+                    os.remove(fpath)
+                    os.rmdir(os.path.dirname(fpath))            # (the tile's directory, when this was its last file)
+                except Exception:                               # noqa: BLE001 -- a failed preparation, a directory still in use
                     pass
         self._ahead.clear()
         self.unmap_pool.shutdown(wait=True)
