@@ -98,9 +98,9 @@ def parse():
     ap.add_argument("--c4-years", type=int, default=69, help="c4 record: years of days from 1948 (69 = 1948-2016, 25 203 days)")
     ap.add_argument("--c4-precision", default="auto", choices=("auto", "fast", "exact"),
                     help="c4 record: covariance build of the streamed run (driver.PrecisionPolicy; auto = exact while it is free)")
-    ap.add_argument("--c4-sink-tiles", type=int, default=8, help="c4 record: tiles written into NetCDF-4 tile files by ncio.TileSink (0 = skip)")
+    ap.add_argument("--c4-sink-tiles", type=int, default=16, help="c4 record: tiles written into NetCDF-4 tile files by ncio.TileSink (0 = skip)")
     ap.add_argument("--c4-sink-dir", default=None, help="where (default: /dev/shm when it has 20 GB free, else $TMPDIR)")
-    ap.add_argument("--c4-sink-threads", type=int, default=0, help="TileSink workers (0 = min(64, cpu count))")
+    ap.add_argument("--c4-sink-threads", type=int, default=0, help="TileSink workers (0 = min(32, cpu count))")
     ap.add_argument("--force-configs", action="store_true", help="time them also on a reduced --size (tests)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
                     help="auto: N = 1 headline (+ configs); N > 1 weak headline + a 'strong' record.  strong: the tile farm "
@@ -746,7 +746,7 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
     ``(ndays, 50, 50)`` int16, uncompressed as the reference's tiles are) through ``ncio.TileSink`` as the sink of
     ``driver.interp_tiles_streamed``, against the same tiles into a discarding sink.  Every tile's files are deleted once written
     (and, the first one, read back through libhdf5 and compared with the pinned block the GPU's outputs arrived in): a run of
-    8 tiles is 50 GB.  Also two tiles deflated (shuffle + zlib level 1, as the reference's MOSAICS are stored).  The timed runs
+    16 tiles is 100 GB.  Also two tiles deflated (shuffle + zlib level 1, as the reference's MOSAICS are stored).  The timed runs
     only write (files are deleted after the run when the file system has room for all of them, else by a second thread); one
     more tile per mode is written, read back through libhdf5 and compared, outside the timing."""
     import shutil
@@ -758,7 +758,7 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
         base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 20e9 else os.environ.get("TMPDIR", "/tmp")
     out_dir = os.path.join(base, "twx_c4_sink_%d" % os.getpid())
     info = Tiler(grid, T, T, 50, 50, process_tiles=()).build_tile_grid_info()
-    threads = args.c4_sink_threads or min(64, os.cpu_count() or 8)
+    threads = args.c4_sink_threads or min(32, os.cpu_count() or 8)
     rec = {"dir": base, "tiles": len(tiles), "threads": threads, "host_cpus": os.cpu_count(),
            "layout": "<tile_id>/<tile_id>_<var>.nc, NetCDF-4, daily int16 chunked (%d, 50, 50), normals / SE f4, inconsist_tair i4" % days.size}
     try:
@@ -767,14 +767,16 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
         per_tile = 2 * days.size * T * T * 2 * 1.01
         for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2])):
             keep_all = shutil.disk_usage(base).free > 2.5 * per_tile * len(sub) + 40e9      # room for every tile of the run: delete afterwards
-            sink = ncio.TileSink(info, out_dir, days, threads=threads, order=[t[0] for t in sub], **kw)
+            writers = 1 if kw["zlib"] else 2                     # (two tiles = four files written at once: pwrite rates add up per file)
+            sink = ncio.TileSink(info, out_dir, days, threads=threads, order=[t[0] for t in sub], ahead=3, prep_threads=4, **kw)
             dropper = ThreadPoolExecutor(1)
 
             def write(k, arrays, sink=sink, keep_all=keep_all, dropper=dropper):
                 sink(k, arrays)
                 if not keep_all:                                 # (off the sink's thread: freeing 6 GB of pages takes about a second)
                     dropper.submit(shutil.rmtree, os.path.join(out_dir, info.get_tile_id(k)), True)
-            _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write, precision=args.c4_precision)
+            _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write, precision=args.c4_precision,
+                                                      writer_threads=writers)
             sink.close()
             dropper.shutdown(wait=True)
             st = dict(sink.stats)
@@ -786,19 +788,21 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
             shutil.rmtree(out_dir, ignore_errors=True)
             rec[name] = {"tiles": st["tiles"], "wall_s": wall, "int16_GB": st["int16_bytes"] / 1e9, "on_disk_GB": st["disk_bytes"] / 1e9,
                          "int16_GBps_end_to_end": st["int16_bytes"] / wall / 1e9, "on_disk_GBps_end_to_end": st["disk_bytes"] / wall / 1e9,
+                         "sink_calls_in_flight": writers,
                          "sink_busy_s": st["total_s"], "of_it_waiting_for_prepared_files_s": st["prepare_s"], "of_it_bulk_copy_s": st["copy_s"],
                          "posix_fallocate_s_off_thread": st["fallocate_s"], "look_ahead": st["look_ahead"],
                          "int16_GBps_while_sink_busy": st["int16_bytes"] / max(st["total_s"], 1e-9) / 1e9,
                          "files_kept_until_the_end_of_the_run": keep_all, "tiles_read_back_equal": chk.stats["verified"]}
         rec["host_new_page_rate"] = host_page_rates(base, threads)
         n4 = rec["netcdf4"]
-        rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files against %.1f GB/s into a discarding sink.  New file "
-                                 "pages by first touch come at %.1f GB/s on this host (one file, %d threads: they serialise on the file's "
-                                 "page-cache lock), which is why the sink allocates a file's pages with ONE posix_fallocate (%.1f GB/s per "
-                                 "file here) off its own thread; the bulk copy into the allocated pages ran at %.1f GB/s"
-                                 % (n4["int16_GBps_end_to_end"], n4["int16_GB"] / wall0, rec["host_new_page_rate"]["cold_GBps"], threads,
-                                    n4["on_disk_GB"] / max(n4["posix_fallocate_s_off_thread"], 1e-9),
-                                    n4["int16_GB"] / max(n4["of_it_bulk_copy_s"], 1e-9)))
+        rec["limiting_stage"] = ("the sink: %.1f GB/s of int16 into NetCDF-4 tile files (pipeline start-up included) against %.1f GB/s into a "
+                                 "discarding sink.  New file pages by first touch come at %.1f GB/s on this host (one file, %d threads: they "
+                                 "serialise on the file's page-cache lock), so the sink allocates a file's pages with ONE posix_fallocate "
+                                 "(%.1f GB/s per file here) on look-ahead threads, gathers a tile into a warm staging buffer in chunk order "
+                                 "and pwrites the chunks -- ~11 GB/s per file, files add up -- with %d tiles in flight"
+                                 % (n4["int16_GBps_end_to_end"], n4["int16_GB"] / max(wall0, 1e-9),
+                                    rec["host_new_page_rate"]["cold_GBps"], threads,
+                                    n4["on_disk_GB"] / max(n4["posix_fallocate_s_off_thread"], 1e-9), n4["sink_calls_in_flight"]))
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
     return rec

@@ -271,7 +271,8 @@ def test_streamed_tiles_into_netcdf4_tile_files(golden_case, tmp_path):
     for zl in (False, True):
         out = str(tmp_path / ("tiles%d" % zl))
         sink = ncio.TileSink(info, out, tmin.days, threads=6, zlib=zl, order=[t[0] for t in tiles], verify=(tiles[1][0],))
-        driver.interp_tiles_streamed(ctx, grid, tiles, 50, 50, daily=True, sink=sink, precision="fast")
+        # (two sink calls in flight for the uncompressed form: TileSink is thread-safe, driver: writer_threads)
+        driver.interp_tiles_streamed(ctx, grid, tiles, 50, 50, daily=True, sink=sink, precision="fast", writer_threads=1 if zl else 2)
         sink.close()
         assert sink.stats["tiles"] == 4 and sink.stats["verified"] == 1
         for k, i, j, _ in tiles:

@@ -267,8 +267,10 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
     tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
     workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
-    returns (they are views of a pinned slot that is reused two tiles later); default: collect copies.
-    All tiles must have the shape tile_y x tile_x.  ``tile_ms``: a list that receives ``(tile_number, device_ms)`` per tile.
+    returns (they are views of a pinned slot that is reused two tiles later); default: collect copies.  ``writer_threads`` > 1:
+    that many sink calls may run at once (on as many pinned slots more) -- for a sink that is thread-safe and whose rate grows with
+    the number of tiles in flight (``ncio.TileSink``: new file pages come per FILE); tiles then reach the sink in order but may
+    finish out of order.  All tiles must have the shape tile_y x tile_x.  ``tile_ms``: a list that receives ``(tile_number, device_ms)`` per tile.
 
     ``precision``: "auto" | "fast" | "exact", see ``PrecisionPolicy`` -- auto = the fp64 covariance build (outputs exact to the
     last int16 / f4 bit) whenever the tiles' kernels hide behind their copy-out, i.e. for free.  ``log``: a dict that receives
@@ -282,7 +284,8 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     if sink is None:
         def sink(k, arrays):
             collected[k] = {n: np.array(v) for n, v in arrays.items() if hasattr(v, "shape")}
-    nslots = 3                                  # one computing, one copying out, one at the writer
+    writer_threads = max(1, int(writer_threads))
+    nslots = 2 + writer_threads                 # one computing, one copying out, one at each writer
     st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots)
     q = queue.Queue(maxsize=1)
     free = [threading.Semaphore(1) for _ in range(nslots)]
@@ -301,8 +304,9 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
             finally:
                 free[slot].release()
 
-    th = threading.Thread(target=writer, daemon=True)
-    th.start()
+    ths = [threading.Thread(target=writer, daemon=True) for _ in range(writer_threads)]
+    for th in ths:
+        th.start()
     t0 = time.perf_counter()
     dev_ms = 0.0
     pending = None
@@ -329,8 +333,10 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
         if pending is not None:
             collect(*pending)
     finally:
-        q.put(None)
-        th.join()
+        for _ in ths:
+            q.put(None)
+        for th in ths:
+            th.join()
         st.close()
         policy.close()
     if log is not None:

@@ -15,6 +15,7 @@ Readers pick the container from the file's magic bytes; every writer takes ``for
 """
 import datetime as _dt
 import os
+import threading
 import warnings
 
 import numpy as np
@@ -495,50 +496,53 @@ class TileSink(object):
     per variable, and one GPU produces a tile every ~0.12 s.  Here, per tile and variable:
 
     * PREPARE (needs no data; with ``order`` -- the tile numbers in the order they will arrive -- the files of the next ``ahead``
-      tiles are prepared by background threads while this tile's bytes are copied): the file is created with EVERY variable's chunks
-      allocated at creation, the daily variable's on page boundaries (``h5nc``: ``alloc_early`` + ``alignment``), coordinates
-      and attributes are written, the chunk addresses are read (``H5Dget_chunk_info``), the file is closed -- and its pages
-      are allocated with ONE ``posix_fallocate``: new file pages by first touch cost a page fault each and serialise on the
-      file's page-cache lock (tests/tools/host_page_rates.py on the GPU box: 1.3-4 GB/s per file however many threads),
-      ``fallocate`` allocates them in one in-kernel loop (13-18 GB/s per file).  (``populate=True`` also maps them ahead,
-      ``MAP_POPULATE``: the copy itself then runs at 43 GB/s instead of 12, but building and tearing down 1.5 M page-table
-      entries per file queues on the process's address-space lock -- 4.5 GB/s end to end against 9.5 without it, measured.)
-    * WRITE: ``threads`` workers copy the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
-      straight into the file's pages through one shared ``mmap`` -- each job one strided gather of a (days segment x chunk)
-      piece, numpy releases the GIL for it -- so the transposition into chunk order IS the write, and no HDF5 call touches
-      the 6.3 GB of a tile; the small variables (normals, SE, inconsist_tair) go through the library into their allocated chunks;
+      tiles are prepared by background threads while this tile is written): the file is created with EVERY variable's chunks
+      allocated at creation (``h5nc``: ``alloc_early``), coordinates and attributes are written, the chunk addresses are read
+      (``H5Dget_chunk_info``), the file is closed, and its pages are allocated with ONE ``posix_fallocate`` (17-19 GB/s per
+      file on the GPU box; new file pages by first touch: 1.3-4 GB/s per file however many threads);
+    * WRITE: ``threads`` workers gather the tile's ``[ndays, Y, X]`` block (the pinned host slot the GPU's outputs arrived in)
+      into a warm, reused STAGING buffer in the file's chunk order -- strided gathers of (days segment x chunk) pieces, numpy
+      releases the GIL: 50-65 GB/s with 32 threads --, and one thread per FILE ``pwrite``s every chunk to its address as soon
+      as it is complete (11 GB/s per file into allocated pages, and files add up: 21 GB/s for a tile's two, 30 for four).  No
+      HDF5 call touches the 6.3 GB of a tile, no page is faulted in or mapped; the small variables (normals, SE,
+      inconsist_tair) go through the library into their allocated chunks meanwhile.
+      (Round 6 went through five forms that copied through a shared ``mmap`` of the file instead: they end at ~10 GB/s, what
+      this host gives a process that maps freshly allocated tmpfs pages whatever the number of threads, files or tiles in
+      flight -- EXPERIMENTS.md.)
     * ``zlib=True`` (the reference's tiles are not compressed; its mosaics are): the workers gather, byte-shuffle and
       deflate each chunk (``zlib`` releases the GIL) and the sink's own thread appends the stored bytes with
       ``H5Dwrite_chunk`` -- for the library a byte copy.
 
+    Thread-safe: with ``driver.interp_tiles_streamed(writer_threads=2)`` two tiles (four files) are written at once.
     The files are complete NetCDF-4 files of the ``TileWriter`` layout (``read_tile`` / ``h5nc.Dataset`` / any HDF5 reader
     open them; tests/test_ncio.py, tests/test_h5py_interop.py).  ``stats``: tiles, int16 bytes handed over, bytes on disk,
-    seconds in preparation (on the caller's thread only: look-ahead preparation is off it) / in the bulk copy / total.
-    ``verify``: tile numbers to read back through the library and compare with what was handed over (``stats["verified"]``:
-    number of tiles checked, raises on a difference)."""
+    seconds waiting for prepared files / in the gather + write / total (summed over concurrent calls).  ``verify``: tile
+    numbers to read back through the library and compare with what was handed over (``stats["verified"]``: number of tiles
+    checked, raises on a difference)."""
 
     def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None,
-                 variables=("tmin", "tmax"), order=None, ahead=2, populate=False, prep_threads=2):
+                 variables=("tmin", "tmax"), order=None, ahead=2, prep_threads=2):
+        import queue
         from concurrent.futures import ThreadPoolExecutor
         if not h5nc.available():
             raise IOError("TileSink needs libhdf5 (NetCDF-4 tiles); TileWriter writes classic netCDF without it")
         self.info, self.path_out, self.days, self.variables = tile_grid_info, path_out, days, tuple(variables)
         self.writer = TileWriter(tile_grid_info, path_out, format="NETCDF4", zlib=zlib, complevel=complevel)
-        self.threads = int(threads or min(64, os.cpu_count() or 8))
+        self.threads = int(threads or min(32, os.cpu_count() or 8))
         self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
-        self.pool = ThreadPoolExecutor(self.threads)
+        self.pool = ThreadPoolExecutor(self.threads)             # gathers / deflates
+        self.write_pool = ThreadPoolExecutor(8)                  # one pwrite loop per file in flight
+        self._lock = threading.Lock()                           # several tiles may be written at once (driver: writer_threads)
+        self._staging = queue.LifoQueue()                       # warm buffers of one variable's chunk region, reused
         self.ahead = max(1, int(ahead))                         # tiles prepared ahead of the one being written (6.3 GB of pages each)
-        self.populate = bool(populate)
-        # few preparing threads: one fallocate runs at 13-18 GB/s by itself, and everything that changes the process's address
-        # space (mmap + populate, munmap) queues on ONE lock -- eight concurrent preparations were slower than two
         self.prep_pool = ThreadPoolExecutor(max(1, int(prep_threads)))
-        self.unmap_pool = ThreadPoolExecutor(1)                 # dropping a 3 GB mapping takes ~0.3 s: off the sink's thread
         self.order = list(order) if order is not None else None
         self._pos = {k: i for i, k in enumerate(self.order)} if self.order is not None else {}
         self._ahead = {}                                        # tile number -> {var: future of _prepare_var}
+        self._taken = set()                                     # tile numbers whose files have been handed to a writer
         cy, cx = tile_grid_info.chk_size_y, tile_grid_info.chk_size_x
         nchunks = len(self.variables) * (tile_grid_info.tile_size_y // cy) * (tile_grid_info.tile_size_x // cx)
-        # enough jobs per tile to keep every worker busy: chunks are cut along the day axis
+        # enough gather jobs per tile to keep every worker busy: chunks are cut along the day axis
         self.day_segments = int(day_segments or max(1, -(-2 * self.threads // max(nchunks, 1))))
         self.stats = {"tiles": 0, "int16_bytes": 0, "disk_bytes": 0, "prepare_s": 0.0, "copy_s": 0.0, "total_s": 0.0, "fallocate_s": 0.0,
                       "verified": 0, "threads": self.threads, "zlib": self.zlib, "complevel": self.complevel if zlib else None,
@@ -546,7 +550,6 @@ class TileSink(object):
 
     # ---- prepare: no data needed ----------------------------------------------------------------------------------------------
     def _prepare_var(self, k, var):
-        import mmap as _mmap
         import time as _t
         tile_id = self.info.get_tile_id(k)
         fpath = self.writer.fpath(tile_id, var)
@@ -558,34 +561,58 @@ class TileSink(object):
         fd = os.open(fpath, os.O_RDWR)
         try:
             os.posix_fallocate(fd, 0, os.fstat(fd).st_size)   # every page of the file, in one in-kernel loop (releases the GIL)
-            # ... and map them all at once (MAP_POPULATE): the copy then meets no page fault at all
-            size = os.fstat(fd).st_size
-            try:
-                mm = _mmap.mmap(fd, size, flags=_mmap.MAP_SHARED | (getattr(_mmap, "MAP_POPULATE", 0x8000) if self.populate else 0),
-                                prot=_mmap.PROT_READ | _mmap.PROT_WRITE)
-            except (OSError, ValueError):
-                mm = _mmap.mmap(fd, size)
-        finally:
-            os.close(fd)
-        dt = _t.perf_counter() - t0
-        return fpath, np.frombuffer(mm, np.uint8), info, dt
+        except OSError:
+            pass                                                # (a file system without fallocate: pwrite allocates as it goes)
+        return fpath, fd, info, _t.perf_counter() - t0
 
     def _prepared(self, k):
-        futs = self._ahead.pop(k, None)
-        if futs is None:
-            futs = {v: self.prep_pool.submit(self._prepare_var, k, v) for v in self.variables}
-        if k in self._pos:                                      # the next tiles' files, while this one is written: preparing a file
-            for i in range(self._pos[k] + 1, min(self._pos[k] + 1 + self.ahead, len(self.order))):   # (fallocate + populate)
-                nk = self.order[i]                              # takes longer than copying into it, and scales with the number of FILES
-                if nk not in self._ahead:
-                    self._ahead[nk] = {v: self.prep_pool.submit(self._prepare_var, nk, v) for v in self.variables}
+        with self._lock:
+            self._taken.add(k)
+            futs = self._ahead.pop(k, None)
+            if futs is None:
+                futs = {v: self.prep_pool.submit(self._prepare_var, k, v) for v in self.variables}
+            if k in self._pos:                                  # the next tiles' files, while this one is written
+                for i in range(self._pos[k] + 1, min(self._pos[k] + 1 + self.ahead, len(self.order))):
+                    nk = self.order[i]
+                    if nk not in self._ahead and nk not in self._taken:
+                        self._ahead[nk] = {v: self.prep_pool.submit(self._prepare_var, nk, v) for v in self.variables}
         return {v: f.result() for v, f in futs.items()}
 
+    def _add(self, **kw):
+        with self._lock:
+            for name, v in kw.items():
+                self.stats[name] += v
+
+    def _stage(self, nbytes):
+        import queue
+        try:
+            buf = self._staging.get_nowait()
+            if buf.size >= nbytes:
+                return buf
+        except queue.Empty:
+            pass
+        return np.empty(nbytes, np.uint8)
+
     @staticmethod
-    def _gather(mm, addr, src, d0, d1, r0, c0, cy, cx):
-        ny, nx = min(cy, src.shape[1] - r0), min(cx, src.shape[2] - c0)
-        dst = mm[addr + d0 * cy * cx * 2:addr + d1 * cy * cx * 2].view(np.int16).reshape(d1 - d0, cy, cx)
-        np.copyto(dst[:, :ny, :nx], src[d0:d1, r0:r0 + ny, c0:c0 + nx])
+    def _gather(dst, src, d0, d1, r0, c0):
+        ny, nx = min(dst.shape[1], src.shape[1] - r0), min(dst.shape[2], src.shape[2] - c0)
+        if (ny, nx) != dst.shape[1:]:
+            dst[d0:d1] = FILL_I2                                # an edge chunk is stored whole: fill value beyond the tile
+        np.copyto(dst[d0:d1, :ny, :nx], src[d0:d1, r0:r0 + ny, c0:c0 + nx])
+
+    @staticmethod
+    def _write_file(fd, chunks):
+        """``chunks``: (file address, staging view, gather futures) in file order -- each chunk goes out as soon as it is whole."""
+        try:
+            for addr, view, futs in chunks:
+                for f in futs:
+                    f.result()
+                mv = memoryview(view)
+                done = 0
+                while done < len(mv):                           # (pwrite may write less than asked: 2 GiB per call at most)
+                    done += os.pwrite(fd, mv[done:], addr + done)
+        finally:
+            os.close(fd)
 
     @staticmethod
     def _deflate(src, r0, c0, cy, cx, level):
@@ -610,7 +637,7 @@ class TileSink(object):
         tile_id = self.info.get_tile_id(k)
         cy, cx = self.info.chk_size_y, self.info.chk_size_x
         present = [v for v in self.variables if arrays.get("daily_" + v) is not None]
-        jobs, maps, open_ds = [], [], []
+        jobs, open_ds, writes, stages = [], [], [], []
         if self.zlib:
             for var in present:
                 src = arrays["daily_" + var]
@@ -620,46 +647,51 @@ class TileSink(object):
                     for c0 in range(0, src.shape[2], cx):
                         jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), ds.variables[var], (0, r0, c0)))
                 open_ds.append(ds)
+            self._add(prepare_s=_t.perf_counter() - t_begin)
+            t1 = _t.perf_counter()
+            for fut, var_obj, off in jobs:
+                var_obj.write_chunk_raw(off, fut.result())      # (raises what a worker raised)
+            for ds in open_ds:
+                ds.close()
         else:
             prepared = self._prepared(k)
+            self._add(prepare_s=_t.perf_counter() - t_begin)
+            t1 = _t.perf_counter()
             for var in present:
                 src = arrays["daily_" + var]
-                fpath, mm, info, dt_f = prepared[var]
-                self.stats["fallocate_s"] += dt_f
-                maps.append(mm)
+                fpath, fd, info, dt_f = prepared[var]
+                self._add(fallocate_s=dt_f)
                 nd = src.shape[0]
+                size = nd * cy * cx * 2
+                stg = self._stage(size * len(info))
+                stages.append(stg)
                 seg = -(-nd // self.day_segments)
-                for (_, r0, c0), (addr, size, _) in info.items():
-                    if size != nd * cy * cx * 2:
-                        raise IOError("%s: unexpected chunk size %d" % (fpath, size))
-                    for d0 in range(0, nd, seg):
-                        jobs.append((self.pool.submit(self._gather, mm, addr, src, d0, min(nd, d0 + seg), r0, c0, cy, cx), None, None))
-        self.stats["prepare_s"] += _t.perf_counter() - t_begin
-        t1 = _t.perf_counter()
-        if not self.zlib:                                       # the small variables, through the library, while the workers copy
-            for var in present:
+                chunks = []
+                for ci, ((_, r0, c0), (addr, csize, _)) in enumerate(info.items()):
+                    if csize != size:
+                        raise IOError("%s: unexpected chunk size %d" % (fpath, csize))
+                    view = stg[ci * size:(ci + 1) * size]
+                    dst = view.view(np.int16).reshape(nd, cy, cx)
+                    chunks.append((addr, view, [self.pool.submit(self._gather, dst, src, d0, min(nd, d0 + seg), r0, c0)
+                                                for d0 in range(0, nd, seg)]))
+                writes.append(self.write_pool.submit(self._write_file, fd, chunks))
+            for var in self.variables:                          # (a variable that was prepared but did not come: close its file)
+                if var not in present:
+                    os.close(prepared[var][1])
+            for var in present:                                 # the small variables, through the library, meanwhile
                 ds = open_dataset(self.writer.fpath(tile_id, var), "a")
                 try:
                     self._small(ds, var, arrays)
                 finally:
                     ds.close()
-        for fut, var_obj, off in jobs:
-            res = fut.result()                                  # (raises what a worker raised)
-            if var_obj is not None:
-                var_obj.write_chunk_raw(off, res)
-        for ds in open_ds:
-            ds.close()
-        if not self.zlib:                                       # the mappings die on the unmapping thread, not here
-            holder = [maps, prepared]
-            maps = prepared = mm = None
-            self.unmap_pool.submit(holder.clear)
-            del holder
-        self.stats["copy_s"] += _t.perf_counter() - t1
+            for w in writes:
+                w.result()                                      # (raises what a worker raised)
+            for stg in stages:
+                self._staging.put(stg)
+        self._add(copy_s=_t.perf_counter() - t1)
         for var in present:
-            self.stats["int16_bytes"] += int(arrays["daily_" + var].nbytes)
-            self.stats["disk_bytes"] += os.path.getsize(self.writer.fpath(tile_id, var))
-        self.stats["tiles"] += 1
-        self.stats["total_s"] += _t.perf_counter() - t_begin
+            self._add(int16_bytes=int(arrays["daily_" + var].nbytes), disk_bytes=os.path.getsize(self.writer.fpath(tile_id, var)))
+        self._add(tiles=1, total_s=_t.perf_counter() - t_begin)
         if k in self.verify:
             for var in present:
                 ds = open_dataset(self.writer.fpath(tile_id, var), "r")
@@ -673,20 +705,21 @@ class TileSink(object):
                             raise IOError("%s: %s read-back differs" % (ds.path, name))
                 finally:
                     ds.close()
-            self.stats["verified"] += 1
+            self._add(verified=1)
 
     def close(self):
         for futs in self._ahead.values():                       # files prepared for tiles that never came hold no data: remove them
             for f in futs.values():
                 try:
-                    fpath = f.result()[0]
+                    fpath, fd = f.result()[:2]
+                    os.close(fd)
                     os.remove(fpath)
                     os.rmdir(os.path.dirname(fpath))            # (the tile's directory, when this was its last file)
                 except Exception:                               # noqa: BLE001 -- a failed preparation, a directory still in use
                     pass
         self._ahead.clear()
-        self.unmap_pool.shutdown(wait=True)
         self.prep_pool.shutdown(wait=True)
+        self.write_pool.shutdown(wait=True)
         self.pool.shutdown(wait=True)
 
 
