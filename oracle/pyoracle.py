@@ -126,6 +126,21 @@ def ellip_dist(lon1, lat1, lon2, lat2):
     return f(lon1, lat1, lon2, lat2)
 
 
+class exclusions(object):
+    """``with exclusions(indices): ...`` -- ``stns_rm`` as an array of ids (station_select.py:74-103): every oracle call of this
+    thread inside the block also drops these station indices (entries < 0 are ignored)."""
+
+    def __init__(self, idx):
+        self.idx = np.ascontiguousarray([i for i in np.asarray(idx).ravel() if i >= 0], np.int32)
+
+    def __enter__(self):
+        lib().orc_set_exclusions(C.c_int(self.idx.size), _ptr(self.idx, _ip))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_exclusions(C.c_int(0), None)
+
+
 def nearest(db, lat, lon, ksel, excl=-1, rm_zero_dist=False):
     idx = np.zeros(ksel, np.int32)
     dist = np.zeros(ksel, np.float64)

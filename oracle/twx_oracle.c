@@ -97,6 +97,17 @@ static int di_cmp(const void *a, const void *b)
  * sort.  Only the first ksel entries are ever read (station_select.py:164-166),
  * so a bounded max-heap replaces the full argsort; ties (undefined under the
  * reference's unstable argsort, :111) break on the smaller station index. */
+/* stns_rm as an ARRAY of ids (station_select.py:74-103: np.in1d over any number of ids): further station indices that
+ * orc_nearest drops, besides its own excl argument, for the calls of THIS thread that follow (n = 0 clears).  Thread-local:
+ * the threaded grid entry never sets it. */
+static __thread int32_t orc_more_excl[16];
+static __thread int orc_n_more_excl = 0;
+void orc_set_exclusions(int n, const int32_t *idx)
+{
+    orc_n_more_excl = n < 0 ? 0 : (n > 16 ? 16 : n);
+    for (int i = 0; i < orc_n_more_excl; ++i) orc_more_excl[i] = idx[i];
+}
+
 int64_t orc_nearest(const orc_db *db, double lat, double lon, int32_t excl,
                     int rm_zero_dist, int64_t ksel, int32_t *idx, double *dist)
 {
@@ -106,6 +117,11 @@ int64_t orc_nearest(const orc_db *db, double lat, double lon, int32_t excl,
     int64_t nh = 0;
     for (int64_t j = 0; j < db->n; ++j) {
         if (j == excl) continue;
+        {
+            int dropped = 0;
+            for (int q = 0; q < orc_n_more_excl; ++q) dropped |= orc_more_excl[q] == j;
+            if (dropped) continue;
+        }
         double d = orc_grt_circle_dist(lon, lat, db->lon[j], db->lat[j]);
         if (rm_zero_dist && d == 0.0) continue;
         di_t e = { d, (int32_t)j };

@@ -70,6 +70,8 @@ double orc_ellip_dist(double lon1, double lat1, double lon2, double lat2);
 
 /* a2: station_select.py:72-119.  The ksel nearest remaining stations in
  * (distance, index) order.  Returns the number written (< ksel if fewer). */
+/* stns_rm as an array of ids (station_select.py:74-103): up to 16 further indices dropped by orc_nearest for this thread's next calls */
+void orc_set_exclusions(int n, const int32_t *idx);
 int64_t orc_nearest(const orc_db *db, double lat, double lon, int32_t excl,
                     int rm_zero_dist, int64_t ksel, int32_t *idx, double *dist);
 

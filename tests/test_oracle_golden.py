@@ -207,3 +207,32 @@ def test_xval_anom_oracle_vs_executed_run_xval(orc, golden_xval, golden_case):
             assert abs(difs.mean() - g["xa_bias"][1][x, m - 1]) < 1e-6
             assert abs(np.abs(difs).mean() - g["xa_mae"][1][x, m - 1]) < 1e-6
             assert abs(np.corrcoef(out - nrm, xval_anom)[0, 1] ** 2 - g["xa_r2"][1][x, m - 1]) < 1e-9
+
+
+def test_oracle_stns_rm_arrays_match_the_executed_reference(orc, golden_case):
+    """``stns_rm`` as an array of ids (station_select.py:74-103): the oracle with an exclusion LIST against
+    tests/golden/golden_rm_v1.npz (made by executing the reference's StationSelect / KrigTair / GwrTairAnom with id arrays)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_rm_v1.npz"))
+    grid, tmin, _ = golden_case
+    db, prm = orc.Db(tmin), orc.params()
+    for q in range(g["k"].size):
+        k = int(g["k"][q])
+        with orc.exclusions(g["excl"][q]):
+            rc, idx, dist, wgt = orc.select(db, g["lat"][q], g["lon"][q], k, rm_zero_dist=bool(g["rmz"][q]))
+        assert rc == 0 and np.array_equal(idx, g["idx"][q][:k])                               # bit-exact
+        np.testing.assert_allclose(dist, g["dist"][q][:k], rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(wgt, g["wgt"][q][:k], rtol=1e-10, atol=1e-12)
+    for i, (r, c) in enumerate(g["kr_cell"]):
+        pt = orc.make_pt(grid["lon"][c], grid["lat"][r], grid["elev"][r, c], grid["tdi"][r, c], grid["lst_night"][:, r, c])
+        mth = int(g["kr_mth"][i])
+        with orc.exclusions(g["kr_excl"][i]):
+            rc, mean, var, used, _ = orc.krig(db, prm, pt, mth)
+            rc2, series, ka, _, _ = orc.gwr_mth(db, prm, pt, float(g["kr_mean"][i]), mth)
+        assert rc == 0 and rc2 == 0
+        assert abs(mean - g["kr_mean"][i]) < 1e-6 and abs(var - g["kr_var"][i]) < 1e-6
+        n = int(g["gw_len"][i])
+        assert np.abs(series[:n] - g["gw_series"][i, :n]).max() < 1e-8
+    # and the setting does not outlive its block
+    rc, idx, _, _ = orc.select(db, g["lat"][0], g["lon"][0], 35)
+    assert np.intersect1d(idx, g["excl"][0][g["excl"][0] >= 0]).size > 0
