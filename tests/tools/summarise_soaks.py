@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_soak_*.json"))):
     d = json.load(open(p))
     recs = d.get("records")
-    if not isinstance(recs, list):
+    if not isinstance(recs, list) or "records_kept" in d:
         continue                                              # already a summary
     out = {k: v for k, v in d.items() if k != "records"}
     seeds = [r["seed"] for r in recs if "seed" in r]
