@@ -68,6 +68,53 @@ def test_tile_writer_roundtrip(tmp_path, fmt):
     ds.close()
 
 
+@pytest.mark.skipif(not h5nc.available(), reason="libhdf5 not loadable")
+@pytest.mark.parametrize("zl", [False, True])
+def test_tile_sink_whole_tiles(tmp_path, zl):
+    """``ncio.TileSink``: whole tiles into the TileWriter layout (chunks gathered and pwritten to their addresses / deflated by
+    the workers), two calls in flight, files prepared ahead for a tile that never comes removed, a normals-only tile."""
+    from concurrent.futures import ThreadPoolExecutor
+    info = _info()
+    days = get_days_metadata(dt.date(1999, 12, 30), dt.date(2000, 1, 8))
+    rng = np.random.default_rng(3)
+
+    def tile(seed):
+        r = np.random.default_rng(seed)
+        d = r.integers(-3000, 3000, (days.size, 8, 6)).astype(np.int16)
+        return {"daily_tmin": d, "daily_tmax": (d + 800).astype(np.int16), "norm_tmin": r.normal(0, 5, (12, 8, 6)).astype("f4"),
+                "norm_tmax": r.normal(9, 5, (12, 8, 6)).astype("f4"), "se_tmin": r.random((12, 8, 6)).astype("f4"),
+                "se_tmax": r.random((12, 8, 6)).astype("f4"), "ninvalid": r.integers(0, 7, (8, 6)).astype("i4")}
+    a0, a1 = tile(0), tile(1)
+    sink = ncio.TileSink(info, str(tmp_path), days, threads=3, zlib=zl, order=[0, 1], ahead=1, verify=(0, 1))
+    with ThreadPoolExecutor(2) as ex:                             # (driver.interp_tiles_streamed(writer_threads=2) does this)
+        list(ex.map(lambda ka: sink(*ka), ((0, a0), (1, a1))))
+    sink.close()
+    assert sink.stats["tiles"] == 2 and sink.stats["verified"] == 2 and sink.stats["int16_bytes"] == 4 * a0["daily_tmin"].nbytes
+    for tid, a in (("h00v00", a0), ("h01v00", a1)):
+        for var in ("tmin", "tmax"):
+            t = ncio.read_tile(sink.writer.fpath(tid, var), var)
+            for got, key in (("daily", "daily_" + var), ("norm", "norm_" + var), ("se", "se_" + var), ("ninvalid", "ninvalid")):
+                np.testing.assert_array_equal(t[got], a[key])
+            ds = h5nc.Dataset(sink.writer.fpath(tid, var))
+            assert ds.variables[var].chunking() == [days.size, 4, 3] and ds.variables[var].filters()["zlib"] == zl
+            ds.close()
+    # look-ahead: tile 1's files are prepared while tile 0 is written; tile 1 never comes -> close() leaves no empty files behind
+    out2 = tmp_path / "ahead"
+    sink = ncio.TileSink(info, str(out2), days, threads=2, zlib=zl, order=[0, 1], ahead=1)
+    sink(0, a0)
+    sink.close()
+    assert sorted(os.listdir(out2)) == ["h00v00"]
+    # a normals-only run hands no daily block over: the small variables are written, the daily variable keeps its fill value
+    out3 = tmp_path / "normals_only"
+    sink = ncio.TileSink(info, str(out3), days, threads=2, zlib=zl)
+    sink(1, {k: (None if k.startswith("daily_") else v) for k, v in a1.items()})
+    sink.close()
+    t = ncio.read_tile(sink.writer.fpath("h01v00", "tmax"), "tmax")
+    np.testing.assert_array_equal(t["norm"], a1["norm_tmax"])
+    np.testing.assert_array_equal(t["ninvalid"], a1["ninvalid"])
+    assert (t["daily"] == ncio.FILL_I2).all() and sink.stats["int16_bytes"] == 0
+
+
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_tiles_to_daily_mosaic(tmp_path, fmt):
     info = _info()

@@ -407,14 +407,14 @@ class TileWriter(object):
         long_name, vunits, std_name, cell_method = VAR_ATTRS[varname]
         cy, cx = min(self.chk_size_y, lats.size), min(self.chk_size_x, lons.size)
         kw = dict(zlib=self.zlib, complevel=self.complevel)
+        if early and _is_nc4(ds) and not self.zlib:
+            kw["alloc_early"] = True                          # (TileSink: the file has its final size once it is created)
         mv = ds.createVariable(varname, "i2", ("time", "lat", "lon"), chunksizes=(int(days.size), cy, cx),
-                               fill_value=FILL_I2, **(dict(kw, alloc_early=True) if early and _is_nc4(ds) and not self.zlib else kw))
+                               fill_value=FILL_I2, **kw)
         mv.long_name, mv.units, mv.standard_name = long_name, vunits, std_name
         mv.scale_factor = SCALE_FACTOR
         mv.cell_methods = "area: mean time: " + cell_method
         _gridded(mv)
-        if early and _is_nc4(ds) and not self.zlib:
-            kw = dict(kw, alloc_early=True)                   # (TileSink: the file has its final size once it is created)
         nv = ds.createVariable(varname + "_normal", "f4", ("time_normals", "lat", "lon"), chunksizes=(12, cy, cx),
                                fill_value=FILL_F4, **kw)
         nv.long_name, nv.units, nv.standard_name = "normal " + long_name, vunits, std_name
@@ -636,17 +636,20 @@ class TileSink(object):
         t_begin = _t.perf_counter()
         tile_id = self.info.get_tile_id(k)
         cy, cx = self.info.chk_size_y, self.info.chk_size_x
-        present = [v for v in self.variables if arrays.get("daily_" + v) is not None]
+        have = [v for v in self.variables if arrays.get("norm_" + v) is not None]
+        present = [v for v in have if arrays.get("daily_" + v) is not None]      # (a normals-only run: the small variables alone)
         jobs, open_ds, writes, stages = [], [], [], []
         if self.zlib:
-            for var in present:
-                src = arrays["daily_" + var]
+            for var in have:
                 ds = self.writer._create(self.writer.fpath(tile_id, var), tile_id, var, self.days, early=True)
                 self._small(ds, var, arrays)
+                open_ds.append(ds)
+                if var not in present:
+                    continue
+                src = arrays["daily_" + var]
                 for r0 in range(0, src.shape[1], cy):
                     for c0 in range(0, src.shape[2], cx):
                         jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), ds.variables[var], (0, r0, c0)))
-                open_ds.append(ds)
             self._add(prepare_s=_t.perf_counter() - t_begin)
             t1 = _t.perf_counter()
             for fut, var_obj, off in jobs:
@@ -675,10 +678,13 @@ class TileSink(object):
                     chunks.append((addr, view, [self.pool.submit(self._gather, dst, src, d0, min(nd, d0 + seg), r0, c0)
                                                 for d0 in range(0, nd, seg)]))
                 writes.append(self.write_pool.submit(self._write_file, fd, chunks))
-            for var in self.variables:                          # (a variable that was prepared but did not come: close its file)
-                if var not in present:
-                    os.close(prepared[var][1])
-            for var in present:                                 # the small variables, through the library, meanwhile
+            for var in self.variables:
+                if var not in present:                          # no daily block came (a normals-only run): the prepared file's chunks
+                    os.close(prepared[var][1])                  # hold zeros, not the fill value -- a plain file takes its place
+                    os.remove(prepared[var][0])
+                    if var in have:
+                        self.writer._create(prepared[var][0], tile_id, var, self.days).close()
+            for var in have:                                    # the small variables, through the library, meanwhile
                 ds = open_dataset(self.writer.fpath(tile_id, var), "a")
                 try:
                     self._small(ds, var, arrays)
