@@ -208,6 +208,33 @@ def test_driver_streamed_tiles_equal_synchronous(golden_case, tmp_path):
             assert np.array_equal(got[name], want[k][name]), (k, name)
 
 
+def test_a_failing_sink_stops_the_run_and_is_reported(golden_case):
+    """The sink's exception reaches the caller, no further tile is interpolated once it is seen, and the context -- handed back
+    in the fast mode, its stream closed -- still computes what it computed before."""
+    from topowx_amd import _lib, driver
+    grid, tmin, tmax = golden_case
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin, with_obs=False)
+    ctx.set_stations(_lib.TMAX, tmax, with_obs=False)
+    tiles = driver.tile_list(grid["mask"], 20, 20)
+    want = driver.interp_tiles(grid, driver.gpu_compute(ctx), tiles[:1], 20, 20)
+    seen = []
+
+    def sink(k, arrays):
+        seen.append(k)
+        if len(seen) == 2:
+            raise IOError("disk full")
+    for writers in (1, 2):
+        del seen[:]
+        with pytest.raises(IOError, match="disk full"):
+            driver.interp_tiles_streamed(ctx, grid, tiles, 20, 20, sink=sink, precision="exact", writer_threads=writers)
+        assert 2 <= len(seen) < len(tiles) and sorted(seen) == [t[0] for t in tiles[:len(seen)]]
+    again = driver.interp_tiles(grid, driver.gpu_compute(ctx), tiles[:1], 20, 20)
+    ctx.close()
+    for name in want[tiles[0][0]]:
+        assert np.array_equal(again[tiles[0][0]][name], want[tiles[0][0]][name]), name
+
+
 def test_stream_outlives_context_close(golden_case):
     """twx_destroy closes a context's open streams (they hold device images and pinned blocks of that context); the
     Python TileStream then only forgets its handle -- in either order of close() / garbage collection nothing is freed

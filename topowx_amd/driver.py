@@ -325,6 +325,8 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
         for n, (k, i, j, _) in enumerate(tiles):
             slot = n % nslots
             free[slot].acquire()                # the writer is done with this slot's previous tile
+            if err:                             # the sink failed: no point in interpolating the rest
+                break
             submitted_as = policy.mode
             st.submit(slot, grid, slice(i, i + tile_y), slice(j, j + tile_x))
             if pending is not None:
