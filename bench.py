@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--c4-years", type=int, default=69, help="c4 record: years of days from 1948 (69 = 1948-2016, 25 203 days)")
     ap.add_argument("--c4-precision", default="auto", choices=("auto", "fast", "exact"),
                     help="c4 record: covariance build of the streamed run (driver.PrecisionPolicy; auto = exact while it is free)")
+    ap.add_argument("--no-c4-deflate", action="store_true", help="c4 record: skip the second pass with the daily values deflated on the GPU")
     ap.add_argument("--c4-sink-tiles", type=int, default=16, help="c4 record: tiles written into NetCDF-4 tile files by ncio.TileSink (0 = skip)")
     ap.add_argument("--c4-sink-dir", default=None, help="where (default: /dev/shm when it has 20 GB free, else $TMPDIR)")
     ap.add_argument("--c4-sink-threads", type=int, default=0, help="TileSink workers (0 = min(32, cpu count))")
@@ -713,9 +714,66 @@ def c4_full_record(env, args):
         rec["spot_check_vs_oracle"] = {"cells": len(kept), "tiles": len(picks), "tile_valid_cells": [mine[q][3] for q in pick_tiles],
                                        "normals_max_abs_degC": worst_n, "int16_max_abs_lsb": worst_lsb,
                                        "int16_values": nvals, "int16_differing": flips, "ninvalid_equal": ninv_eq, "status_equal": stat_eq}
+    if not args.no_c4_deflate:
+        rec["deflated_on_gpu"] = c4_deflated_record(ctx, grid, mine, T, nd, args, kept, wall, acc["bytes"])
     if args.c4_sink_tiles > 0:
         rec["sink"] = c4_sink_record(ctx, grid, mine[:args.c4_sink_tiles], T, days, args)
     ctx.close()
+    return rec
+
+
+def c4_deflated_record(ctx, grid, mine, T, nd, args, kept, wall_int16, bytes_int16):
+    """configs[3] once more, the daily values leaving the GPU as the chunk bytes of an HDF5 dataset with shuffle + deflate (the
+    storage form of the reference's products, tiling.py:720,894,913,1035) formed on the device (csrc/twx_deflate.h,
+    twx_stream_deflate): what crosses PCIe and what a writer has to store is ~2/3 of the int16 arrays, and no core deflates.
+    Same tiles, same order, same discarding sink as the run above.  Check: the streams of the chunks holding the cells the
+    run above kept for its oracle check are inflated by zlib (outside the timing) and give the same int16 series."""
+    import zlib
+    from topowx_amd import driver
+    cy = cx = 50
+    ncx = T // cx
+    origin = {k: (i, j) for k, i, j, _ in mine}
+    want_chunks = {}
+    for (k, r, c) in kept:
+        want_chunks.setdefault(k, set()).add((r // cy) * ncx + c // cx)
+    blobs, acc = {}, {"bytes": 0, "stream_bytes": 0, "tiles": 0}
+
+    def sink(k, arrays):
+        acc["tiles"] += 1
+        for v in ("tmin", "tmax"):
+            n = sum(len(b) for b in arrays["deflated_" + v])
+            acc["stream_bytes"] += n
+            acc["bytes"] += n
+            for ch in want_chunks.get(k, ()):
+                blobs[(k, v, ch)] = bytes(arrays["deflated_" + v][ch])
+        acc["bytes"] += sum(a.nbytes for a in arrays.values() if hasattr(a, "nbytes"))
+
+    kw = dict(daily=True, deflate_chunks=(cy, cx))
+    driver.interp_tiles_streamed(ctx, grid, mine[:1], T, T, sink=lambda k, a: None, **kw)       # warm-up: chunk slots, pinned stream blocks
+    plog = {}
+    t0 = time.perf_counter()
+    _, secs, dev_ms = driver.interp_tiles_streamed(ctx, grid, mine, T, T, sink=sink, precision=args.c4_precision, log=plog, **kw)
+    wall = time.perf_counter() - t0
+    deflate_ms = ctx.timing()["deflate_ms"]
+    int16_bytes = acc["tiles"] * 2 * nd * T * T * 2
+    rec = {"wall_s": wall, "wall_s_int16_run": wall_int16, "speedup_end_to_end": wall_int16 / wall, "tiles": acc["tiles"],
+           "chunks": "(%d, %d, %d) int16 -> one zlib stream each: low bytes stored, high bytes run-length coded in fixed-Huffman blocks" % (nd, cy, cx),
+           "d2h_bytes": acc["bytes"], "d2h_bytes_int16_run": bytes_int16, "d2h_GBps": acc["bytes"] / wall / 1e9,
+           "stream_bytes_over_int16": acc["stream_bytes"] / int16_bytes, "int16_equivalent_GBps": int16_bytes / wall / 1e9,
+           "device_ms_total": dev_ms, "deflate_kernels_ms_last_tile": deflate_ms,
+           "precision": {k: v for k, v in plog.items() if k != "tile_modes"}}
+    # zlib -- the decoder inside libhdf5 -- on the kept cells' chunks
+    same, n = True, 0
+    for (k, r, c), got in kept.items():
+        ch = (r // cy) * ncx + c // cx
+        for v in ("tmin", "tmax"):
+            raw = np.frombuffer(zlib.decompress(blobs[(k, v, ch)]), np.uint8)
+            m = raw.size // 2
+            e = np.arange(nd) * (cy * cx) + (r % cy) * cx + c % cx
+            series = (raw[e].astype(np.uint16) | (raw[m + e].astype(np.uint16) << 8)).view(np.int16)
+            same = same and bool(np.array_equal(series, got["daily_" + v]))
+            n += nd
+    rec["inflated_by_zlib"] = {"cells": len(kept), "int16_values": n, "equal_to_the_int16_run": same}
     return rec
 
 
@@ -765,9 +823,11 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
         _, wall0, _ = driver.interp_tiles_streamed(ctx, grid, tiles, T, T, daily=True, sink=lambda k, a: None, precision=args.c4_precision)
         rec["wall_discarding_sink_s"] = wall0
         per_tile = 2 * days.size * T * T * 2 * 1.01
-        for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2])):
+        for name, kw, sub in (("netcdf4", dict(zlib=False), tiles), ("netcdf4_deflate1", dict(zlib=True, complevel=1), tiles[:2]),
+                              ("netcdf4_deflated_on_gpu", dict(zlib=True), tiles)):
             keep_all = shutil.disk_usage(base).free > 2.5 * per_tile * len(sub) + 40e9      # room for every tile of the run: delete afterwards
-            writers = 1 if kw["zlib"] else 2                     # (two tiles = four files written at once: pwrite rates add up per file)
+            writers = 1 if name == "netcdf4_deflate1" else 2     # (two tiles = four files written at once: pwrite rates add up per file)
+            dkw = dict(deflate_chunks=(50, 50)) if name == "netcdf4_deflated_on_gpu" else {}     # chunk bytes formed by the GPU: the sink only appends them
             sink = ncio.TileSink(info, out_dir, days, threads=threads, order=[t[0] for t in sub], ahead=3, prep_threads=4, **kw)
             dropper = ThreadPoolExecutor(1)
 
@@ -776,14 +836,14 @@ def c4_sink_record(ctx, grid, tiles, T, days, args):
                 if not keep_all:                                 # (off the sink's thread: freeing 6 GB of pages takes about a second)
                     dropper.submit(shutil.rmtree, os.path.join(out_dir, info.get_tile_id(k)), True)
             _, wall, _ = driver.interp_tiles_streamed(ctx, grid, sub, T, T, daily=True, sink=write, precision=args.c4_precision,
-                                                      writer_threads=writers)
+                                                      writer_threads=writers, **dkw)
             sink.close()
             dropper.shutdown(wait=True)
             st = dict(sink.stats)
             shutil.rmtree(out_dir, ignore_errors=True)
             # one more tile, outside the timing: written, read back through libhdf5, compared with the pinned block it came from
             chk = ncio.TileSink(info, out_dir, days, threads=threads, verify=(sub[0][0],), **kw)
-            driver.interp_tiles_streamed(ctx, grid, sub[:1], T, T, daily=True, sink=chk, precision=args.c4_precision)
+            driver.interp_tiles_streamed(ctx, grid, sub[:1], T, T, daily=True, sink=chk, precision=args.c4_precision, **dkw)
             chk.close()
             shutil.rmtree(out_dir, ignore_errors=True)
             rec[name] = {"tiles": st["tiles"], "wall_s": wall, "int16_GB": st["int16_bytes"] / 1e9, "on_disk_GB": st["disk_bytes"] / 1e9,

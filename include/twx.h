@@ -196,7 +196,7 @@ typedef struct {
     int64_t tie_cells;    /* tie guard (TWX_FLAG_NO_TIE_GUARD): cells with a day of |Tmax - Tmin| < 2e-5 degC, kriged a second time */
     int64_t tie_solves;   /* ... and their kriging systems (both variables; not counted in uk_solves) */
     float tie_ms;         /* ... and the device time of that second pass (kriging + epilogues; their fixer time is in fix_ms) */
-    float reserved;
+    float deflate_ms;     /* twx_stream_deflate: device time of the deflate kernels of the last tile (0 otherwise) */
 } twx_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -336,6 +336,26 @@ int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device
  * stream's compute / copy streams; ms).  What precision="auto" of topowx_amd/driver.py compares. */
 int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms);
 void twx_stream_destroy(twx_stream *st);
+
+/* ---- deflated daily outputs of a streamed tile.  The reference stores its products through netCDF4-python with zlib=True
+ * (tiling.py:720,894,913,1035), i.e. as HDF5 chunks filtered by shuffle + deflate; on the host that is one core per ~60 MB/s.
+ * twx_stream_deflate (once, before the first submit of a stream created with daily != 0; Y % chunk_y == 0, X % chunk_x == 0) makes
+ * the stream form those chunk bytes ON THE DEVICE (csrc/twx_deflate.h): per variable and chunk of chunk_y x chunk_x cells x all
+ * days one zlib stream (RFC 1950) of the shuffled chunk -- low bytes in stored blocks, high bytes run-length coded in
+ * fixed-Huffman blocks -- that any inflate reads and H5Dwrite_chunk appends to a dataset created with shuffle + deflate as it is.
+ * The daily arrays then stay on the device (views.daily_* are NULL) and the tile leaves it at ~0.5-0.65 of its size.
+ * twx_stream_wait_deflated replaces twx_stream_wait for such a stream: the copy-out of a tile is enqueued by THIS call (the sizes
+ * of its streams are known only when its kernels are done), so call it for tile t after submitting tile t + 1, as a pipelined
+ * caller does anyway; a tile still not waited for when its slot or its device image is needed again is copied out by
+ * twx_stream_submit itself.  Chunks are in row-major order of the tile's chunk grid. */
+typedef struct twx_deflated {
+    const uint8_t *data[2];   /* [TWX_TMIN], [TWX_TMAX]: the variable's chunk streams one after the other (pinned; valid until the
+                                 slot is submitted again); NULL for a variable the stream does not have */
+    const int64_t *offset[2]; /* [nchunks + 1] byte offsets of the chunks in data[v] */
+    int32_t nchunks, chunk_y, chunk_x, reserved;
+} twx_deflated;
+int twx_stream_deflate(twx_stream *st, int chunk_y, int chunk_x);
+int twx_stream_wait_deflated(twx_stream *st, int slot, twx_grid_out *views, twx_deflated *streams, float *device_ms);
 
 /* free / total device memory of the context's GPU in bytes (hipMemGetInfo): what a caller sizes its batches by
  * (topowx_amd/xval.py: step21 pushes ~22 MB of workspace per cross-validated station through one call) */

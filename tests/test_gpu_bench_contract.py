@@ -125,6 +125,12 @@ def test_bench_c2_fitted_and_c4_reduced():
     assert k["netcdf4"]["tiles"] >= 4 and k["netcdf4"]["tiles_read_back_equal"] == 1 and k["netcdf4"]["int16_GBps_end_to_end"] > 0
     assert k["netcdf4_deflate1"]["tiles_read_back_equal"] == 1 and k["netcdf4_deflate1"]["on_disk_GB"] < k["netcdf4_deflate1"]["int16_GB"]
     assert k["host_new_page_rate"]["cold_GBps"] > 0 and "posix_fallocate" in k["limiting_stage"]
+    g = k["netcdf4_deflated_on_gpu"]                    # chunk bytes formed on the device (twx_stream_deflate), appended by the sink
+    assert g["tiles_read_back_equal"] == 1 and g["on_disk_GB"] < g["int16_GB"] and g["tiles"] == k["netcdf4"]["tiles"]
+    z = c["deflated_on_gpu"]                            # the whole run once more, the daily values leaving the GPU deflated
+    assert z["tiles"] == c["tiles"] and z["wall_s"] > 0 and 0 < z["stream_bytes_over_int16"] < 1.001 and z["d2h_bytes"] < c["d2h_bytes"]
+    assert z["inflated_by_zlib"]["equal_to_the_int16_run"] and z["inflated_by_zlib"]["int16_values"] == z["inflated_by_zlib"]["cells"] * 731 * 2
+    assert z["deflate_kernels_ms_last_tile"] > 0
     s = c["spot_check_vs_oracle"]
     assert s["cells"] >= 12 and s["tiles"] >= 3 and s["status_equal"] and s["ninvalid_equal"]
     assert s["normals_max_abs_degC"] < 1e-4 and s["int16_max_abs_lsb"] <= 1

@@ -40,6 +40,7 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(built.TwxGrid) == 8 + 8 * 8
     assert ctypes.sizeof(built.TwxGridOut) == 8 * 8
     assert ctypes.sizeof(built.TwxTiming) == 4 * 7 + 4 + 8 * 6 + 4 * 2
+    assert ctypes.sizeof(built.TwxDeflated) == 8 * 2 + 8 * 2 + 4 * 4 and [f[0] for f in built.TwxTiming._fields_][-1] == "deflate_ms"
 
 
 def test_no_gpu_fails_loudly(built):
@@ -56,7 +57,7 @@ def test_product_package_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "pyoracle" not in src and "twx_oracle" not in src and "libtwxoracle" not in src, f
+                assert "pyoracle" not in src and "twx_oracle" not in src and "libtwxoracle" not in src and "import deflate_oracle" not in src, f
 
 
 def test_days_metadata():

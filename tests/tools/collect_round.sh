@@ -25,3 +25,11 @@ cp gpurun_out/closepair_scan.json gpurun_out/closepair_scan_fast.json gpurun_out
 python3 tests/tools/cycle_floor.py gpurun_out/sq_krig gpurun_out/prof_round/kernel_stats.csv > gpurun_out/prof_round/cycle_floor.md 2> gpurun_out/prof_round/cycle_floor.err
 python3 tests/tools/host_page_rates.py /dev/shm 8 > gpurun_out/prof_round/host_page_rates.log 2>&1
 cp gpurun_out/host_page_rates.json gpurun_out/prof_round/
+# round 6: the deflate kernels (csrc/twx_deflate.h) on one configs[3]-sized tile: kernel summary, HBM bytes per launch
+D=gpurun_out/prof_round/dfl
+mkdir -p $D
+rocprofv3 --kernel-trace --stats -d $D/stats -o s --output-format csv -- python3 tests/tools/gpu_deflate_ab.py --child > $D/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $D/fetch -o f --output-format csv -- python3 tests/tools/gpu_deflate_ab.py --child > $D/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $D/write -o w --output-format csv -- python3 tests/tools/gpu_deflate_ab.py --child > $D/write.log 2>&1
+python3 tests/tools/reduce_deflate.py $D > $D/reduce.log 2>&1
+cp $D/deflate_kernels.json gpurun_out/prof_round/

@@ -27,3 +27,4 @@ cp gpurun_out/prof_c4/pmc_daily_FETCH_SIZE.csv profiles/${R}_c4_daily_pmc_FETCH_
 cp gpurun_out/prof_c4/pmc_daily_WRITE_SIZE.csv profiles/${R}_c4_daily_pmc_WRITE_SIZE.csv
 [ -f $P/cycle_floor.md ] && cp $P/cycle_floor.md profiles/${R}_cycle_floor.md
 [ -f $P/host_page_rates.json ] && cp $P/host_page_rates.json profiles/${R}_host_page_rates.json
+[ -f $P/deflate_kernels.json ] && cp $P/deflate_kernels.json profiles/${R}_deflate_kernels.json

@@ -90,7 +90,13 @@ class TwxTiming(C.Structure):
                 ("gwr_ms", C.c_float), ("daily_ms", C.c_float), ("fix_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_int64), ("uk_solves", C.c_int64),
                 ("uk_launches", C.c_int64), ("uk_f64_solves", C.c_int64), ("tie_cells", C.c_int64),
-                ("tie_solves", C.c_int64), ("tie_ms", C.c_float), ("reserved", C.c_float)]
+                ("tie_solves", C.c_int64), ("tie_ms", C.c_float), ("deflate_ms", C.c_float)]
+
+
+class TwxDeflated(C.Structure):
+    """twx_deflated (include/twx.h): the chunk streams of a tile whose daily values were deflated on the device."""
+    _fields_ = [("data", C.c_void_p * 2), ("offset", C.POINTER(C.c_int64) * 2), ("nchunks", C.c_int32), ("chunk_y", C.c_int32),
+                ("chunk_x", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_set_days", "twx_set_stations",
@@ -98,6 +104,7 @@ EXPORTS = ("twx_create", "twx_destroy", "twx_last_error", "twx_version", "twx_se
            "twx_interp_grid", "twx_interp_grid_dev", "twx_get_timing", "twx_last_bandwidths",
            "twx_fit_vario_points", "twx_krigall_points", "twx_aggregate_dims", "twx_aggregate", "twx_sample_points", "twx_gwr_xval_points",
            "twx_stream_create", "twx_stream_submit", "twx_stream_wait", "twx_stream_destroy", "twx_stream_times",
+           "twx_stream_deflate", "twx_stream_wait_deflated",
            "twx_set_precision", "twx_set_exclusions", "twx_device_memory")
 
 _LIB = None
@@ -482,9 +489,9 @@ class Context(object):
         self._chk(self.lib.twx_interp_grid(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask)), "twx_interp_grid")
         return out
 
-    def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2):
+    def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2, deflate_chunks=None):
         """Streamed tiles of one shape (twx_stream_*): see ``TileStream``."""
-        return TileStream(self, Y, X, variables, daily, nslots)
+        return TileStream(self, Y, X, variables, daily, nslots, deflate_chunks)
 
     def interp_grid_dev(self, g, o, vars_mask, stream=0):
         """Device-pointer entry (TwxGrid / TwxGridOut hold device addresses)."""
@@ -514,16 +521,26 @@ class Context(object):
 class TileStream(object):
     """Pipelined tiles (twx_stream_create / submit / wait): the outputs of tile t travel to pinned host memory while
     the kernels of tile t + 1 run.  ``wait(slot)`` returns numpy views of the slot's pinned block; they stay valid
-    until the slot is submitted again (copy or write them out before that)."""
+    until the slot is submitted again (copy or write them out before that).
 
-    def __init__(self, ctx, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2):
+    ``deflate_chunks=(cy, cx)`` (twx_stream_deflate): the daily values leave the GPU as the chunk bytes of an HDF5 dataset with
+    shuffle + deflate (one zlib stream per variable and ``(ndays, cy, cx)`` chunk, formed on the device); ``wait`` then returns
+    ``deflated_tmin`` / ``deflated_tmax`` -- lists of uint8 views, chunks in row-major order -- instead of the daily arrays,
+    and ``deflate_chunks``."""
+
+    def __init__(self, ctx, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2, deflate_chunks=None):
         self.ctx, self.Y, self.X, self.daily, self.nslots = ctx, Y, X, daily, nslots
+        self.deflate_chunks = None
         self.vars_mask = (VAR_TMIN_BIT if "tmin" in variables else 0) | (VAR_TMAX_BIT if "tmax" in variables else 0)
         h = C.c_void_p()
         ctx._chk(ctx.lib.twx_stream_create(ctx.h, C.c_int(Y), C.c_int(X), C.c_int(self.vars_mask), C.c_int(int(daily)),
                                            C.c_int(nslots), C.byref(h)), "twx_stream_create")
         self.h = h
         ctx._streams.add(self)
+        if deflate_chunks is not None:
+            cy, cx = (int(v) for v in deflate_chunks)
+            ctx._chk(ctx.lib.twx_stream_deflate(h, C.c_int(cy), C.c_int(cx)), "twx_stream_deflate")
+            self.deflate_chunks = (cy, cx)
 
     def submit(self, slot, grid, rows=None, cols=None):
         a = Context.grid_arrays(grid, rows, cols)
@@ -536,7 +553,12 @@ class TileStream(object):
     def wait(self, slot):
         o = TwxGridOut()
         ms = C.c_float()
-        self.ctx._chk(self.ctx.lib.twx_stream_wait(self.h, C.c_int(slot), C.byref(o), C.byref(ms)), "twx_stream_wait")
+        df = TwxDeflated()
+        if self.deflate_chunks:
+            self.ctx._chk(self.ctx.lib.twx_stream_wait_deflated(self.h, C.c_int(slot), C.byref(o), C.byref(df), C.byref(ms)),
+                          "twx_stream_wait_deflated")
+        else:
+            self.ctx._chk(self.ctx.lib.twx_stream_wait(self.h, C.c_int(slot), C.byref(o), C.byref(ms)), "twx_stream_wait")
         Y, X, nd = self.Y, self.X, self.ctx.ndays
         spec = (("norm_tmin", np.float32, (12, Y, X)), ("se_tmin", np.float32, (12, Y, X)),
                 ("norm_tmax", np.float32, (12, Y, X)), ("se_tmax", np.float32, (12, Y, X)),
@@ -550,6 +572,13 @@ class TileStream(object):
                 buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
                 out[name] = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
         out["device_ms"] = ms.value
+        if self.deflate_chunks:
+            out["deflate_chunks"] = self.deflate_chunks
+            for v, name in enumerate(("tmin", "tmax")):
+                if df.data[v]:
+                    off = np.ctypeslib.as_array(df.offset[v], shape=(df.nchunks + 1,))
+                    whole = np.frombuffer((C.c_char * int(off[-1])).from_address(df.data[v]), np.uint8)
+                    out["deflated_" + name] = [whole[off[c]:off[c + 1]] for c in range(df.nchunks)]
         return out
 
     def times(self, slot):

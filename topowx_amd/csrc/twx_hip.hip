@@ -21,6 +21,7 @@
 #include "twx_vario.h"
 #include "twx_agg.h"
 #include "twx_sample.h"
+#include "twx_deflate.h"
 
 namespace {
 
@@ -64,7 +65,7 @@ struct Work {
     }
 };
 
-enum { EV_TILE = 0, EV_SELECT, EV_UK, EV_GWR, EV_DAILY, EV_FIX, EV_TIE, EV_NKIND };
+enum { EV_TILE = 0, EV_SELECT, EV_UK, EV_GWR, EV_DAILY, EV_FIX, EV_TIE, EV_DEFLATE, EV_NKIND };
 
 struct EvPair { hipEvent_t a, b; int kind; };
 
@@ -1607,6 +1608,16 @@ struct twx_stream {
     hipEvent_t ev_free[2] = {nullptr, nullptr};   // device set d has been copied out
     bool used[2] = {false, false};
     int64_t nsub = 0;
+    // twx_stream_deflate: the daily outputs leave the device as zlib streams per chunk (twx_deflate.h)
+    int df_cy = 0, df_cx = 0, df_nchunk = 0, df_nvar = 0, df_nseg = 0;
+    int64_t df_N = 0, df_slot = 0;                // elements per chunk, bytes of a chunk's device slot
+    DevBuf df_out[2], df_small[2];                // per device set: chunk slots [var][chunk]; block sizes / offsets / Adler sums / chunk sizes
+    std::vector<char *> df_host;                  // per slot, pinned: the tile's streams, one after the other
+    std::vector<int64_t *> df_sizes;              // per slot, pinned: [var][chunk] bytes of every stream
+    std::vector<std::vector<int64_t>> df_off;     // per slot: [var][nchunk + 1] offsets inside the variable's part of df_host[slot]
+    std::vector<GridDev> df_dev;                  // per slot: the device images its deferred copy-out reads
+    std::vector<int> df_set;                      // per slot: device set of its tile
+    int df_pending[2] = {-1, -1};                 // per device set: slot whose copy-out has not been enqueued yet
 };
 
 void twx_stream_destroy(twx_stream *st);
@@ -1654,12 +1665,109 @@ void twx_stream_destroy(twx_stream *st)
     for (int d = 0; d < 2; ++d) { st->din[d].release(); st->dout[d].release(); if (st->ev_free[d]) (void)hipEventDestroy(st->ev_free[d]); }
     for (char *p : st->hin) if (p) (void)hipHostFree(p);
     for (char *p : st->hout) if (p) (void)hipHostFree(p);
+    for (char *p : st->df_host) if (p) (void)hipHostFree(p);
+    for (int64_t *p : st->df_sizes) if (p) (void)hipHostFree(p);
+    for (int d = 0; d < 2; ++d) { st->df_out[d].release(); st->df_small[d].release(); }
     for (auto *v : {&st->ev_start, &st->ev_comp, &st->ev_copy0, &st->ev_done})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (st->s_comp) (void)hipStreamDestroy(st->s_comp);
     if (st->s_copy) (void)hipStreamDestroy(st->s_copy);
     delete st;
 }
+
+namespace {
+// per variable: block sizes + offsets (u32 each), Adler sums (4 u32), piece bits (256 u16) per segment; chunk sizes
+size_t df_small_bytes(const twx_stream *st)
+{
+    return (size_t)st->df_nchunk * st->df_nseg * (24 + 2 * TWX_DF_THREADS) + (size_t)st->df_nchunk * 8 + 5 * 256;
+}
+
+// kernels of twx_deflate.h for the tile in device set d (after its daily values are final), sizes -> the slot's pinned table
+int df_launch(twx_stream *st, int d, const GridDev &dev, int slot)
+{
+    twx_ctx *ctx = st->ctx;
+    EvScope ev(ctx, st->s_comp, EV_DEFLATE);
+    const size_t per_var = (size_t)st->df_nchunk * st->df_nseg;
+    char *small = st->df_small[d].as<char>();
+    int v = 0;
+    for (int var = 0; var < 2; ++var) {
+        const int16_t *daily = var == 0 ? dev.o.daily_tmin : dev.o.daily_tmax;
+        if (!daily) continue;
+        DfArgs a{};
+        a.daily = reinterpret_cast<const uint16_t *>(daily);
+        a.out = st->df_out[d].as<uint8_t>() + (size_t)v * st->df_nchunk * st->df_slot;
+        char *cur = small + (size_t)v * df_small_bytes(st);
+        a.seg_bytes = carve<uint32_t>(cur, per_var);
+        a.seg_off = carve<uint32_t>(cur, per_var);
+        a.adl = carve<uint32_t>(cur, per_var * 4);
+        a.piece_bits = carve<uint16_t>(cur, per_var * TWX_DF_THREADS);
+        // the chunk sizes go straight into the slot's pinned table (mapped host memory): a copy command on this stream would queue
+        // behind the bulk copy-out of the tile before on the DMA engine and hold this tile's "kernels done" event back
+        a.chunk_bytes = st->df_sizes[slot] + (size_t)v * st->df_nchunk;
+        a.N = st->df_N; a.slot_bytes = st->df_slot; a.lo_bytes = df_lo_bytes(st->df_N);
+        a.Y = st->Y; a.X = st->X; a.cy = st->df_cy; a.cx = st->df_cx; a.ncx = st->X / st->df_cx; a.nseg = st->df_nseg;
+        const dim3 grid((unsigned)st->df_nchunk, (unsigned)st->df_nseg);     // (chunks fastest: twx_deflate.h)
+        const bool pairs = st->df_cx % 2 == 0 && st->X % 2 == 0;     // two neighbouring values per load
+        if (pairs) hipLaunchKernelGGL(k_deflate_count<2>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
+        else hipLaunchKernelGGL(k_deflate_count<1>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
+        hipLaunchKernelGGL(k_deflate_scan, dim3((unsigned)st->df_nchunk), dim3(TWX_DF_THREADS), 0, st->s_comp, a);
+        if (pairs) hipLaunchKernelGGL(k_deflate_emit<2>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
+        else hipLaunchKernelGGL(k_deflate_emit<1>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
+        ++v;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the copy-out of the slot's tile: small outputs into the slot's pinned block, every chunk stream -- its size is known now --
+// into the slot's stream block, one after the other
+int df_enqueue_copy(twx_stream *st, int slot)
+{
+    twx_ctx *ctx = st->ctx;
+    const int d = st->df_set[slot];
+    GridDev &dev = st->df_dev[slot];
+    HIPCHK(hipEventSynchronize(st->ev_comp[slot]));                 // kernels done, sizes in df_sizes[slot]
+    HIPCHK(hipStreamWaitEvent(st->s_copy, st->ev_comp[slot], 0));
+    HIPCHK(hipEventRecord(st->ev_copy0[slot], st->s_copy));
+    GridDev &view = st->views[slot];
+    view = GridDev{};
+    char *hout = st->hout[slot];
+    twx_grid_out hv{};
+    void **fields_dev[6] = {(void **)&dev.o.norm_tmin, (void **)&dev.o.se_tmin, (void **)&dev.o.norm_tmax, (void **)&dev.o.se_tmax,
+                            (void **)&dev.o.ninvalid, (void **)&dev.o.status};
+    void **fields_host[6] = {(void **)&hv.norm_tmin, (void **)&hv.se_tmin, (void **)&hv.norm_tmax, (void **)&hv.se_tmax,
+                             (void **)&hv.ninvalid, (void **)&hv.status};
+    const size_t yx = (size_t)st->Y * st->X;
+    const size_t fbytes[6] = {yx * 48, yx * 48, yx * 48, yx * 48, yx * 4, yx * 4};
+    for (int f = 0; f < 6; ++f) {
+        if (!*fields_dev[f]) continue;
+        *fields_host[f] = hout;
+        HIPCHK(hipMemcpyAsync(hout, *fields_dev[f], fbytes[f], hipMemcpyDeviceToHost, st->s_copy));
+        hout += (fbytes[f] + 255) / 256 * 256;
+    }
+    view.o = hv;
+    std::vector<int64_t> &off = st->df_off[slot];
+    off.assign((size_t)st->df_nvar * (st->df_nchunk + 1), 0);
+    char *dst = st->df_host[slot];
+    for (int v = 0; v < st->df_nvar; ++v) {
+        int64_t o = 0;
+        for (int c = 0; c < st->df_nchunk; ++c) {
+            const int64_t n = st->df_sizes[slot][(size_t)v * st->df_nchunk + c];
+            if (n <= 0 || n > st->df_slot) return fail(ctx, "twx_stream: a deflated chunk has an impossible size (device fault?)");
+            off[(size_t)v * (st->df_nchunk + 1) + c] = o;
+            HIPCHK(hipMemcpyAsync(dst + o, st->df_out[d].as<char>() + ((size_t)v * st->df_nchunk + c) * st->df_slot, (size_t)n,
+                                  hipMemcpyDeviceToHost, st->s_copy));
+            o += n;
+        }
+        off[(size_t)v * (st->df_nchunk + 1) + st->df_nchunk] = o;
+        dst += (size_t)st->df_nchunk * st->df_slot;                  // (every variable's part can hold the longest streams)
+    }
+    HIPCHK(hipEventRecord(st->ev_free[d], st->s_copy));
+    HIPCHK(hipEventRecord(st->ev_done[slot], st->s_copy));
+    st->df_pending[d] = -1;
+    return 0;
+}
+}  // namespace
 
 int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
 {
@@ -1680,6 +1788,16 @@ int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
     carve_grid(g, &want, st->vars, ctx->ndays, st->din[d].as<char>(), st->dout[d].as<char>(), dev);
     // stage the predictors in pinned memory (61 B / cell), then everything else is asynchronous
     char *hin = st->hin[slot];
+    if (st->df_cy) {
+        // Deflated outputs: the copy-out of a tile nobody has waited for yet starts NOW (df_enqueue_copy waits for its kernels) --
+        // the tile whose slot / device set this call reuses, and also the tile in the other device set: a pipelined caller gets
+        // here right after the copy-out of the tile before that one, and this call's own read-backs return only ~20 ms into this
+        // tile's kernels; enqueued after them, the copy engine idled that long per tile (configs[3]: 30.2 s end to end, 26.8 s with
+        // a non-blocking test of the event here, which often lost the race by a hair).  Where the kernels are the longer stage
+        // this wait costs the host's launch latency per tile, nothing more: the next kernels queue behind them anyway.
+        for (int dd = 0; dd < 2; ++dd)
+            if (st->df_pending[dd] >= 0 && df_enqueue_copy(st, st->df_pending[dd])) return -1;
+    }
     HIPCHK(hipEventSynchronize(st->ev_done[slot]));                 // the slot's previous tile has left the device
     for (auto &it : dev.in_items) {
         std::memcpy(hin, it.host, it.bytes);
@@ -1689,6 +1807,20 @@ int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
     }
     HIPCHK(hipEventRecord(st->ev_start[slot], st->s_comp));
     if (twx_interp_grid_dev(ctx, &dev.g, &dev.o, st->vars, st->s_comp)) return -1;
+    if (st->df_cy) {
+        // the chunk streams of both variables, and their sizes to the slot's pinned table; the copy-out itself is enqueued by
+        // twx_stream_wait_deflated (it needs the sizes) -- nothing goes on the copy stream here, so that the copy-out of tile t
+        // is never queued behind a wait for the kernels of tile t + 1
+        if (df_launch(st, d, dev, slot)) return -1;
+        HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_comp));
+        st->df_dev[slot] = dev;
+        st->df_set[slot] = d;
+        st->df_pending[d] = slot;
+        st->views[slot] = GridDev{};
+        st->used[d] = true;
+        st->nsub++;
+        return 0;
+    }
     HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_comp));
     // copy stream: device set d -> the slot's pinned block, overlapping the next tile's kernels
     HIPCHK(hipStreamWaitEvent(st->s_copy, st->ev_comp[slot], 0));
@@ -1723,9 +1855,78 @@ int twx_stream_wait(twx_stream *st, int slot, twx_grid_out *views, float *device
     twx_ctx *ctx = st->ctx;
     ctx->err.clear();
     if (slot < 0 || slot >= st->nslots || !views) return fail(ctx, "twx_stream_wait: bad arguments");
+    if (st->df_cy) return fail(ctx, "twx_stream_wait: this stream delivers deflated chunks (twx_stream_deflate): call twx_stream_wait_deflated");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipEventSynchronize(st->ev_done[slot]));
     *views = st->views[slot].o;
+    if (device_ms) {
+        *device_ms = 0.f;
+        if (st->views[slot].o.status) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
+    }
+    return 0;
+}
+
+int twx_stream_deflate(twx_stream *st, int chunk_y, int chunk_x)
+{
+    if (!st) return -1;
+    twx_ctx *ctx = st->ctx;
+    ctx->err.clear();
+    if (!st->daily) return fail(ctx, "twx_stream_deflate: the stream has no daily outputs");
+    if (st->nsub || st->df_cy) return fail(ctx, "twx_stream_deflate: call it once, before the first twx_stream_submit");
+    if (chunk_y <= 0 || chunk_x <= 0 || st->Y % chunk_y || st->X % chunk_x)
+        return fail(ctx, "twx_stream_deflate: the chunk shape must divide the tile's");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t N = ctx->ndays * (int64_t)chunk_y * chunk_x;
+    if (df_slot_bytes(N) >= (int64_t)1 << 32) return fail(ctx, "twx_stream_deflate: a chunk of more than 2^31 values");
+    st->df_N = N; st->df_slot = df_slot_bytes(N); st->df_nseg = df_nseg(N);
+    st->df_nchunk = (st->Y / chunk_y) * (st->X / chunk_x);
+    st->df_nvar = ((st->vars & TWX_VAR_TMIN_BIT) ? 1 : 0) + ((st->vars & TWX_VAR_TMAX_BIT) ? 1 : 0);
+    const size_t per_var = (size_t)st->df_nchunk * st->df_nseg;
+    const size_t out_bytes = (size_t)st->df_nvar * st->df_nchunk * st->df_slot;
+    bool ok = true;
+    for (int d = 0; ok && d < 2; ++d)
+        ok = st->df_out[d].ensure(out_bytes) == hipSuccess &&
+             st->df_small[d].ensure((size_t)st->df_nvar * df_small_bytes(st)) == hipSuccess;
+    // the pinned blocks no longer hold the daily arrays: allocate them again without, and the stream blocks beside them
+    const size_t small_bytes = grid_out_bytes(st->Y, st->X, ctx->ndays, false, false);
+    st->df_host.assign(st->nslots, nullptr); st->df_sizes.assign(st->nslots, nullptr);
+    st->df_off.resize(st->nslots); st->df_dev.resize(st->nslots); st->df_set.assign(st->nslots, 0);
+    for (int i = 0; ok && i < st->nslots; ++i) {
+        if (st->hout[i]) (void)hipHostFree(st->hout[i]);
+        st->hout[i] = nullptr;
+        ok = hipHostMalloc((void **)&st->hout[i], small_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void **)&st->df_host[i], out_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void **)&st->df_sizes[i], (size_t)st->df_nvar * st->df_nchunk * 8, hipHostMallocDefault) == hipSuccess;
+    }
+    if (!ok) return fail(ctx, "twx_stream_deflate: allocation failed (chunk slots / pinned stream blocks)");
+    st->df_cy = chunk_y; st->df_cx = chunk_x;
+    return 0;
+}
+
+int twx_stream_wait_deflated(twx_stream *st, int slot, twx_grid_out *views, twx_deflated *streams, float *device_ms)
+{
+    if (!st) return -1;
+    twx_ctx *ctx = st->ctx;
+    ctx->err.clear();
+    if (slot < 0 || slot >= st->nslots || !views || !streams) return fail(ctx, "twx_stream_wait_deflated: bad arguments");
+    if (!st->df_cy) return fail(ctx, "twx_stream_wait_deflated: twx_stream_deflate was not called on this stream");
+    HIPCHK(hipSetDevice(ctx->device));
+    for (int d = 0; d < 2; ++d)
+        if (st->df_pending[d] == slot && df_enqueue_copy(st, slot)) return -1;
+    HIPCHK(hipEventSynchronize(st->ev_done[slot]));
+    *views = st->views[slot].o;
+    twx_deflated r{};
+    r.nchunks = st->df_nchunk; r.chunk_y = st->df_cy; r.chunk_x = st->df_cx;
+    if (st->views[slot].o.status) {
+        int v = 0;
+        for (int var = 0; var < 2; ++var) {
+            if (!(st->vars & (var == 0 ? TWX_VAR_TMIN_BIT : TWX_VAR_TMAX_BIT))) continue;
+            r.data[var] = reinterpret_cast<const uint8_t *>(st->df_host[slot]) + (size_t)v * st->df_nchunk * st->df_slot;
+            r.offset[var] = st->df_off[slot].data() + (size_t)v * (st->df_nchunk + 1);
+            ++v;
+        }
+    }
+    *streams = r;
     if (device_ms) {
         *device_ms = 0.f;
         if (st->views[slot].o.status) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
@@ -1763,7 +1964,7 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
 {
     if (!ctx || !t) return -1;
     HIPCHK(hipSetDevice(ctx->device));
-    float acc[EV_NKIND] = {0, 0, 0, 0, 0, 0, 0};
+    float acc[EV_NKIND] = {};
     for (size_t i = 0; i < ctx->ev_used; ++i) {
         HIPCHK(hipEventSynchronize(ctx->ev_pool[i].b));
         float ms = 0;
@@ -1780,7 +1981,7 @@ int twx_get_timing(twx_ctx *ctx, twx_timing *t)
     long long st[5] = {0, 0, 0, 0, 0};
     if (ctx->stats.p) HIPCHK(hipMemcpy(st, ctx->stats.p, sizeof st, hipMemcpyDeviceToHost));
     r.cells = ctx->t_cells; r.uk_solves = st[0]; r.uk_launches = st[1]; r.uk_f64_solves = st[2];
-    r.tie_solves = st[3]; r.tie_cells = st[4]; r.tie_ms = acc[EV_TIE];
+    r.tie_solves = st[3]; r.tie_cells = st[4]; r.tie_ms = acc[EV_TIE]; r.deflate_ms = acc[EV_DEFLATE];
     *t = r;
     return 0;
 }

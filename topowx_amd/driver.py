@@ -263,7 +263,7 @@ class PrecisionPolicy(object):
 
 
 def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
-                          writer_threads=1, tile_ms=None, precision="auto", log=None):
+                          writer_threads=1, tile_ms=None, precision="auto", log=None, deflate_chunks=None):
     """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
     tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
     workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
@@ -275,6 +275,10 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     ``precision``: "auto" | "fast" | "exact", see ``PrecisionPolicy`` -- auto = the fp64 covariance build (outputs exact to the
     last int16 / f4 bit) whenever the tiles' kernels hide behind their copy-out, i.e. for free.  ``log``: a dict that receives
     the policy's summary (the mode the run ended in, tiles per mode, mean device / copy ms, the decision in words).
+    ``deflate_chunks=(cy, cx)``: the daily values leave the GPU as the chunk bytes of an HDF5 dataset with shuffle + deflate
+    (``TileStream``, twx_stream_deflate): ``arrays`` then holds ``deflated_tmin`` / ``deflated_tmax`` (one zlib stream per
+    ``(ndays, cy, cx)`` chunk, row-major chunk order) instead of the daily arrays -- about half the bytes over PCIe and no
+    deflate on the host (``ncio.TileSink(zlib=True)`` appends them with ``H5Dwrite_chunk``).
     Returns (results or None, seconds, device_ms)."""
     import queue
     import threading
@@ -283,10 +287,11 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     collected = {}
     if sink is None:
         def sink(k, arrays):
-            collected[k] = {n: np.array(v) for n, v in arrays.items() if hasattr(v, "shape")}
+            collected[k] = {n: (np.array(v) if hasattr(v, "shape") else [bytes(b) for b in v])
+                            for n, v in arrays.items() if hasattr(v, "shape") or n.startswith("deflated_")}
     writer_threads = max(1, int(writer_threads))
     nslots = 2 + writer_threads                 # one computing, one copying out, one at each writer
-    st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots)
+    st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots, deflate_chunks=deflate_chunks)
     q = queue.Queue(maxsize=1)
     free = [threading.Semaphore(1) for _ in range(nslots)]
     err = []

@@ -625,6 +625,19 @@ class TileSink(object):
         shuf = np.ascontiguousarray(blk.reshape(-1).view(np.uint8).reshape(-1, 2).T)      # HDF5's shuffle: byte planes
         return _z.compress(shuf, level)
 
+    @staticmethod
+    def _inflate_tile(blobs, shape, cy, cx):
+        """Chunk streams (row-major chunk order) -> the int16 tile they hold: inflate, undo HDF5's shuffle."""
+        import zlib as _z
+        out = np.empty(shape, np.int16)
+        it = iter(blobs)
+        for r0 in range(0, shape[1], cy):
+            for c0 in range(0, shape[2], cx):
+                raw = np.frombuffer(_z.decompress(next(it)), np.uint8)
+                n = raw.size // 2
+                out[:, r0:r0 + cy, c0:c0 + cx] = np.stack([raw[:n], raw[n:]], axis=1).reshape(-1).view("<i2").reshape(shape[0], cy, cx)
+        return out
+
     def _small(self, ds, var, arrays):
         g = ds.variables
         g[var + "_normal"][:] = np.asarray(arrays["norm_" + var], np.float32)
@@ -637,7 +650,11 @@ class TileSink(object):
         tile_id = self.info.get_tile_id(k)
         cy, cx = self.info.chk_size_y, self.info.chk_size_x
         have = [v for v in self.variables if arrays.get("norm_" + v) is not None]
-        present = [v for v in have if arrays.get("daily_" + v) is not None]      # (a normals-only run: the small variables alone)
+        # (a normals-only run: the small variables alone; a stream with deflate_chunks: the chunk bytes as the GPU formed them)
+        present = [v for v in have if arrays.get("daily_" + v) is not None or arrays.get("deflated_" + v) is not None]
+        if any(arrays.get("deflated_" + v) is not None for v in present):
+            if not self.zlib or tuple(arrays["deflate_chunks"]) != (cy, cx):
+                raise IOError("deflated chunks need a TileSink with zlib=True and the stream's chunk shape %r" % ((cy, cx),))
         jobs, open_ds, writes, stages = [], [], [], []
         if self.zlib:
             for var in have:
@@ -646,14 +663,18 @@ class TileSink(object):
                 open_ds.append(ds)
                 if var not in present:
                     continue
+                if arrays.get("deflated_" + var) is not None:  # already shuffled + deflated, chunks in row-major order
+                    offs = [(0, r0, c0) for r0 in range(0, self.info.tile_size_y, cy) for c0 in range(0, self.info.tile_size_x, cx)]
+                    jobs += [(None, ds.variables[var], off, blob) for off, blob in zip(offs, arrays["deflated_" + var])]
+                    continue
                 src = arrays["daily_" + var]
                 for r0 in range(0, src.shape[1], cy):
                     for c0 in range(0, src.shape[2], cx):
-                        jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), ds.variables[var], (0, r0, c0)))
+                        jobs.append((self.pool.submit(self._deflate, src, r0, c0, cy, cx, self.complevel), ds.variables[var], (0, r0, c0), None))
             self._add(prepare_s=_t.perf_counter() - t_begin)
             t1 = _t.perf_counter()
-            for fut, var_obj, off in jobs:
-                var_obj.write_chunk_raw(off, fut.result())      # (raises what a worker raised)
+            for fut, var_obj, off, blob in jobs:
+                var_obj.write_chunk_raw(off, blob if fut is None else fut.result())      # (raises what a worker raised)
             for ds in open_ds:
                 ds.close()
         else:
@@ -696,15 +717,20 @@ class TileSink(object):
                 self._staging.put(stg)
         self._add(copy_s=_t.perf_counter() - t1)
         for var in present:
-            self._add(int16_bytes=int(arrays["daily_" + var].nbytes), disk_bytes=os.path.getsize(self.writer.fpath(tile_id, var)))
+            nb = (arrays["daily_" + var].nbytes if arrays.get("daily_" + var) is not None
+                  else 2 * self.days.size * self.info.tile_size_y * self.info.tile_size_x)
+            self._add(int16_bytes=int(nb), disk_bytes=os.path.getsize(self.writer.fpath(tile_id, var)))
         self._add(tiles=1, total_s=_t.perf_counter() - t_begin)
         if k in self.verify:
             for var in present:
                 ds = open_dataset(self.writer.fpath(tile_id, var), "r")
                 try:
                     v = ds.variables[var]
+                    want = arrays.get("daily_" + var)
+                    if want is None:                            # deflated on the GPU: what zlib makes of the streams handed over
+                        want = self._inflate_tile(arrays["deflated_" + var], v.shape, cy, cx)
                     for r0 in range(0, v.shape[1], cy):        # chunk-aligned slabs: every stored byte is read once
-                        if not np.array_equal(v[:, r0:r0 + cy, :], arrays["daily_" + var][:, r0:r0 + cy, :]):
+                        if not np.array_equal(v[:, r0:r0 + cy, :], want[:, r0:r0 + cy, :]):
                             raise IOError("%s: read-back differs from what was written" % ds.path)
                     for name, key in ((var + "_normal", "norm_" + var), (var + "_se", "se_" + var), ("inconsist_tair", "ninvalid")):
                         if not np.array_equal(ds.variables[name][:], arrays[key]):
