@@ -120,6 +120,19 @@ def test_h5py_reads_what_ncio_writes(tmp_path):
             assert d[var]["attrs"]["_FillValue"] == [-32767]
         t = ncio.read_tile(sink.writer.fpath("h00v00", "tmin"), "tmin")
         assert np.array_equal(t["daily"], arrays["daily_tmin"]) and np.array_equal(t["ninvalid"], ninv)
+    # ---- chunks deflated by the GPU's encoder (here: its CPU restatement, byte-identical -- tests/test_gpu_deflate.py), appended
+    #      with H5Dwrite_chunk: h5py's own HDF5 + zlib decode them
+    from oracle import deflate_oracle as dorc
+    pre = {k: v for k, v in arrays.items() if not k.startswith("daily_")}
+    pre.update({"deflated_tmin": dorc.deflate_tile(arrays["daily_tmin"], 4, 3), "deflated_tmax": dorc.deflate_tile(arrays["daily_tmax"], 4, 3),
+                "deflate_chunks": (4, 3)})
+    sink = ncio.TileSink(info, str(tmp_path / "sink_gpu"), days, threads=2, zlib=True, verify=(0,))
+    sink(0, pre)
+    sink.close()
+    for var in ("tmin", "tmax"):
+        d = peer("describe", sink.writer.fpath("h00v00", var))
+        assert d[var]["compression"] == "gzip" and d[var]["shuffle"] and d[var]["chunks"] == [nd, 4, 3]
+        assert d[var]["sha256"] == sha(arrays["daily_" + var]), var
     # ---- a daily mosaic file
     p_m = str(tmp_path / "mosaic.nc")
     ds = ncio.create_dly_mosaic_ds(p_m, "tmin", days, lons, lats, "1.2.3", format="NETCDF4")

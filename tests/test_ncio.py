@@ -115,6 +115,50 @@ def test_tile_sink_whole_tiles(tmp_path, zl):
     assert (t["daily"] == ncio.FILL_I2).all() and sink.stats["int16_bytes"] == 0
 
 
+@pytest.mark.skipif(not h5nc.available(), reason="libhdf5 not loadable")
+def test_tile_sink_appends_chunks_deflated_elsewhere(tmp_path):
+    """``TileSink(zlib=True)`` fed with chunk bytes that are already shuffled + deflated -- what a stream with ``deflate_chunks``
+    delivers (twx_stream_deflate; here the CPU restatement of the GPU's encoder makes them): ``H5Dwrite_chunk`` appends them as
+    they are, libhdf5's filter pipeline (its zlib) reads the int16 values back."""
+    from oracle import deflate_oracle as dorc
+    info = _info()
+    days = get_days_metadata(dt.date(1999, 12, 1), dt.date(2000, 3, 31))
+    rng = np.random.default_rng(5)
+    base = 800 * np.sin(np.arange(days.size) / 9.0)[:, None, None] + rng.normal(0, 40, (1, 8, 6))
+    arrays = {"ninvalid": rng.integers(0, 7, (8, 6)).astype("i4"), "deflate_chunks": (4, 3)}
+    daily = {}
+    for var, off in (("tmin", -300), ("tmax", 500)):
+        daily[var] = np.rint(base + off + rng.normal(0, 15, (days.size, 8, 6))).astype(np.int16)
+        daily[var][:, 0, :2] = ncio.FILL_I2
+        arrays["deflated_" + var] = dorc.deflate_tile(daily[var], 4, 3)
+        arrays["norm_" + var] = rng.normal(0, 5, (12, 8, 6)).astype("f4")
+        arrays["se_" + var] = rng.random((12, 8, 6)).astype("f4")
+    sink = ncio.TileSink(info, str(tmp_path), days, threads=2, zlib=True, verify=(1,))
+    sink(1, arrays)
+    sink.close()
+    assert sink.stats["verified"] == 1 and sink.stats["int16_bytes"] == 2 * daily["tmin"].nbytes
+    for var in ("tmin", "tmax"):
+        t = ncio.read_tile(sink.writer.fpath("h01v00", var), var)
+        np.testing.assert_array_equal(t["daily"], daily[var])
+        np.testing.assert_array_equal(t["norm"], arrays["norm_" + var])
+        ds = h5nc.Dataset(sink.writer.fpath("h01v00", var))
+        f = ds.variables[var].filters()
+        assert f["zlib"] and f["shuffle"] and ds.variables[var].chunking() == [days.size, 4, 3]
+        ds.close()
+    with pytest.raises(IOError, match="zlib=True"):
+        plain = ncio.TileSink(info, str(tmp_path / "p"), days, threads=2)
+        try:
+            plain(1, arrays)
+        finally:
+            plain.close()
+    with pytest.raises(IOError, match="chunk shape"):
+        other = ncio.TileSink(info, str(tmp_path / "o"), days, threads=2, zlib=True)
+        try:
+            other(1, dict(arrays, deflate_chunks=(8, 6)))
+        finally:
+            other.close()
+
+
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_tiles_to_daily_mosaic(tmp_path, fmt):
     info = _info()

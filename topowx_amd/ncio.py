@@ -511,7 +511,10 @@ class TileSink(object):
       flight -- EXPERIMENTS.md.)
     * ``zlib=True`` (the reference's tiles are not compressed; its mosaics are): the workers gather, byte-shuffle and
       deflate each chunk (``zlib`` releases the GIL) and the sink's own thread appends the stored bytes with
-      ``H5Dwrite_chunk`` -- for the library a byte copy.
+      ``H5Dwrite_chunk`` -- for the library a byte copy.  A tile that arrives with ``deflated_<var>`` lists (a stream with
+      ``deflate_chunks``: the GPU formed the chunk bytes, twx_stream_deflate) is appended as it is: no core deflates.  The files
+      are prepared ahead like the plain ones, extended by ``deflate_prealloc`` x the int16 size so that the appends go into
+      allocated pages (the library truncates a file to its end-of-allocation when it closes it).
 
     Thread-safe: with ``driver.interp_tiles_streamed(writer_threads=2)`` two tiles (four files) are written at once.
     The files are complete NetCDF-4 files of the ``TileWriter`` layout (``read_tile`` / ``h5nc.Dataset`` / any HDF5 reader
@@ -521,7 +524,7 @@ class TileSink(object):
     checked, raises on a difference)."""
 
     def __init__(self, tile_grid_info, path_out, days, threads=None, zlib=False, complevel=1, verify=(), day_segments=None,
-                 variables=("tmin", "tmax"), order=None, ahead=2, prep_threads=2):
+                 variables=("tmin", "tmax"), order=None, ahead=2, prep_threads=2, deflate_prealloc=0.75):
         import queue
         from concurrent.futures import ThreadPoolExecutor
         if not h5nc.available():
@@ -530,6 +533,7 @@ class TileSink(object):
         self.writer = TileWriter(tile_grid_info, path_out, format="NETCDF4", zlib=zlib, complevel=complevel)
         self.threads = int(threads or min(32, os.cpu_count() or 8))
         self.zlib, self.complevel, self.verify = bool(zlib), int(complevel), set(verify)
+        self.deflate_prealloc = float(deflate_prealloc)         # zlib: pages allocated ahead, as a fraction of the int16 size
         self.pool = ThreadPoolExecutor(self.threads)             # gathers / deflates
         self.write_pool = ThreadPoolExecutor(8)                  # one pwrite loop per file in flight
         self._lock = threading.Lock()                           # several tiles may be written at once (driver: writer_threads)
@@ -554,6 +558,21 @@ class TileSink(object):
         tile_id = self.info.get_tile_id(k)
         fpath = self.writer.fpath(tile_id, var)
         ds = self.writer._create(fpath, tile_id, var, self.days, early=True)
+        if self.zlib:
+            # deflated chunks have no address before they exist: the library appends them (H5Dwrite_chunk).  But the pages it will
+            # append into can exist: the file is extended to what the chunks will about need (libhdf5 opens a file longer than
+            # its end-of-allocation and truncates it to that when it closes), so the appends are copies into allocated pages
+            ds.close()
+            t0 = _t.perf_counter()
+            raw = 2 * self.days.size * self.info.tile_size_y * self.info.tile_size_x
+            fd = os.open(fpath, os.O_RDWR)
+            try:
+                os.posix_fallocate(fd, 0, os.fstat(fd).st_size + int(self.deflate_prealloc * raw))
+            except OSError:
+                pass
+            finally:
+                os.close(fd)
+            return fpath, None, None, _t.perf_counter() - t0
         ds.sync()
         info = ds.variables[var].chunk_info()
         ds.close()
@@ -657,8 +676,13 @@ class TileSink(object):
                 raise IOError("deflated chunks need a TileSink with zlib=True and the stream's chunk shape %r" % ((cy, cx),))
         jobs, open_ds, writes, stages = [], [], [], []
         if self.zlib:
+            prepared = self._prepared(k)
+            for var in self.variables:
+                if var not in have:
+                    os.remove(prepared[var][0])
             for var in have:
-                ds = self.writer._create(self.writer.fpath(tile_id, var), tile_id, var, self.days, early=True)
+                self._add(fallocate_s=prepared[var][3])
+                ds = open_dataset(prepared[var][0], "a")
                 self._small(ds, var, arrays)
                 open_ds.append(ds)
                 if var not in present:
@@ -744,7 +768,8 @@ class TileSink(object):
             for f in futs.values():
                 try:
                     fpath, fd = f.result()[:2]
-                    os.close(fd)
+                    if fd is not None:
+                        os.close(fd)
                     os.remove(fpath)
                     os.rmdir(os.path.dirname(fpath))            # (the tile's directory, when this was its last file)
                 except Exception:                               # noqa: BLE001 -- a failed preparation, a directory still in use
