@@ -174,9 +174,17 @@ class Context(object):
         self.id_to_idx = {}
         self.mth_days = None
         self._streams = weakref.WeakSet()       # open TileStreams: closed before the context (twx_destroy frees them too)
+        self._kept_streams = {}                 # stream(..., keep=True): by shape, reused until drop_streams() / close()
+
+    def drop_streams(self):
+        """Close the streams ``stream(..., keep=True)`` holds (each: two device images and its pinned host slots)."""
+        for st in list(self._kept_streams.values()):
+            st.close()
+        self._kept_streams.clear()
 
     def close(self):
         if getattr(self, "h", None):
+            self._kept_streams.clear()
             for st in list(self._streams):
                 st.close()
             self.lib.twx_destroy(self.h)
@@ -489,9 +497,17 @@ class Context(object):
         self._chk(self.lib.twx_interp_grid(self.h, C.byref(g), C.byref(o), C.c_int(vars_mask)), "twx_interp_grid")
         return out
 
-    def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2, deflate_chunks=None):
-        """Streamed tiles of one shape (twx_stream_*): see ``TileStream``."""
-        return TileStream(self, Y, X, variables, daily, nslots, deflate_chunks)
+    def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2, deflate_chunks=None, keep=False):
+        """Streamed tiles of one shape (twx_stream_*): see ``TileStream``.  ``keep``: the stream stays with the context and the
+        next call with the same arguments gets it back (pinning and unpinning the host slots of a configs[3]-sized stream takes
+        ~1 s each way: a run that streams tile lists one after the other pays it once)."""
+        if not keep:
+            return TileStream(self, Y, X, variables, daily, nslots, deflate_chunks)
+        key = (Y, X, tuple(variables), bool(daily), int(nslots), None if deflate_chunks is None else tuple(int(v) for v in deflate_chunks))
+        st = self._kept_streams.get(key)
+        if st is None or not getattr(st, "h", None):
+            st = self._kept_streams[key] = TileStream(self, Y, X, variables, daily, nslots, deflate_chunks)
+        return st
 
     def interp_grid_dev(self, g, o, vars_mask, stream=0):
         """Device-pointer entry (TwxGrid / TwxGridOut hold device addresses)."""

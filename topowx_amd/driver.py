@@ -263,7 +263,7 @@ class PrecisionPolicy(object):
 
 
 def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "tmax"), daily=False, sink=None,
-                          writer_threads=1, tile_ms=None, precision="auto", log=None, deflate_chunks=None):
+                          writer_threads=1, tile_ms=None, precision="auto", log=None, deflate_chunks=None, trace=None):
     """Tiles of this rank through a ``TileStream`` (twx_stream_*): while the GPU interpolates tile t + 1 the outputs of
     tile t arrive in pinned host memory and go to ``sink(tile_number, arrays)`` on a writer thread (the reference's
     workers hand every finished chunk to a writer, step25:177-196).  ``sink`` must be done with the arrays when it
@@ -279,6 +279,10 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     (``TileStream``, twx_stream_deflate): ``arrays`` then holds ``deflated_tmin`` / ``deflated_tmax`` (one zlib stream per
     ``(ndays, cy, cx)`` chunk, row-major chunk order) instead of the daily arrays -- about half the bytes over PCIe and no
     deflate on the host (``ncio.TileSink(zlib=True)`` appends them with ``H5Dwrite_chunk``).
+    ``trace``: a list that receives ``(tile_number, "submit" | "wait", t_begin, t_end)`` in seconds since the start of the run
+    (a diagnostic: where the host spends a tile's period).
+    The stream (two device images, ``2 + writer_threads`` pinned host slots: 6.3 GB each for a configs[3] tile) stays with the
+    context for the next run over tiles of this shape; ``ctx.drop_streams()`` releases it.
     Returns (results or None, seconds, device_ms)."""
     import queue
     import threading
@@ -291,7 +295,8 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
                             for n, v in arrays.items() if hasattr(v, "shape") or n.startswith("deflated_")}
     writer_threads = max(1, int(writer_threads))
     nslots = 2 + writer_threads                 # one computing, one copying out, one at each writer
-    st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots, deflate_chunks=deflate_chunks)
+    # (kept with the context: the next run over tiles of this shape reuses the device images and the pinned slots)
+    st = ctx.stream(tile_y, tile_x, variables=variables, daily=daily, nslots=nslots, deflate_chunks=deflate_chunks, keep=True)
     q = queue.Queue(maxsize=1)
     free = [threading.Semaphore(1) for _ in range(nslots)]
     err = []
@@ -316,9 +321,15 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
     dev_ms = 0.0
     pending = None
 
+    seen_in, seen_out, done = [], [], False
+
     def collect(pk, pslot, pmode):
         nonlocal dev_ms
+        tb = time.perf_counter()
         out = st.wait(pslot)                    # tile t is on the host; tile t + 1 is already running
+        seen_out.append(pk)
+        if trace is not None:
+            trace.append((pk, "wait", tb - t0, time.perf_counter() - t0))
         ms = out.pop("device_ms")
         dev_ms += ms
         policy.observe(pmode, ms, st.times(pslot)[1], tile=pk)
@@ -333,18 +344,24 @@ def interp_tiles_streamed(ctx, grid, tiles, tile_y, tile_x, variables=("tmin", "
             if err:                             # the sink failed: no point in interpolating the rest
                 break
             submitted_as = policy.mode
+            tb = time.perf_counter()
             st.submit(slot, grid, slice(i, i + tile_y), slice(j, j + tile_x))
+            seen_in.append(k)
+            if trace is not None:
+                trace.append((k, "submit", tb - t0, time.perf_counter() - t0))
             if pending is not None:
                 collect(*pending)
             pending = (k, slot, submitted_as)
         if pending is not None:
             collect(*pending)
+        done = True
     finally:
         for _ in ths:
             q.put(None)
         for th in ths:
             th.join()
-        st.close()
+        if not done or len(seen_out) != len(seen_in):     # an error on the way, a tile submitted and never collected: start afresh next time
+            st.close()
         policy.close()
     if log is not None:
         log.update(policy.summary())
