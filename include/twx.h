@@ -342,8 +342,9 @@ void twx_stream_destroy(twx_stream *st);
  * twx_stream_deflate (once, before the first submit of a stream created with daily != 0; Y % chunk_y == 0, X % chunk_x == 0) makes
  * the stream form those chunk bytes ON THE DEVICE (csrc/twx_deflate.h): per variable and chunk of chunk_y x chunk_x cells x all
  * days one zlib stream (RFC 1950) of the shuffled chunk -- low bytes in stored blocks, high bytes run-length coded in
- * fixed-Huffman blocks -- that any inflate reads and H5Dwrite_chunk appends to a dataset created with shuffle + deflate as it is.
- * The daily arrays then stay on the device (views.daily_* are NULL) and the tile leaves it at ~0.5-0.65 of its size.
+ * dynamic-Huffman blocks, one code per variable and tile -- that any inflate reads and H5Dwrite_chunk appends to a dataset
+ * created with shuffle + deflate as it is (zlib level 1's size on the same chunks).
+ * The daily arrays then stay on the device (views.daily_* are NULL) and the tile leaves it at ~0.5-0.6 of its size.
  * twx_stream_wait_deflated replaces twx_stream_wait for such a stream: the copy-out of a tile is enqueued by THIS call (the sizes
  * of its streams are known only when its kernels are done), so call it for tile t after submitting tile t + 1, as a pipelined
  * caller does anyway; a tile still not waited for when its slot or its device image is needed again is copied out by

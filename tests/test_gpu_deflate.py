@@ -17,7 +17,7 @@ def _tile_chunks(daily, cy, cx):
 
 
 @pytest.mark.parametrize("rows,cols,cy,cx", [(slice(20, 60), slice(30, 80), 10, 10),      # 20 chunks of 109 600 values: 7 blocks each
-                                             (slice(0, 30), slice(60, 100), 30, 40),      # one chunk: 21 stored blocks, 81 segments
+                                             (slice(0, 30), slice(60, 100), 30, 40),      # one chunk: 21 stored blocks, 81 segments (6 of them counted for the code)
                                              (slice(40, 52), slice(8, 22), 4, 7)])        # odd shapes: rows of 7 cells
 def test_deflated_chunks_equal_the_restatement_and_inflate_to_the_daily_values(golden_case, rows, cols, cy, cx):
     from oracle import deflate_oracle as dorc
@@ -63,10 +63,11 @@ def test_deflated_chunks_equal_the_restatement_and_inflate_to_the_daily_values(g
     o = outs[0]
     for var in ("tmin", "tmax"):
         chunks = _tile_chunks(want["daily_" + var], cy, cx)
+        table = dorc.tile_table(want["daily_" + var], cy, cx)         # the variable's Huffman code, from every 16th segment of every chunk
         for c in sorted({0, len(chunks) // 2, len(chunks) - 1}):
             if chunks[c].size > 400000:
                 continue
-            assert o["deflated_" + var][c] == dorc.deflate_chunk(chunks[c]), (var, c)
+            assert o["deflated_" + var][c] == dorc.deflate_chunk(chunks[c], table), (var, c)
     sizes = [len(b) for b in o["deflated_tmin"]]
     assert max(sizes) <= 2 * nd * cy * cx + 5 * (nd * cy * cx // dorc.SEG + nd * cy * cx // 65535 + 2) + 11       # never longer than stored
 

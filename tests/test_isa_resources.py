@@ -79,4 +79,5 @@ def test_daily_tile_keeps_three_workgroups_per_cu(table):
 def test_no_kernel_uses_dynamic_scratch_unexpectedly(table):
     spilled = {k: r["scratch"] for k, r in table.items() if r["scratch"] > 0}
     assert set(spilled) <= {"k_uk<10, 2, 0>", "k_uk<10, 2, 1>", "k_uk<7, 2, 2>", "k_uk<10, 2, 2>", "k_ukw<4, 1>", "k_ukw<5, 1>",
-                            "k_ukwz<6, 1>"}, spilled
+                            "k_ukwz<6, 1>",
+                            "k_deflate_table"}, spilled       # (one thread per variable and tile: the 19-symbol alphabet's small arrays)

@@ -48,8 +48,8 @@ ks = res["kernels"]
 per_var = {k: v for k, v in ks.items()}
 res["per_tile"] = {
     "int16_bytes": int16,
-    "algorithmic_bytes": {"read": 2 * int16, "written": None if ratio is None else ratio * int16,
-                          "note": "every value is read by k_deflate_count and again by k_deflate_emit (2 bytes each time); the streams are written once"},
+    "algorithmic_bytes": {"read": (2 + 1.0 / 16) * int16, "written": None if ratio is None else ratio * int16,
+                          "note": "every value is read by k_deflate_count and again by k_deflate_emit (2 bytes each time), every 16th segment also by k_deflate_hist; the streams are written once"},
     "measured_bytes": {"read": 2 * sum(v.get("FETCH_SIZE_bytes_per_launch", 0.0) for v in per_var.values()),
                        "written": 2 * sum(v.get("WRITE_SIZE_bytes_per_launch", 0.0) for v in per_var.values()),
                        "note": "two launches of each kernel per tile (Tmin, Tmax)"},

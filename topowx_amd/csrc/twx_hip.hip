@@ -1679,7 +1679,7 @@ namespace {
 // per variable: block sizes + offsets (u32 each), Adler sums (4 u32), piece bits (256 u16) per segment; chunk sizes
 size_t df_small_bytes(const twx_stream *st)
 {
-    return (size_t)st->df_nchunk * st->df_nseg * (24 + 2 * TWX_DF_THREADS) + (size_t)st->df_nchunk * 8 + 5 * 256;
+    return (size_t)st->df_nchunk * st->df_nseg * (24 + 2 * TWX_DF_THREADS) + TWX_DF_NSYM * 4 + sizeof(DfTable) + 7 * 256;
 }
 
 // kernels of twx_deflate.h for the tile in device set d (after its daily values are final), sizes -> the slot's pinned table
@@ -1689,31 +1689,46 @@ int df_launch(twx_stream *st, int d, const GridDev &dev, int slot)
     EvScope ev(ctx, st->s_comp, EV_DEFLATE);
     const size_t per_var = (size_t)st->df_nchunk * st->df_nseg;
     char *small = st->df_small[d].as<char>();
-    int v = 0;
+    DfArgs args[2];
+    int nv = 0;
     for (int var = 0; var < 2; ++var) {
         const int16_t *daily = var == 0 ? dev.o.daily_tmin : dev.o.daily_tmax;
         if (!daily) continue;
         DfArgs a{};
         a.daily = reinterpret_cast<const uint16_t *>(daily);
-        a.out = st->df_out[d].as<uint8_t>() + (size_t)v * st->df_nchunk * st->df_slot;
-        char *cur = small + (size_t)v * df_small_bytes(st);
+        a.out = st->df_out[d].as<uint8_t>() + (size_t)nv * st->df_nchunk * st->df_slot;
+        char *cur = small + (size_t)nv * df_small_bytes(st);
         a.seg_bytes = carve<uint32_t>(cur, per_var);
         a.seg_off = carve<uint32_t>(cur, per_var);
         a.adl = carve<uint32_t>(cur, per_var * 4);
         a.piece_bits = carve<uint16_t>(cur, per_var * TWX_DF_THREADS);
+        a.hist = carve<uint32_t>(cur, TWX_DF_NSYM);
+        a.table = carve<DfTable>(cur, 1);
         // the chunk sizes go straight into the slot's pinned table (mapped host memory): a copy command on this stream would queue
         // behind the bulk copy-out of the tile before on the DMA engine and hold this tile's "kernels done" event back
-        a.chunk_bytes = st->df_sizes[slot] + (size_t)v * st->df_nchunk;
+        a.chunk_bytes = st->df_sizes[slot] + (size_t)nv * st->df_nchunk;
         a.N = st->df_N; a.slot_bytes = st->df_slot; a.lo_bytes = df_lo_bytes(st->df_N);
         a.Y = st->Y; a.X = st->X; a.cy = st->df_cy; a.cx = st->df_cx; a.ncx = st->X / st->df_cx; a.nseg = st->df_nseg;
-        const dim3 grid((unsigned)st->df_nchunk, (unsigned)st->df_nseg);     // (chunks fastest: twx_deflate.h)
-        const bool pairs = st->df_cx % 2 == 0 && st->X % 2 == 0;     // two neighbouring values per load
-        if (pairs) hipLaunchKernelGGL(k_deflate_count<2>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
-        else hipLaunchKernelGGL(k_deflate_count<1>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
-        hipLaunchKernelGGL(k_deflate_scan, dim3((unsigned)st->df_nchunk), dim3(TWX_DF_THREADS), 0, st->s_comp, a);
-        if (pairs) hipLaunchKernelGGL(k_deflate_emit<2>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
-        else hipLaunchKernelGGL(k_deflate_emit<1>, grid, dim3(TWX_DF_THREADS), 0, st->s_comp, a);
-        ++v;
+        args[nv++] = a;
+    }
+    const dim3 grid((unsigned)st->df_nchunk, (unsigned)st->df_nseg);     // (chunks fastest: twx_deflate.h)
+    const dim3 sgrid((unsigned)st->df_nchunk, (unsigned)((st->df_nseg + TWX_DF_SAMPLE - 1) / TWX_DF_SAMPLE));
+    const dim3 th(TWX_DF_THREADS);
+    const bool pairs = st->df_cx % 2 == 0 && st->X % 2 == 0;           // two neighbouring values per load
+    // the variables' Huffman codes: token counts of every 16th segment -> code lengths, codes, the block header (one work-group
+    // each, mostly one thread: both in ONE launch)
+    for (int v = 0; v < nv; ++v) {
+        HIPCHK(hipMemsetAsync(args[v].hist, 0, TWX_DF_NSYM * 4, st->s_comp));
+        if (pairs) hipLaunchKernelGGL(k_deflate_hist<2>, sgrid, th, 0, st->s_comp, args[v]);
+        else hipLaunchKernelGGL(k_deflate_hist<1>, sgrid, th, 0, st->s_comp, args[v]);
+    }
+    hipLaunchKernelGGL(k_deflate_table, dim3((unsigned)nv), th, 0, st->s_comp, args[0].hist, args[0].table, args[nv - 1].hist, args[nv - 1].table);
+    for (int v = 0; v < nv; ++v) {
+        if (pairs) hipLaunchKernelGGL(k_deflate_count<2>, grid, th, 0, st->s_comp, args[v]);
+        else hipLaunchKernelGGL(k_deflate_count<1>, grid, th, 0, st->s_comp, args[v]);
+        hipLaunchKernelGGL(k_deflate_scan, dim3((unsigned)st->df_nchunk), th, 0, st->s_comp, args[v]);
+        if (pairs) hipLaunchKernelGGL(k_deflate_emit<2>, grid, th, 0, st->s_comp, args[v]);
+        else hipLaunchKernelGGL(k_deflate_emit<1>, grid, th, 0, st->s_comp, args[v]);
     }
     HIPCHK(hipGetLastError());
     return 0;
