@@ -50,10 +50,10 @@ res["per_tile"] = {
     "int16_bytes": int16,
     "algorithmic_bytes": {"read": (2 + 1.0 / 16) * int16, "written": None if ratio is None else ratio * int16,
                           "note": "every value is read by k_deflate_count and again by k_deflate_emit (2 bytes each time), every 16th segment also by k_deflate_hist; the streams are written once"},
-    "measured_bytes": {"read": 2 * sum(v.get("FETCH_SIZE_bytes_per_launch", 0.0) for v in per_var.values()),
-                       "written": 2 * sum(v.get("WRITE_SIZE_bytes_per_launch", 0.0) for v in per_var.values()),
-                       "note": "two launches of each kernel per tile (Tmin, Tmax)"},
-    "kernel_us": 2 * sum(v.get("avg_us", 0.0) for v in per_var.values())}
+    "measured_bytes": {"read": sum(v.get("FETCH_SIZE_bytes_per_launch", 0.0) * (1 if k == "k_deflate_table" else 2) for k, v in per_var.items()),
+                       "written": sum(v.get("WRITE_SIZE_bytes_per_launch", 0.0) * (1 if k == "k_deflate_table" else 2) for k, v in per_var.items()),
+                       "note": "two launches of each kernel per tile (Tmin, Tmax); k_deflate_table: one, both variables"},
+    "kernel_us": sum(v.get("avg_us", 0.0) * v.get("calls", 0) for v in per_var.values()) / max(1, ks.get("k_deflate_scan", {}).get("calls", 2) // 2)}
 alg = res["per_tile"]["algorithmic_bytes"]
 if alg["written"] is not None and res["per_tile"]["kernel_us"] > 0:
     res["per_tile"]["achieved_GBps_algorithmic"] = (alg["read"] + alg["written"]) / res["per_tile"]["kernel_us"] / 1e3
