@@ -1618,6 +1618,8 @@ struct twx_stream {
     std::vector<GridDev> df_dev;                  // per slot: the device images its deferred copy-out reads
     std::vector<int> df_set;                      // per slot: device set of its tile
     int df_pending[2] = {-1, -1};                 // per device set: slot whose copy-out has not been enqueued yet
+    hipStream_t s_defl = nullptr;                 // the deflate kernels' own stream: tile t is deflated while tile t + 1 is interpolated
+    std::vector<hipEvent_t> ev_k;                 // per slot: the tile's interpolation kernels are done (on s_comp)
 };
 
 void twx_stream_destroy(twx_stream *st);
@@ -1662,6 +1664,8 @@ void twx_stream_destroy(twx_stream *st)
     }
     if (st->s_comp) (void)hipStreamSynchronize(st->s_comp);
     if (st->s_copy) (void)hipStreamSynchronize(st->s_copy);
+    if (st->s_defl) { (void)hipStreamSynchronize(st->s_defl); (void)hipStreamDestroy(st->s_defl); }
+    for (hipEvent_t e : st->ev_k) if (e) (void)hipEventDestroy(e);
     for (int d = 0; d < 2; ++d) { st->din[d].release(); st->dout[d].release(); if (st->ev_free[d]) (void)hipEventDestroy(st->ev_free[d]); }
     for (char *p : st->hin) if (p) (void)hipHostFree(p);
     for (char *p : st->hout) if (p) (void)hipHostFree(p);
@@ -1686,7 +1690,7 @@ size_t df_small_bytes(const twx_stream *st)
 int df_launch(twx_stream *st, int d, const GridDev &dev, int slot)
 {
     twx_ctx *ctx = st->ctx;
-    EvScope ev(ctx, st->s_comp, EV_DEFLATE);
+    EvScope ev(ctx, st->s_defl, EV_DEFLATE);
     const size_t per_var = (size_t)st->df_nchunk * st->df_nseg;
     char *small = st->df_small[d].as<char>();
     DfArgs args[2];
@@ -1718,17 +1722,17 @@ int df_launch(twx_stream *st, int d, const GridDev &dev, int slot)
     // the variables' Huffman codes: token counts of every 16th segment -> code lengths, codes, the block header (one work-group
     // each, mostly one thread: both in ONE launch)
     for (int v = 0; v < nv; ++v) {
-        HIPCHK(hipMemsetAsync(args[v].hist, 0, TWX_DF_NSYM * 4, st->s_comp));
-        if (pairs) hipLaunchKernelGGL(k_deflate_hist<2>, sgrid, th, 0, st->s_comp, args[v]);
-        else hipLaunchKernelGGL(k_deflate_hist<1>, sgrid, th, 0, st->s_comp, args[v]);
+        HIPCHK(hipMemsetAsync(args[v].hist, 0, TWX_DF_NSYM * 4, st->s_defl));
+        if (pairs) hipLaunchKernelGGL(k_deflate_hist<2>, sgrid, th, 0, st->s_defl, args[v]);
+        else hipLaunchKernelGGL(k_deflate_hist<1>, sgrid, th, 0, st->s_defl, args[v]);
     }
-    hipLaunchKernelGGL(k_deflate_table, dim3((unsigned)nv), th, 0, st->s_comp, args[0].hist, args[0].table, args[nv - 1].hist, args[nv - 1].table);
+    hipLaunchKernelGGL(k_deflate_table, dim3((unsigned)nv), th, 0, st->s_defl, args[0].hist, args[0].table, args[nv - 1].hist, args[nv - 1].table);
     for (int v = 0; v < nv; ++v) {
-        if (pairs) hipLaunchKernelGGL(k_deflate_count<2>, grid, th, 0, st->s_comp, args[v]);
-        else hipLaunchKernelGGL(k_deflate_count<1>, grid, th, 0, st->s_comp, args[v]);
-        hipLaunchKernelGGL(k_deflate_scan, dim3((unsigned)st->df_nchunk), th, 0, st->s_comp, args[v]);
-        if (pairs) hipLaunchKernelGGL(k_deflate_emit<2>, grid, th, 0, st->s_comp, args[v]);
-        else hipLaunchKernelGGL(k_deflate_emit<1>, grid, th, 0, st->s_comp, args[v]);
+        if (pairs) hipLaunchKernelGGL(k_deflate_count<2>, grid, th, 0, st->s_defl, args[v]);
+        else hipLaunchKernelGGL(k_deflate_count<1>, grid, th, 0, st->s_defl, args[v]);
+        hipLaunchKernelGGL(k_deflate_scan, dim3((unsigned)st->df_nchunk), th, 0, st->s_defl, args[v]);
+        if (pairs) hipLaunchKernelGGL(k_deflate_emit<2>, grid, th, 0, st->s_defl, args[v]);
+        else hipLaunchKernelGGL(k_deflate_emit<1>, grid, th, 0, st->s_defl, args[v]);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1826,8 +1830,12 @@ int twx_stream_submit(twx_stream *st, int slot, const twx_grid *g)
         // the chunk streams of both variables, and their sizes to the slot's pinned table; the copy-out itself is enqueued by
         // twx_stream_wait_deflated (it needs the sizes) -- nothing goes on the copy stream here, so that the copy-out of tile t
         // is never queued behind a wait for the kernels of tile t + 1
+        // (on the deflate kernels' own stream: they wait on memory, the next tile's kriging kernels on the fp64 pipes -- side by
+        // side the tile's device time is again what it was without them, and precision="auto" keeps the fp64 build)
+        HIPCHK(hipEventRecord(st->ev_k[slot], st->s_comp));
+        HIPCHK(hipStreamWaitEvent(st->s_defl, st->ev_k[slot], 0));
         if (df_launch(st, d, dev, slot)) return -1;
-        HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_comp));
+        HIPCHK(hipEventRecord(st->ev_comp[slot], st->s_defl));
         st->df_dev[slot] = dev;
         st->df_set[slot] = d;
         st->df_pending[d] = slot;
@@ -1913,6 +1921,9 @@ int twx_stream_deflate(twx_stream *st, int chunk_y, int chunk_x)
              hipHostMalloc((void **)&st->df_host[i], out_bytes, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void **)&st->df_sizes[i], (size_t)st->df_nvar * st->df_nchunk * 8, hipHostMallocDefault) == hipSuccess;
     }
+    ok = ok && hipStreamCreateWithFlags(&st->s_defl, hipStreamNonBlocking) == hipSuccess;
+    st->ev_k.assign(st->nslots, nullptr);
+    for (int i = 0; ok && i < st->nslots; ++i) ok = hipEventCreate(&st->ev_k[i]) == hipSuccess;
     if (!ok) return fail(ctx, "twx_stream_deflate: allocation failed (chunk slots / pinned stream blocks)");
     st->df_cy = chunk_y; st->df_cx = chunk_x;
     return 0;
@@ -1942,9 +1953,9 @@ int twx_stream_wait_deflated(twx_stream *st, int slot, twx_grid_out *views, twx_
         }
     }
     *streams = r;
-    if (device_ms) {
+    if (device_ms) {      // (the tile's interpolation kernels: its deflate kernels run beside the next tile's)
         *device_ms = 0.f;
-        if (st->views[slot].o.status) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
+        if (st->views[slot].o.status) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_k[slot]));
     }
     return 0;
 }
@@ -1958,7 +1969,7 @@ int twx_stream_times(twx_stream *st, int slot, float *device_ms, float *copy_ms)
     if (!st->views[slot].o.status) return fail(ctx, "twx_stream_times: nothing submitted in this slot");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipEventSynchronize(st->ev_done[slot]));
-    if (device_ms) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->ev_comp[slot]));
+    if (device_ms) HIPCHK(hipEventElapsedTime(device_ms, st->ev_start[slot], st->df_cy ? st->ev_k[slot] : st->ev_comp[slot]));
     if (copy_ms) HIPCHK(hipEventElapsedTime(copy_ms, st->ev_copy0[slot], st->ev_done[slot]));
     return 0;
 }
