@@ -47,3 +47,35 @@ def test_driver_streamed_tiles_and_refusal(tmp_path):
     t0 = np.load(os.path.join(d, "tile00000.npz"))
     m = np.load(out)
     assert np.array_equal(m["norm_tmin"][:, :50, :50], t0["norm_tmin"]) and np.array_equal(m["se_tmax"][:, :50, :50], t0["se_tmax"])
+
+
+@pytest.mark.parametrize("deflate", [False, True])
+def test_driver_writes_netcdf4_tile_files(tmp_path, deflate):
+    """--nc-dir: every tile into the reference's NetCDF-4 tile files through ncio.TileSink; --deflate: the daily variables with
+    shuffle + deflate, their chunk bytes formed on the GPU.  Files == the whole-grid call."""
+    from topowx_amd import _lib, h5nc, ncio, synth
+    if not h5nc.available():
+        pytest.skip("libhdf5 not loadable")
+    d = str(tmp_path / "nc")
+    p = _driver("--config", "C1", "--tile", "50", "--daily", "--nc-dir", d, "--chunk", "25", "--precision", "fast", *(["--deflate"] if deflate else []))
+    assert p.returncode == 0, p.stderr[-2000:]
+    grid, tmin, tmax = synth.make_case("C1", with_obs=True)
+    ctx = _lib.Context()
+    ctx.set_stations(_lib.TMIN, tmin)
+    ctx.set_stations(_lib.TMAX, tmax)
+    want = ctx.interp_grid(grid, daily=True)
+    ctx.close()
+    tiles = sorted(os.listdir(d))
+    assert len(tiles) == 4
+    from topowx_amd.interp import Tiler
+    info = Tiler(grid, 50, 50, 25, 25, process_tiles=()).build_tile_grid_info()
+    for k in range(4):
+        tid = info.get_tile_id(k)
+        r0, c0 = info.tile_rc[tid] if hasattr(info, "tile_rc") else (50 * (k // 2), 50 * (k % 2))
+        for var in ("tmin", "tmax"):
+            t = ncio.read_tile(os.path.join(d, tid, "%s_%s.nc" % (tid, var)), var)
+            assert np.array_equal(t["daily"], want["daily_" + var][:, r0:r0 + 50, c0:c0 + 50]), (tid, var)
+            assert np.array_equal(t["norm"], want["norm_" + var][:, r0:r0 + 50, c0:c0 + 50])
+        ds = h5nc.Dataset(os.path.join(d, tid, "%s_tmin.nc" % tid))
+        assert ds.variables["tmin"].chunking() == [tmin.days.size, 25, 25] and ds.variables["tmin"].filters()["zlib"] == deflate
+        ds.close()

@@ -385,6 +385,12 @@ def main():
     ap.add_argument("--gather", action="store_true", help="assemble the normals mosaic on rank 0 (RCCL gather)")
     ap.add_argument("--out", default=None, help=".npz for rank 0's mosaic")
     ap.add_argument("--tile-dir", default=None, help="write every tile of this rank as <dir>/tileNNNNN.npz while the next one runs")
+    ap.add_argument("--nc-dir", default=None, help="(with --daily) write every tile of this rank into the reference's NetCDF-4 tile files "
+                                                   "<dir>/<tile_id>/<tile_id>_<var>.nc while the next one runs (ncio.TileSink)")
+    ap.add_argument("--precision", default="auto", choices=("auto", "fast", "exact"), help="--nc-dir / --tile-dir: PrecisionPolicy of the streamed run")
+    ap.add_argument("--chunk", type=int, default=50, help="chunk edge of the tile files (tiling.py:453-486: 50)")
+    ap.add_argument("--deflate", action="store_true", help="--nc-dir: store the daily variables with shuffle + deflate, the chunk bytes "
+                                                           "formed on the GPU (twx_stream_deflate)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -394,7 +400,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     grid, tmin, tmax = synth.make_case(args.config, with_obs=args.daily)
     even = grid["mask"].shape[0] % args.tile == 0 and grid["mask"].shape[1] % args.tile == 0
-    if args.tile_dir and not even:
+    if args.nc_dir and not args.daily:
+        raise SystemExit("--nc-dir writes the daily tile files: add --daily")
+    if (args.tile_dir or args.nc_dir) and not even:
         # the streamed writer works on tiles of ONE shape (twx_stream_*): say so before anything is computed
         raise SystemExit("--tile-dir needs a grid that --tile divides evenly (grid %dx%d, tile %d): choose another "
                          "--tile or drop --tile-dir" % (grid["mask"].shape + (args.tile,)))
@@ -408,7 +416,19 @@ def main():
     tiles = tile_list(grid["mask"], args.tile, args.tile)
     assignment = assign_tiles(tiles, world)
     t0 = time.perf_counter()
-    if args.tile_dir:
+    if args.nc_dir:
+        # streamed into NetCDF-4 tile files; --deflate: the GPU hands over chunk bytes, the sink appends them
+        from . import ncio
+        from .interp import Tiler
+        if args.tile % args.chunk:
+            raise SystemExit("--chunk must divide --tile")
+        info = Tiler(grid, args.tile, args.tile, args.chunk, args.chunk, process_tiles=()).build_tile_grid_info()
+        sink = ncio.TileSink(info, args.nc_dir, tmin.days, zlib=args.deflate, order=[t[0] for t in assignment[rank]])
+        _, _, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=True, sink=sink, precision=args.precision,
+                                             deflate_chunks=(args.chunk, args.chunk) if args.deflate else None)
+        sink.close()
+        mosaic = None
+    elif args.tile_dir:
         # streamed: outputs of tile t travel to the host and to disk while tile t + 1 is computed; the normals (small)
         # are kept for --gather
         os.makedirs(args.tile_dir, exist_ok=True)
@@ -418,7 +438,7 @@ def main():
             np.savez(os.path.join(args.tile_dir, "tile%05d.npz" % k), **{n: v for n, v in arrays.items() if hasattr(v, "shape")})
             if args.gather:
                 mine[k] = {n: np.array(arrays[n]) for n in NORMAL_KEYS}
-        _, _, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=args.daily, sink=sink)
+        _, _, dev_ms = interp_tiles_streamed(ctx, grid, assignment[rank], args.tile, args.tile, daily=args.daily, sink=sink, precision=args.precision)
         mosaic = gather_mosaic(mine, assignment, grid["mask"].shape, args.tile, args.tile, NORMAL_KEYS, rank, world,
                                device="cuda:%d" % local) if args.gather else None
     elif args.daily:
