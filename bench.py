@@ -765,6 +765,11 @@ def c4_deflated_record(ctx, grid, mine, T, nd, args, kept, wall_int16, bytes_int
            "d2h_bytes": acc["bytes"], "d2h_bytes_int16_run": bytes_int16, "d2h_GBps": acc["bytes"] / wall / 1e9,
            "stream_bytes_over_int16": acc["stream_bytes"] / int16_bytes, "int16_equivalent_GBps": int16_bytes / wall / 1e9,
            "device_ms_total": dev_ms, "deflate_kernels_ms_last_tile": deflate_ms,
+           # the deflate kernels against their roofline (HBM): every value read by the count and the emit pass, every 16th segment by
+           # the histogram pass, the streams written once (counters: profiles/r6_deflate_kernels.json)
+           "deflate_kernels_roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                        "achieved": ((2 + 1 / 16.0) + acc["stream_bytes"] / int16_bytes) * 2 * nd * T * T * 2 / max(deflate_ms, 1e-9) / 1e6,
+                                        "note": "algorithmic bytes of one full tile / the last tile's deflate kernel time (HIP events)"},
            "precision": {k: v for k, v in plog.items() if k != "tile_modes"}}
     # zlib -- the decoder inside libhdf5 -- on the kept cells' chunks
     ndiff, worst, n = 0, 0, 0
@@ -781,6 +786,7 @@ def c4_deflated_record(ctx, grid, mine, T, nd, args, kept, wall_int16, bytes_int
             n += nd
     # (the two runs may end in different precisions -- "auto" decides by each run's own device / copy-out times --: then the
     # default build's ~1e-5 of values one count off show here; the same precision gives the same bits)
+    rec["deflate_kernels_roofline"]["frac"] = rec["deflate_kernels_roofline"]["achieved"] / HBM_PEAK_GBS
     rec["inflated_by_zlib"] = {"cells": len(kept), "int16_values": n, "differing_from_the_int16_run": ndiff, "max_abs_lsb": worst,
                                "precision_of_the_int16_run": int16_precision, "precision_of_this_run": plog.get("precision")}
     return rec
