@@ -141,3 +141,90 @@ def test_precision_policy_decides_once_on_the_median_of_three_tiles():
         assert p.mode == req and p.decided and c.calls == [req] and p.decision == "as requested"
     with pytest.raises(ValueError):
         driver.PrecisionPolicy(Ctx(), "double")
+
+
+def test_streamed_driver_loop_on_a_fake_stream():
+    """driver.interp_tiles_streamed's host logic without a GPU (a fake context / stream): every tile reaches the sink once, in order
+    with one writer; the stream is asked for with keep=True and handed back open; two writers get two more slots; deflate_chunks
+    and the precision reach the stream / context; a failing sink stops the run early and is reported, the stream survives; a
+    failing submit closes the stream (its state is unknown); the trace holds one submit and one wait per tile."""
+    import threading
+    from topowx_amd import driver
+
+    class Stream(object):
+        def __init__(self, ctx, **kw):
+            self.ctx, self.kw, self.open, self.inflight, self.fail_at = ctx, kw, True, {}, None
+            self.nsub = 0
+
+        def submit(self, slot, grid, rows, cols):
+            assert self.open and slot not in self.inflight and 0 <= slot < self.kw["nslots"]
+            if self.fail_at is not None and self.nsub == self.fail_at:
+                raise RuntimeError("device lost")
+            self.inflight[slot] = (rows.start, cols.start, self.ctx.mode)
+            self.nsub += 1
+
+        def wait(self, slot):
+            r, c, mode = self.inflight.pop(slot)
+            out = {"status": np.zeros((2, 2), np.int32), "origin": np.array([r, c]), "device_ms": 5.0}
+            if self.kw.get("deflate_chunks"):
+                out["deflated_tmin"], out["deflate_chunks"] = [b"x"], self.kw["deflate_chunks"]
+            return out
+
+        def times(self, slot):
+            return 5.0, 20.0
+
+        def close(self):
+            self.open = False
+
+    class Ctx(object):
+        def __init__(self):
+            self.mode, self.streams, self.asked = None, {}, []
+
+        def set_precision(self, mode):
+            self.mode = mode
+
+        def stream(self, Y, X, variables=("tmin", "tmax"), daily=False, nslots=2, deflate_chunks=None, keep=False):
+            self.asked.append(keep)
+            key = (Y, X, daily, nslots, deflate_chunks)
+            if key not in self.streams or not self.streams[key].open:
+                self.streams[key] = Stream(self, nslots=nslots, deflate_chunks=deflate_chunks)
+            return self.streams[key]
+
+    tiles = [(k, 10 * k, 20 * k, 4) for k in range(9)]
+    ctx = Ctx()
+    seen, lock = [], threading.Lock()
+
+    def sink(k, arrays):
+        with lock:
+            seen.append((k, int(arrays["origin"][0]), int(arrays["origin"][1])))
+    trace, log = [], {}
+    res, secs, dev_ms = driver.interp_tiles_streamed(ctx, None, tiles, 2, 2, daily=True, sink=sink, precision="exact", trace=trace, log=log)
+    assert res is None and seen == [(k, 10 * k, 20 * k) for k in range(9)] and dev_ms == 45.0 and secs > 0
+    assert ctx.asked == [True] and ctx.mode == "fast" and log["tiles_exact"] == 9          # handed back in the fast mode
+    (st,) = ctx.streams.values()
+    assert st.open and not st.inflight and st.kw["nslots"] == 3
+    assert sorted(t[1] for t in trace) == ["submit"] * 9 + ["wait"] * 9
+    # again: the same stream; two writers: two more slots, another stream; the default sink collects copies (deflated lists too)
+    driver.interp_tiles_streamed(ctx, None, tiles[:2], 2, 2, daily=True, sink=sink, precision="fast")
+    assert len(ctx.streams) == 1 and st.nsub == 11
+    got, _, _ = driver.interp_tiles_streamed(ctx, None, tiles[:4], 2, 2, daily=True, precision="fast", writer_threads=2, deflate_chunks=(1, 2))
+    assert len(ctx.streams) == 2 and sorted(got) == [0, 1, 2, 3] and got[2]["deflated_tmin"] == [b"x"] and "deflate_chunks" not in got[2]
+    st2 = [s for s in ctx.streams.values() if s is not st][0]
+    assert st2.kw == {"nslots": 4, "deflate_chunks": (1, 2)} and st2.open
+    # a failing sink: reported, the run stops early, the stream is still good
+    del seen[:]
+
+    def bad(k, arrays):
+        seen.append(k)
+        if k == 2:
+            raise IOError("disk full")
+    with pytest.raises(IOError, match="disk full"):
+        driver.interp_tiles_streamed(ctx, None, tiles, 2, 2, daily=True, sink=bad, precision="fast")
+    assert seen[:3] == [0, 1, 2] and len(seen) < 9 and st.open and not st.inflight
+    # a failing submit: the exception reaches the caller and the stream is closed, the next run gets a new one
+    st.fail_at = st.nsub + 3
+    with pytest.raises(RuntimeError, match="device lost"):
+        driver.interp_tiles_streamed(ctx, None, tiles, 2, 2, daily=True, sink=sink, precision="fast")
+    assert not st.open
+    driver.interp_tiles_streamed(ctx, None, tiles[:1], 2, 2, daily=True, sink=sink, precision="fast")
+    assert [s for s in ctx.streams.values() if s.kw["nslots"] == 3][0] is not st
