@@ -155,3 +155,48 @@ def test_device_table_builder_equals_the_restatement(codes_exe, tmp_path, kind):
     assert nbits == hdr.nbits()
     val = int.from_bytes(bytes(hdr.out), "little") | (hdr.acc << (8 * len(hdr.out)))
     assert sum(w << (32 * i) for i, w in enumerate(words)) == val
+
+
+def test_property_any_int16_tile_round_trips():
+    """hypothesis: arbitrary int16 tiles (runs, noise, extremes), arbitrary chunk shapes that divide them -> every chunk's stream
+    is inflated by zlib to the chunk, never longer than stored + block headers."""
+    from hypothesis import given, settings, strategies as stg
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=40, deadline=None)
+    @given(stg.data())
+    def run(data):
+        cy, cx = data.draw(stg.integers(1, 4)), data.draw(stg.integers(1, 5))
+        ny, nx, nd = data.draw(stg.integers(1, 3)), data.draw(stg.integers(1, 3)), data.draw(stg.integers(1, 60))
+        elems = stg.one_of(stg.integers(-32768, 32767), stg.sampled_from([-32767, 0, 255, 256, -1, 1234]))
+        d = data.draw(hnp.arrays(np.int16, (nd, ny * cy, nx * cx), elements=elems))
+        if data.draw(stg.booleans()):
+            d = np.repeat(d, 3, axis=0)[:nd]                   # runs along the day axis too
+        blobs = dorc.deflate_tile(d, cy, cx)
+        assert len(blobs) == ny * nx
+        n = d.shape[0] * cy * cx
+        for blob, chunk in zip(blobs, dorc._chunks(d, cy, cx)):
+            assert np.array_equal(dorc.inflate_chunk(blob, d.shape[0], cy, cx), chunk)
+            assert len(blob) <= 2 + 2 * n + 5 * (-(-n // 65535) + -(-n // dorc.SEG)) + 9
+    run()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_table_builder_on_random_counts(codes_exe, tmp_path, seed):
+    """df_build_table against the restatement on random sparse / dense / heavy-tailed counts (ties, zeros, one dominant symbol)."""
+    rng = np.random.default_rng(100 + seed)
+    kind = seed % 3
+    if kind == 0:
+        hist = (rng.integers(0, 50, dorc.NSYM) * (rng.random(dorc.NSYM) < 0.1)).tolist()              # sparse, many ties
+    elif kind == 1:
+        hist = rng.integers(0, 2 ** 20, dorc.NSYM).tolist()
+    else:
+        hist = np.floor(rng.pareto(0.4, dorc.NSYM) * 3).clip(0, 2 ** 31 - 2).astype(np.int64).tolist()     # heavy tail: deep trees
+    p = tmp_path / "hist.txt"
+    p.write_text(" ".join(str(int(h)) for h in hist))
+    out = subprocess.run([codes_exe, "table", str(p)], check=True, capture_output=True, text=True).stdout.split("\n")
+    lens, codes, hdr = dorc.make_table(hist)
+    rows = [ln.split() for ln in out if ln.startswith("C ")]
+    assert [int(f[2]) for f in rows] == lens
+    assert [int(f[3]) for f in rows] == [int(format(c, "0%db" % l)[::-1], 2) for c, l in zip(codes, lens)]
+    assert int([ln.split()[1] for ln in out if ln.startswith("H ")][0]) == hdr.nbits()
